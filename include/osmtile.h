@@ -1,0 +1,190 @@
+/*
+ * osmtile.h — C ABI of the MI355X tile rasterizer (libosmtile.so).
+ *
+ * Drop-in boundary for ONE hot path of dfyz/osm-renderer: the per-tile
+ * project -> fill -> stroke -> blend -> RGB(A) pipeline.  The reference has no
+ * FFI of its own (pure Rust crate); every entry point below cites the
+ * reference interface (path:line under /root/reference) it stands in for.
+ * INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all structs are POD with fixed layout;
+ *   - the caller owns every input/output buffer for the duration of a call
+ *     (borrowed, never retained — the Rust `&` / `&mut` of the reference);
+ *   - every function returns an osmt_status (0 = OK, negative = error) unless
+ *     stated; the message of the last error on the calling thread is
+ *     available from osmt_last_error(); no exception crosses this boundary;
+ *   - geometry outside the tile is not an error: pixels outside the drawable
+ *     box are silently dropped (src/draw/tile_pixels.rs:107-111,191-195);
+ *   - pixel coordinates are tile-relative, already multiplied by `scale`,
+ *     y down; W = H = 256*scale (src/tile.rs:6, src/draw/tile_pixels.rs:57-66).
+ */
+#ifndef OSMTILE_H
+#define OSMTILE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSMT_TILE_SIZE 256u /* src/tile.rs:6  TILE_SIZE */
+#define OSMT_MAX_ZOOM 18u   /* src/tile.rs:5  MAX_ZOOM  */
+#define OSMT_MAX_SCALE 4u
+#define OSMT_MAX_DASHES 16u /* dash-pattern entries per op (stylesheets use <= 6) */
+
+typedef enum osmt_status {
+    OSMT_OK = 0,
+    OSMT_INVALID_ARG = -1,
+    OSMT_OOM = -2,
+    OSMT_HIP_ERROR = -3,
+    OSMT_UNSUPPORTED = -4,
+    OSMT_NO_DEVICE = -5
+} osmt_status;
+
+/* One draw_one_area() call of the reference == one op == one "generation"
+ * (src/draw/drawer.rs:156-219, bump_generation at :218).  Casing is a STROKE
+ * op with opacity 1.0 emitted at the casing-pass position (drawer.rs:186-201). */
+typedef enum osmt_op_kind {
+    OSMT_OP_NONE = 0,       /* draws nothing (generation bump only)            */
+    OSMT_OP_FILL_COLOR = 1, /* fill_contour(.., Filler::Color, opacity)  fill.rs:16 */
+    OSMT_OP_FILL_IMAGE = 2, /* fill_contour(.., Filler::Image, _)        fill.rs:36-40 */
+    OSMT_OP_STROKE = 3      /* draw_lines(..)                            line.rs:9-61 */
+} osmt_op_kind;
+
+/* Option<LineCap>  (src/mapcss/styler.rs:11-16) */
+typedef enum osmt_line_cap {
+    OSMT_CAP_NONE = 0,
+    OSMT_CAP_BUTT = 1,
+    OSMT_CAP_ROUND = 2,
+    OSMT_CAP_SQUARE = 3
+} osmt_line_cap;
+
+typedef enum osmt_coord_kind {
+    OSMT_COORD_LATLON_F64 = 0, /* (lat, lon) degrees; projected on the GPU (tile.rs:88-106, point.rs:11-19) */
+    OSMT_COORD_POINT_I32 = 1   /* already-projected draw::point::Point {x, y} (point.rs:5-8) */
+} osmt_coord_kind;
+
+/* 64-byte op header. */
+typedef struct osmt_op {
+    uint8_t kind;                /* osmt_op_kind                                              */
+    uint8_t cap;                 /* osmt_line_cap (STROKE)                       line.rs:15   */
+    uint8_t use_caps_for_dashes; /* Styler::use_caps_for_dashes (STROKE)         line.rs:16   */
+    uint8_t has_dashes;          /* 1 = Some(dashes), 0 = None (STROKE)          line.rs:14   */
+    uint8_t color[3];            /* mapcss::color::Color {r,g,b}                 color.rs:2-6 */
+    uint8_t _pad0;
+    double opacity;              /* fill_opacity / opacity (1.0 when the style has none; drawer.rs:169) */
+    double width;                /* STROKE: line width, already * scale          drawer.rs:191,206 */
+    uint32_t n_dashes;           /* entries in the dash pattern (<= OSMT_MAX_DASHES)          */
+    uint32_t dashes_off;         /* first entry in osmt_batch.dashes (already * scale; drawer.rs:171-172) */
+    uint32_t n_rings;            /* Way: 1; Multipolygon: polygon_count()        point_pairs.rs:36-40 */
+    uint32_t ring_off;           /* first entry in osmt_batch.rings                           */
+    uint32_t image_id;           /* FILL_IMAGE: id from osmt_register_image                   */
+    uint32_t _reserved[5];
+} osmt_op;
+
+/* One ring = consecutive nodes of a Way / Polygon; edges are (P[i-1], P[i]),
+ * i = 1..n_pts-1 (point_pairs.rs:11-22).  A multipolygon's rings share ONE
+ * running edge index (fill.rs:19). */
+typedef struct osmt_ring {
+    uint32_t first_pt; /* index into osmt_batch.latlon / .points */
+    uint32_t n_pts;
+} osmt_ring;
+
+/* One tile == one Drawer::draw_to_pixels() call (drawer.rs:60-131), minus labels. */
+typedef struct osmt_tile_job {
+    uint32_t x, y;         /* tile::Tile {x, y}        tile.rs:9-13 */
+    uint8_t zoom;          /* tile::Tile {zoom}                      */
+    uint8_t has_canvas;    /* 0: canvas = opaque black (tile_pixels.rs:231-236) */
+    uint8_t canvas_rgb[3]; /* Styler::canvas_fill_color (tile_pixels.rs:89-93)  */
+    uint8_t _pad[3];
+    uint32_t n_ops;  /* ops of this tile, in draw (= generation) order  */
+    uint32_t op_off; /* first op in osmt_batch.ops                      */
+    uint32_t n_pts;  /* the tile's points are one contiguous pool range */
+    uint32_t pt_off;
+} osmt_tile_job;
+
+/* A batch of tiles sharing flat pools (display list).  All indices absolute. */
+typedef struct osmt_batch {
+    const osmt_tile_job* jobs;
+    size_t n_jobs;
+    const osmt_op* ops;
+    size_t n_ops;
+    const osmt_ring* rings;
+    size_t n_rings;
+    uint32_t coord_kind;  /* osmt_coord_kind: which of the two pools below is used */
+    uint32_t scale;       /* integer scale: 1 or 2 (.. OSMT_MAX_SCALE); http_server.rs:250-258 */
+    const double* latlon; /* [n_pts][2] = (lat, lon) degrees   (coords.rs:1-14) */
+    const int32_t* points; /* [n_pts][2] = (x, y)               (point.rs:5-8)   */
+    size_t n_pts;
+    const double* dashes; /* dash pool, already * scale */
+    size_t n_dashes;
+} osmt_batch;
+
+typedef struct osmt_config {
+    int32_t device; /* HIP device ordinal */
+    uint32_t flags; /* reserved, 0 */
+} osmt_config;
+
+typedef struct osmt_ctx osmt_ctx;     /* one per GPU; analogue of Drawer + worker pool state */
+typedef struct osmt_scene osmt_scene; /* a batch resident in HBM + its workspace              */
+
+/* ---- lifecycle --------------------------------------------------------- */
+/* Drawer::new (drawer.rs:33-38) + per-worker TilePixels::new (tile_pixels.rs:57-87). */
+int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx);
+void osmt_destroy(osmt_ctx* ctx);
+/* anyhow::Error text (http_server.rs:127-132 prints it); thread-local, never NULL. */
+const char* osmt_last_error(void);
+/* Library / ABI version: (major << 16) | minor. */
+uint32_t osmt_version(void);
+
+/* ---- icons for Filler::Image ------------------------------------------- */
+/* Icon::load result (icon.rs:14-58): straight-alpha RGBA8 pixels, row-major;
+ * stored premultiplied exactly as RgbaColor::from_components (tile_pixels.rs:21-23). */
+int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_image_id);
+
+/* ---- whole path, host buffers (Drawer::draw_to_pixels, drawer.rs:60-131) -- */
+/* out_rgba: n_jobs tiles of (256*scale)^2 RGBA8 pixels (A = 255), tile i at
+ * out_rgba + i*out_tile_stride_bytes, rows tightly packed
+ * (TileRenderedPixels, drawer.rs:27-30; to_rgb_triples, tile_pixels.rs:164-181). */
+int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba, size_t out_tile_stride_bytes);
+
+/* ---- whole path, HBM-resident (the fast path) --------------------------- */
+int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* batch, osmt_scene** out_scene);
+void osmt_scene_free(osmt_scene* scene);
+/* d_out_rgba: DEVICE pointer, same layout as osmt_render_batch's out_rgba.
+ * stream: hipStream_t (NULL = default stream).  Asynchronous w.r.t. the host. */
+int osmt_render_scene(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t out_tile_stride_bytes, void* stream);
+/* Same, but returns the un-quantised canvas: d_out_f64 = [n_jobs][H][W][4]
+ * premultiplied f64 RGBA == TilePixels::pixels of the centre tile after
+ * blend_unfinished_pixels(false) (tile_pixels.rs:154-158) — what the label pass
+ * of the reference would continue from. */
+int osmt_render_scene_f64(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, void* stream);
+/* Individual stages of osmt_render_scene (for profiling/tests): 1 = project
+ * (Point::from_node), 2 = per-op extents + traveled distances, 4 = raster. */
+int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba,
+                             size_t out_tile_stride_bytes, void* stream);
+/* Copies the projected integer points of the scene back: xy = [n_pts][2]. */
+int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* scene, int32_t* xy);
+
+/* ---- projection only (tile.rs:88-106 + point.rs:11-19) ------------------ */
+/* xy[i] = round(coords_to_xy_tile_relative(latlon[i], tile) * scale) as i32 */
+int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tile_x, uint32_t tile_y,
+                 double scale, int32_t* xy);
+
+/* ---- layer compositing only (tile_pixels.rs:205-223 + :164-181) ---------- */
+/* planes: [n][L][H][W][4] premultiplied f64 RGBA (NextPixel.color of L
+ * successive generations); canvas_rgba: premultiplied f64[4]; result per pixel:
+ * dst = canvas; for l in 0..L: dst = src_l + (1 - src_l.a) * dst; then
+ * un-premultiply + truncate to u8 -> out_rgba [n][H][W][4], A = 255. */
+int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas_rgba[4], uint32_t n, uint32_t L,
+                   uint32_t W, uint32_t H, uint8_t* out_rgba);
+/* DEVICE pointers; asynchronous on `stream`. */
+int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canvas_rgba[4], uint32_t n, uint32_t L,
+                          uint32_t W, uint32_t H, void* d_out_rgba, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSMTILE_H */
