@@ -1,0 +1,444 @@
+/*
+ * osmt_api.cpp — host side of libosmtile.so: contexts, HBM-resident scenes, the C ABI
+ * of include/osmtile.h.  No CPU rendering path exists here on purpose: every entry point
+ * either runs the HIP kernels or fails with an error code.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/osmtile.h"
+#include "osmt_geom.h"
+#include "osmt_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(_e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "%s failed: %s", #expr, \
+                        hipGetErrorString(_e));                                                  \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct osmt_ctx {
+    int device = 0;
+    std::mutex mu; /* guards the image registry */
+    std::vector<osmt_image_desc> images;
+    std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
+    osmt_image_desc* d_images = nullptr;
+    double4* d_image_pool = nullptr;
+    bool images_dirty = false;
+};
+
+struct osmt_scene {
+    osmt_ctx* ctx = nullptr;
+    uint32_t n_jobs = 0, n_ops = 0, n_rings = 0, n_pts = 0, n_dashes = 0, n_strokes = 0;
+    uint32_t scale = 1, coord_kind = 0;
+    char* d_base = nullptr; /* one allocation, carved below */
+    size_t bytes = 0;
+    osmt_tile_job* d_jobs = nullptr;
+    osmt_op* d_ops = nullptr;
+    osmt_ring* d_rings = nullptr;
+    double* d_latlon = nullptr;
+    int32_t* d_pts = nullptr;
+    double* d_dashes = nullptr;
+    uint32_t* d_pt_job = nullptr;
+    uint32_t* d_op_aux = nullptr;
+    osmt_opinfo* d_info = nullptr;
+    double* d_trav = nullptr;
+    osmt_stroke_aux* d_aux = nullptr;
+};
+
+namespace {
+
+int sync_images(osmt_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->images_dirty) return OSMT_OK;
+    if (ctx->d_images) (void)hipFree(ctx->d_images);
+    if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
+    ctx->d_images = nullptr;
+    ctx->d_image_pool = nullptr;
+    if (!ctx->images.empty()) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_images, ctx->images.size() * sizeof(osmt_image_desc)));
+        HIP_TRY(hipMalloc((void**)&ctx->d_image_pool, ctx->image_pool_host.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(ctx->d_images, ctx->images.data(), ctx->images.size() * sizeof(osmt_image_desc),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_image_pool, ctx->image_pool_host.data(), ctx->image_pool_host.size() * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    ctx->images_dirty = false;
+    return OSMT_OK;
+}
+
+int validate_batch(const osmt_batch* b) {
+    if (!b) return fail(OSMT_INVALID_ARG, "batch is NULL");
+    if (b->scale < 1 || b->scale > OSMT_MAX_SCALE) return fail(OSMT_INVALID_ARG, "scale %u not in 1..%u", b->scale, OSMT_MAX_SCALE);
+    if (b->coord_kind != OSMT_COORD_LATLON_F64 && b->coord_kind != OSMT_COORD_POINT_I32)
+        return fail(OSMT_INVALID_ARG, "unknown coord_kind %u", b->coord_kind);
+    if (b->n_jobs >= 0x7FFFFFFFull / 64 || b->n_ops >= 0xFFFFFFFFull || b->n_rings >= 0xFFFFFFFFull ||
+        b->n_pts >= 0xFFFFFFFFull || b->n_dashes >= 0xFFFFFFFFull)
+        return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices");
+    if ((b->n_jobs && !b->jobs) || (b->n_ops && !b->ops) || (b->n_rings && !b->rings) || (b->n_dashes && !b->dashes))
+        return fail(OSMT_INVALID_ARG, "NULL pool with non-zero count");
+    if (b->n_pts) {
+        if (b->coord_kind == OSMT_COORD_LATLON_F64 && !b->latlon) return fail(OSMT_INVALID_ARG, "latlon pool is NULL");
+        if (b->coord_kind == OSMT_COORD_POINT_I32 && !b->points) return fail(OSMT_INVALID_ARG, "points pool is NULL");
+    }
+    for (size_t j = 0; j < b->n_jobs; ++j) {
+        const osmt_tile_job& job = b->jobs[j];
+        if (job.zoom > 22) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u too large", j, job.zoom);
+        if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
+        if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
+        for (uint32_t k = 0; k < job.n_ops; ++k) {
+            const osmt_op& op = b->ops[job.op_off + k];
+            if (op.kind > OSMT_OP_STROKE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown kind %u", j, k, op.kind);
+            if (op.kind == OSMT_OP_NONE) continue;
+            if ((size_t)op.ring_off + op.n_rings > b->n_rings)
+                return fail(OSMT_INVALID_ARG, "job %zu op %u: ring range out of bounds", j, k);
+            for (uint32_t r = 0; r < op.n_rings; ++r) {
+                const osmt_ring& ring = b->rings[op.ring_off + r];
+                if (ring.first_pt < job.pt_off || (size_t)ring.first_pt + ring.n_pts > (size_t)job.pt_off + job.n_pts)
+                    return fail(OSMT_INVALID_ARG, "job %zu op %u ring %u: points outside the job's pool range", j, k, r);
+            }
+            if (!(op.opacity >= 0.0) || !std::isfinite(op.opacity))
+                return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be finite and >= 0", j, k);
+            if (op.kind == OSMT_OP_STROKE) {
+                if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
+                if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
+                if (op.has_dashes) {
+                    /* Some([]) panics in the reference (opacity_calculator.rs:109 indexes dashes[0]) */
+                    if (op.n_dashes == 0) return fail(OSMT_INVALID_ARG, "job %zu op %u: empty dash list", j, k);
+                    if (op.n_dashes > OSMT_MAX_DASHES)
+                        return fail(OSMT_UNSUPPORTED, "job %zu op %u: more than %u dashes", j, k, OSMT_MAX_DASHES);
+                    if ((size_t)op.dashes_off + op.n_dashes > b->n_dashes)
+                        return fail(OSMT_INVALID_ARG, "job %zu op %u: dash range out of bounds", j, k);
+                }
+            }
+        }
+    }
+    if (b->coord_kind == OSMT_COORD_POINT_I32) {
+        for (size_t i = 0; i < 2 * b->n_pts; ++i)
+            if (b->points[i] > OSMT_COORD_LIMIT || b->points[i] < -OSMT_COORD_LIMIT)
+                return fail(OSMT_UNSUPPORTED, "point %zu: |coordinate| > 2^28", i / 2);
+    }
+    return OSMT_OK;
+}
+
+int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, size_t stride, bool f64, void* stream) {
+    if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t W = OSMT_TILE_SIZE * sc->scale;
+    if ((stages & 4u) && !d_out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
+    if ((stages & 4u) && !f64 && stride < (size_t)W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    if ((stages & 1u) && sc->coord_kind == OSMT_COORD_LATLON_F64)
+        HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
+    if (stages & 2u)
+        HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
+                                   sc->d_trav, sc->d_aux, st));
+    if (stages & 4u) {
+        int rc = sync_images(ctx);
+        if (rc != OSMT_OK) return rc;
+        osmt_raster_args a;
+        memset(&a, 0, sizeof a);
+        a.jobs = sc->d_jobs;
+        a.n_jobs = sc->n_jobs;
+        a.scale = sc->scale;
+        a.ops = sc->d_ops;
+        a.info = sc->d_info;
+        a.rings = sc->d_rings;
+        a.pts = reinterpret_cast<const int2*>(sc->d_pts);
+        a.trav = sc->d_trav;
+        a.aux = sc->d_aux;
+        a.images = ctx->d_images;
+        a.image_pool = ctx->d_image_pool;
+        a.n_images = (uint32_t)ctx->images.size();
+        a.out = d_out;
+        a.out_tile_stride = stride;
+        HIP_TRY(osmt_launch_raster(a, f64, st));
+    }
+    return OSMT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t osmt_version(void) { return (1u << 16) | 0u; }
+
+const char* osmt_last_error(void) { return g_last_error.c_str(); }
+
+int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx) {
+    if (!out_ctx) return fail(OSMT_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(OSMT_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    const int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= n) return fail(OSMT_INVALID_ARG, "device %d out of range (0..%d)", dev, n - 1);
+    HIP_TRY(hipSetDevice(dev));
+    osmt_ctx* c = new (std::nothrow) osmt_ctx();
+    if (!c) return fail(OSMT_OOM, "out of host memory");
+    c->device = dev;
+    *out_ctx = c;
+    return OSMT_OK;
+}
+
+void osmt_destroy(osmt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_images) (void)hipFree(ctx->d_images);
+    if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
+    delete ctx;
+}
+
+int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_id) {
+    if (!ctx || !rgba8 || !out_id) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (width == 0 || height == 0) return fail(OSMT_INVALID_ARG, "empty image");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    osmt_image_desc d;
+    d.offset = ctx->image_pool_host.size() / 4;
+    d.width = width;
+    d.height = height;
+    const size_t n = (size_t)width * height;
+    ctx->image_pool_host.reserve(ctx->image_pool_host.size() + 4 * n);
+    for (size_t i = 0; i < n; ++i) {
+        /* RgbaColor::from_components (tile_pixels.rs:21-23): from_color(Color{r,g,b}, a/255) */
+        const double a = (double)rgba8[4 * i + 3] / 255.0;
+        ctx->image_pool_host.push_back(a * ((double)rgba8[4 * i + 0] / 255.0));
+        ctx->image_pool_host.push_back(a * ((double)rgba8[4 * i + 1] / 255.0));
+        ctx->image_pool_host.push_back(a * ((double)rgba8[4 * i + 2] / 255.0));
+        ctx->image_pool_host.push_back(a);
+    }
+    *out_id = (uint32_t)ctx->images.size();
+    ctx->images.push_back(d);
+    ctx->images_dirty = true;
+    return OSMT_OK;
+}
+
+int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
+    if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
+    *out_scene = nullptr;
+    int rc = validate_batch(b);
+    if (rc != OSMT_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    /* host-side index tables: point -> job (for projection), op -> stroke slot */
+    std::vector<uint32_t> pt_job(b->n_pts, 0xFFFFFFFFu), op_aux(b->n_ops, 0u);
+    uint32_t n_strokes = 0;
+    for (size_t j = 0; j < b->n_jobs; ++j) {
+        const osmt_tile_job& job = b->jobs[j];
+        for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
+        for (uint32_t k = 0; k < job.n_ops; ++k)
+            if (b->ops[job.op_off + k].kind == OSMT_OP_STROKE) op_aux[job.op_off + k] = n_strokes++;
+    }
+
+    osmt_scene* s = new (std::nothrow) osmt_scene();
+    if (!s) return fail(OSMT_OOM, "out of host memory");
+    s->ctx = ctx;
+    s->n_jobs = (uint32_t)b->n_jobs;
+    s->n_ops = (uint32_t)b->n_ops;
+    s->n_rings = (uint32_t)b->n_rings;
+    s->n_pts = (uint32_t)b->n_pts;
+    s->n_dashes = (uint32_t)b->n_dashes;
+    s->n_strokes = n_strokes;
+    s->scale = b->scale;
+    s->coord_kind = b->coord_kind;
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const bool ll = b->coord_kind == OSMT_COORD_LATLON_F64;
+    const size_t o_jobs = carve(b->n_jobs * sizeof(osmt_tile_job));
+    const size_t o_ops = carve(b->n_ops * sizeof(osmt_op));
+    const size_t o_rings = carve(b->n_rings * sizeof(osmt_ring));
+    const size_t o_latlon = carve(ll ? b->n_pts * 16 : 0);
+    const size_t o_pts = carve(b->n_pts * 8);
+    const size_t o_dashes = carve((b->n_dashes + 1) * 8);
+    const size_t o_ptjob = carve(b->n_pts * 4);
+    const size_t o_opaux = carve(b->n_ops * 4);
+    const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
+    const size_t o_trav = carve(b->n_pts * 8);
+    const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
+    s->bytes = off + 256;
+    hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
+                    hipGetErrorString(e));
+    }
+    s->d_jobs = (osmt_tile_job*)(s->d_base + o_jobs);
+    s->d_ops = (osmt_op*)(s->d_base + o_ops);
+    s->d_rings = (osmt_ring*)(s->d_base + o_rings);
+    s->d_latlon = (double*)(s->d_base + o_latlon);
+    s->d_pts = (int32_t*)(s->d_base + o_pts);
+    s->d_dashes = (double*)(s->d_base + o_dashes);
+    s->d_pt_job = (uint32_t*)(s->d_base + o_ptjob);
+    s->d_op_aux = (uint32_t*)(s->d_base + o_opaux);
+    s->d_info = (osmt_opinfo*)(s->d_base + o_info);
+    s->d_trav = (double*)(s->d_base + o_trav);
+    s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
+
+    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t err = hipSuccess;
+    if (err == hipSuccess) err = up(s->d_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
+    if (err == hipSuccess) err = up(s->d_ops, b->ops, b->n_ops * sizeof(osmt_op));
+    if (err == hipSuccess) err = up(s->d_rings, b->rings, b->n_rings * sizeof(osmt_ring));
+    if (err == hipSuccess && ll) err = up(s->d_latlon, b->latlon, b->n_pts * 16);
+    if (err == hipSuccess && !ll) err = up(s->d_pts, b->points, b->n_pts * 8);
+    if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
+    if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
+    if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
+    if (err != hipSuccess) {
+        (void)hipFree(s->d_base);
+        delete s;
+        return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
+    }
+    *out_scene = s;
+    return OSMT_OK;
+}
+
+void osmt_scene_free(osmt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_base) (void)hipFree(s->d_base);
+    delete s;
+}
+
+int osmt_render_scene(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t stride, void* stream) {
+    return render_impl(ctx, scene, 7u, d_out_rgba, stride, false, stream);
+}
+
+int osmt_render_scene_f64(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, void* stream) {
+    return render_impl(ctx, scene, 7u, d_out_f64, 0, true, stream);
+}
+
+int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba, size_t stride,
+                             void* stream) {
+    return render_impl(ctx, scene, stage_mask & 7u, d_out_rgba, stride, false, stream);
+}
+
+int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
+    if (!ctx || !sc || !xy) return fail(OSMT_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (sc->n_pts) HIP_TRY(hipMemcpy(xy, sc->d_pts, (size_t)sc->n_pts * 8, hipMemcpyDeviceToHost));
+    return OSMT_OK;
+}
+
+int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba, size_t stride) {
+    if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
+    osmt_scene* sc = nullptr;
+    int rc = osmt_scene_upload(ctx, batch, &sc);
+    if (rc != OSMT_OK) return rc;
+    const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
+    const size_t tile_bytes = W * W * 4;
+    if (stride < tile_bytes) {
+        osmt_scene_free(sc);
+        return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    }
+    void* d_out = nullptr;
+    if (batch->n_jobs) {
+        hipError_t e = hipMalloc(&d_out, batch->n_jobs * tile_bytes);
+        if (e != hipSuccess) {
+            osmt_scene_free(sc);
+            return fail(OSMT_OOM, "hipMalloc(output) failed: %s", hipGetErrorString(e));
+        }
+    }
+    rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, nullptr);
+    if (rc == OSMT_OK && batch->n_jobs) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess)
+            e = hipMemcpy2D(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
+    }
+    if (d_out) (void)hipFree(d_out);
+    osmt_scene_free(sc);
+    return rc;
+}
+
+int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tx, uint32_t ty, double scale,
+                 int32_t* xy) {
+    if (!ctx || (n && (!latlon || !xy))) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (n >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "too many points");
+    if (n == 0) return OSMT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* d_in = nullptr;
+    int32_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 16));
+    hipError_t e = hipMalloc((void**)&d_out, n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_in, latlon, n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = osmt_launch_project_single(d_in, (uint32_t)n, zoom, tx, ty, scale, d_out, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(xy, d_out, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(OSMT_HIP_ERROR, "osmt_project: %s", hipGetErrorString(e));
+    return OSMT_OK;
+}
+
+int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canvas[4], uint32_t n, uint32_t L,
+                          uint32_t W, uint32_t H, void* d_out, void* stream) {
+    if (!ctx || !canvas) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if ((uint64_t)W * H >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "tile too large");
+    if ((size_t)n * W * H && (!d_planes || !d_out)) return fail(OSMT_INVALID_ARG, "NULL device pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(osmt_launch_composite(d_planes, canvas, n, L, W * H, d_out, (hipStream_t)stream));
+    return OSMT_OK;
+}
+
+int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t W,
+                   uint32_t H, uint8_t* out_rgba) {
+    if (!ctx || !canvas) return fail(OSMT_INVALID_ARG, "NULL argument");
+    const size_t npx = (size_t)n * W * H;
+    if (npx == 0) return OSMT_OK;
+    if (!planes || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    const size_t in_bytes = npx * L * 32;
+    if (in_bytes) HIP_TRY(hipMalloc(&d_in, in_bytes));
+    hipError_t e = hipMalloc(&d_out, npx * 4);
+    if (e == hipSuccess && in_bytes) e = hipMemcpy(d_in, planes, in_bytes, hipMemcpyHostToDevice);
+    int rc = OSMT_OK;
+    if (e == hipSuccess) rc = osmt_composite_device(ctx, d_in ? d_in : (void*)1, canvas, n, L, W, H, d_out, nullptr);
+    if (e == hipSuccess && rc == OSMT_OK) e = hipDeviceSynchronize();
+    if (e == hipSuccess && rc == OSMT_OK) e = hipMemcpy(out_rgba, d_out, npx * 4, hipMemcpyDeviceToHost);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(OSMT_HIP_ERROR, "osmt_composite: %s", hipGetErrorString(e));
+    return rc;
+}
+
+} /* extern "C" */

@@ -1,0 +1,76 @@
+/* osmt_internal.h — device-side records shared by the kernels and the host library. */
+#ifndef OSMT_INTERNAL_H
+#define OSMT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/osmtile.h"
+
+/* even dash indices (<= 8) + the first dash repeated (opacity_calculator.rs:105-106) */
+#define OSMT_MAX_DASH_SEGS 10
+
+/* DashSegment, opacity_calculator.rs:88-96 */
+struct osmt_dash_seg {
+    double start_from, start_to, end_from, end_to, opacity_mul;
+    double orig_a, orig_b; /* original_endpoints (valid when table.has_orig) */
+};
+
+/* OpacityCalculator minus half_line_width/traveled (opacity_calculator.rs:3-8) */
+struct osmt_dash_table {
+    int32_t n_segs;
+    int32_t has_orig; /* line cap is Round: original_endpoints = Some(..) */
+    double total_len;
+    osmt_dash_seg segs[OSMT_MAX_DASH_SEGS];
+};
+
+/* the two calculators of draw_lines (line.rs:21-22) */
+struct osmt_stroke_aux {
+    double half_width;
+    osmt_dash_table main;
+    osmt_dash_table caps;
+};
+
+struct osmt_opinfo {
+    int32_t x0, y0, x1, y1; /* inclusive extent of pixels the op can touch (empty: x0 > x1) */
+    uint32_t aux;           /* STROKE: index into the stroke_aux table */
+    uint32_t n_edges;       /* total edges over all rings */
+    int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its segment's box */
+    int32_t _pad[1];
+};
+
+struct osmt_image_desc {
+    uint64_t offset; /* first pixel in the image pool (double4 units) */
+    uint32_t width, height;
+};
+
+struct osmt_raster_args {
+    const osmt_tile_job* jobs;
+    uint32_t n_jobs;
+    uint32_t scale;
+    const osmt_op* ops;
+    const osmt_opinfo* info;
+    const osmt_ring* rings;
+    const int2* pts;
+    const double* trav;
+    const osmt_stroke_aux* aux;
+    const osmt_image_desc* images;
+    const double4* image_pool;
+    uint32_t n_images;
+    uint32_t _pad;
+    void* out;
+    size_t out_tile_stride; /* bytes (RGBA8 output) */
+};
+
+hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
+                               double scale, int32_t* pts, hipStream_t st);
+hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
+                                      double scale, int32_t* pts, hipStream_t st);
+hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
+                              const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
+                              osmt_stroke_aux* aux, hipStream_t st);
+hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
+hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
+                                 void* out, hipStream_t st);
+
+#endif

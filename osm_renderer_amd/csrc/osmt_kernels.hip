@@ -1,0 +1,785 @@
+/*
+ * osmt_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the tile hot path.
+ *
+ *   k_project    Point::from_node                 (src/tile.rs:88-106, src/draw/point.rs:11-19)
+ *   k_opinfo     per-op pixel extents, traveled distances and dash tables
+ *                (src/draw/line.rs:21-33, src/draw/opacity_calculator.rs:16-30,98-143)
+ *   k_raster     fill_contour + draw_lines + set_pixel/blend + to_rgb_triples, fused per
+ *                32x32-pixel sub-tile (src/draw/fill.rs, line.rs, opacity_calculator.rs,
+ *                tile_pixels.rs, drawer.rs:133-219)
+ *   k_composite  blend_pixel over L resident layers + to_rgb_triples (tile_pixels.rs:205-223,164-181)
+ *
+ * Everything is f64 / integer and compiled with -ffp-contract=off: the reference never
+ * forms an FMA and its u8 output is a truncation, so contraction would flip pixels
+ * (SURVEY.md §7).  MFMA is unused on purpose: nothing here is a dense contraction.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/osmtile.h"
+#include "osmt_geom.h"
+#include "osmt_internal.h"
+
+namespace {
+
+constexpr double PI = 3.14159265358979323846264338327950288;
+
+/* Rust `f64 as i32` (saturating, NaN -> 0) */
+__device__ __forceinline__ int32_t f64_as_i32(double v) {
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return INT32_MAX;
+    if (v <= -2147483648.0) return INT32_MIN;
+    return (int32_t)v;
+}
+/* Rust `f64 as u8` */
+__device__ __forceinline__ uint32_t f64_as_u8(double v) {
+    if (v != v) return 0u;
+    if (v >= 255.0) return 255u;
+    if (v <= 0.0) return 0u;
+    return (uint32_t)(int32_t)v;
+}
+
+/* ------------------------------------------------------------------------- */
+/* tile.rs:88-106 + point.rs:11-19 */
+__device__ __forceinline__ void project_point(double lat, double lon, uint32_t zoom, uint32_t tx, uint32_t ty,
+                                              double scale, int32_t* ox, int32_t* oy) {
+    const double lat_rad = lat * (PI / 180.0);
+    const double lon_rad = lon * (PI / 180.0);
+    const double x = lon_rad + PI;
+    const double y = PI - log(tan((PI / 4.0) + (lat_rad / 2.0)));
+    const double dim = (double)(OSMT_TILE_SIZE * (1u << zoom));
+    const double px = (x / (2.0 * PI)) * dim;
+    const double py = (y / (2.0 * PI)) * dim;
+    const double rx = px - (double)(uint32_t)(tx * OSMT_TILE_SIZE);
+    const double ry = py - (double)(uint32_t)(ty * OSMT_TILE_SIZE);
+    *ox = f64_as_i32(round(rx * scale));
+    *oy = f64_as_i32(round(ry * scale));
+}
+
+__global__ __launch_bounds__(256) void k_project(const osmt_tile_job* __restrict__ jobs,
+                                                 const uint32_t* __restrict__ pt_job,
+                                                 const double2* __restrict__ latlon, uint32_t n_pts, double scale,
+                                                 int2* __restrict__ pts) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pts) return;
+    const uint32_t j = pt_job[i];
+    if (j == 0xFFFFFFFFu) {
+        pts[i] = make_int2(0, 0);
+        return;
+    }
+    const osmt_tile_job job = jobs[j];
+    const double2 ll = latlon[i];
+    int32_t x, y;
+    project_point(ll.x, ll.y, job.zoom, job.x, job.y, scale, &x, &y);
+    pts[i] = make_int2(x, y);
+}
+
+/* One point, explicit tile (osmt_project). */
+__global__ __launch_bounds__(256) void k_project_single(const double2* __restrict__ latlon, uint32_t n, uint32_t zoom,
+                                                        uint32_t tx, uint32_t ty, double scale,
+                                                        int2* __restrict__ pts) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const double2 ll = latlon[i];
+    int32_t x, y;
+    project_point(ll.x, ll.y, zoom, tx, ty, scale, &x, &y);
+    pts[i] = make_int2(x, y);
+}
+
+/* ------------------------------------------------------------------------- */
+/* point.rs:21-25 */
+__device__ __forceinline__ double point_dist(int32_t ax, int32_t ay, int32_t bx, int32_t by) {
+    const double dx = (double)(ax - bx);
+    const double dy = (double)(ay - by);
+    return sqrt(dx * dx + dy * dy);
+}
+
+/* opacity_calculator.rs:98-143 compute_segments, for one calculator. */
+__device__ void compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap,
+                                 osmt_dash_table* t) {
+    double len_before = 0.0;
+    int n = 0;
+    for (int it = 0; it <= n_dashes; ++it) {
+        const int idx = (it < n_dashes) ? it : 0; /* (0..len).chain(0..1) */
+        const double dash = dashes[idx];
+        double start = len_before;
+        if (idx != 0 || n == 0) len_before += dash;
+        if (idx % 2 != 0) continue;
+        double end = start + dash;
+        osmt_dash_seg s;
+        s.orig_a = start;
+        s.orig_b = end;
+        if (cap == OSMT_CAP_SQUARE || cap == OSMT_CAP_ROUND) {
+            start -= hlw;
+            end += hlw;
+        }
+        const double midpoint = (start + end) / 2.0;
+        s.start_from = fmin(start - 0.5, midpoint - 1.0);
+        s.start_to = fmin(start + 0.5, midpoint);
+        s.end_from = fmax(end - 0.5, midpoint);
+        s.end_to = fmax(end + 0.5, midpoint + 1.0);
+        s.opacity_mul = fmin(end - start, 1.0);
+        t->segs[n++] = s;
+    }
+    t->n_segs = n;
+    t->has_orig = (cap == OSMT_CAP_ROUND) ? 1 : 0;
+    t->total_len = len_before;
+}
+
+/* Per-op pre-pass: pixel extents (for sub-tile culling), traveled distance before every
+ * edge of a stroke (line.rs:31: add_traveled_distance, summed in edge order), and the two
+ * dash tables of draw_lines (line.rs:21-22). One thread per op. */
+__global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, uint32_t n_ops,
+                                               const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
+                                               const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
+                                               osmt_opinfo* __restrict__ info, double* __restrict__ trav,
+                                               osmt_stroke_aux* __restrict__ aux) {
+    const uint32_t o = blockIdx.x * 64u + threadIdx.x;
+    if (o >= n_ops) return;
+    const osmt_op op = ops[o];
+    osmt_opinfo oi;
+    oi.x0 = oi.y0 = INT32_MAX;
+    oi.x1 = oi.y1 = INT32_MIN;
+    oi.aux = op_aux[o];
+    oi.n_edges = 0;
+    oi._pad[0] = 0;
+    if (op.kind == OSMT_OP_NONE) {
+        info[o] = oi;
+        return;
+    }
+    double traveled = 0.0;
+    uint32_t n_edges = 0;
+    for (uint32_t r = 0; r < op.n_rings; ++r) {
+        const osmt_ring ring = rings[op.ring_off + r];
+        int2 prev = make_int2(0, 0);
+        for (uint32_t i = 0; i < ring.n_pts; ++i) {
+            const int2 p = pts[ring.first_pt + i];
+            oi.x0 = min(oi.x0, p.x);
+            oi.x1 = max(oi.x1, p.x);
+            oi.y0 = min(oi.y0, p.y);
+            oi.y1 = max(oi.y1, p.y);
+            if (op.kind == OSMT_OP_STROKE) {
+                if (i > 0) traveled += point_dist(prev.x, prev.y, p.x, p.y);
+                trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
+            }
+            prev = p;
+        }
+        if (ring.n_pts >= 2) n_edges += ring.n_pts - 1;
+    }
+    oi.n_edges = n_edges;
+    if (op.kind == OSMT_OP_STROKE) {
+        const double hw = op.width / 2.0;
+        const double ft = fmax(hw + 0.5, 1.0);
+        /* a perpendicular run leaves the Bresenham centre by < ft + 3.3 px per axis */
+        int32_t reach = (int32_t)fmin(ceil(ft), 1.0e6) + 4;
+        const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
+        int32_t cap_reach = caps ? (int32_t)fmin(ceil(fabs(hw)), 1.0e6) + 1 : 0;
+        oi.reach = reach;
+        if (oi.x0 <= oi.x1) {
+            oi.x0 -= reach + cap_reach;
+            oi.y0 -= reach + cap_reach;
+            oi.x1 += reach + cap_reach;
+            oi.y1 += reach + cap_reach;
+        }
+        osmt_stroke_aux* sa = &aux[oi.aux];
+        sa->half_width = hw;
+        const int cap_for_dashes = op.use_caps_for_dashes ? op.cap : OSMT_CAP_NONE;
+        if (op.has_dashes) {
+            compute_segments(hw, dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes, &sa->main);
+        } else {
+            sa->main.n_segs = 0;
+            sa->main.has_orig = 0;
+            sa->main.total_len = 0.0;
+        }
+        const double zero = 0.0;
+        compute_segments(hw, &zero, 1, op.cap, &sa->caps);
+        /* the chained (0..1) pass pushes the same segment twice; max/min over two equal
+         * entries equals one entry, keep one */
+        sa->caps.n_segs = 1;
+    } else {
+        oi.reach = 0;
+    }
+    info[o] = oi;
+}
+
+/* ------------------------------------------------------------------------- */
+/* opacity_calculator.rs:171-185 */
+__device__ __forceinline__ double opacity_by_center_distance(double cd, double hlw) {
+    const double feather_from = fmax(hlw - 0.5, 0.0);
+    const double feather_to = fmax(hlw + 0.5, 1.0);
+    const double feather_dist = feather_to - feather_from;
+    const double opacity_mul = fmin(2.0 * hlw, 1.0);
+    double v;
+    if (cd < feather_from)
+        v = 1.0;
+    else if (cd < feather_to)
+        v = (feather_to - cd) / feather_dist;
+    else
+        v = 0.0;
+    return opacity_mul * v;
+}
+
+/* opacity_calculator.rs:32-80 calculate (+ get_opacity_by_start_distance) */
+__device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restrict__ t, double half_width,
+                                                  double traveled, double cd, double sd, double* opacity) {
+    double sd_op = 1.0;
+    double cap_dist = 0.0;
+    const int n = t->n_segs;
+    if (n > 0) {
+        double dist_rem = traveled + sd;
+        const double total = t->total_len;
+        if (total > 0.0) dist_rem = fmod(dist_rem, total);
+        sd_op = 0.0;
+        bool has = false;
+        double dic = 0.0;
+        const int has_orig = t->has_orig;
+        for (int i = 0; i < n; ++i) {
+            const osmt_dash_seg* s = &t->segs[i];
+            /* :145-157 */
+            if (dist_rem < s->start_from || dist_rem > s->end_to) continue;
+            double base;
+            if (dist_rem <= s->start_to)
+                base = (dist_rem - s->start_from) / (s->start_to - s->start_from);
+            else if (dist_rem < s->end_from)
+                base = 1.0;
+            else
+                base = (s->end_to - dist_rem) / (s->end_to - s->end_from);
+            sd_op = fmax(sd_op, s->opacity_mul * base);
+            if (has_orig) { /* :159-169 */
+                double d;
+                if (dist_rem < s->orig_a)
+                    d = s->orig_a - dist_rem;
+                else if (dist_rem <= s->orig_b)
+                    d = 0.0;
+                else
+                    d = dist_rem - s->orig_b;
+                if (!has || d < dic) {
+                    has = true;
+                    dic = d;
+                }
+            }
+        }
+        cap_dist = has ? dic : 0.0;
+    }
+    const double hlw = sqrt(half_width * half_width - cap_dist * cap_dist);
+    const double cdop = opacity_by_center_distance(cd, hlw);
+    *opacity = fmin(sd_op, cdop);
+    return cdop > 0.0;
+}
+
+/* ---- the fused raster kernel ---------------------------------------------- */
+constexpr int SUB = 32;            /* sub-tile edge in pixels */
+constexpr int NTHREADS = 256;      /* 4 waves */
+constexpr int PXT = SUB * SUB / NTHREADS; /* pixels per thread = 4 */
+constexpr int ROWCAP = 32;         /* crossing records kept per row before the slow path */
+constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
+
+struct RowRec {
+    int32_t x_min, x_max;
+    uint32_t edge;
+};
+
+struct RasterShared {
+    unsigned long long plane[2][SUB * SUB]; /* generation alpha planes (f64 bit patterns) */
+    uint32_t mask[2][SUB];                  /* fill coverage per row */
+    RowRec rec[SUB][ROWCAP];
+    uint32_t rowcnt[SUB];
+    uint32_t oplist[OPCHUNK];
+    uint32_t wcount[NTHREADS / 64];
+};
+
+struct SubRect {
+    int32_t x0, y0, x1, y1; /* inclusive */
+};
+
+__device__ __forceinline__ void blend_px(double* acc, double sr, double sg, double sb, double sa) {
+    /* tile_pixels.rs:209-219: new + (1.0 - a) * old, mul then add, no FMA */
+    const double k = 1.0 - sa;
+    acc[0] = sr + k * acc[0];
+    acc[1] = sg + k * acc[1];
+    acc[2] = sb + k * acc[2];
+    acc[3] = sa + k * acc[3];
+}
+
+/* One perpendicular run (line.rs:108-137). */
+__device__ __forceinline__ void walk_perpendicular(const osmt_seg& s, const osmt_dash_table* __restrict__ tab,
+                                                   double half_width, double traveled, double initial_opacity,
+                                                   int32_t mn, int32_t mx, int32_t p_error, int32_t mul,
+                                                   const SubRect& rc, unsigned long long* __restrict__ plane) {
+    int32_t p_mn = mx;
+    int32_t p_mx = mn;
+    int32_t err = mul * p_error;
+    const int32_t two_a = 2 * s.a, two_b = 2 * s.b;
+    for (;;) {
+        const int32_t px = s.swap ? p_mn : p_mx;
+        const int32_t py = s.swap ? p_mx : p_mn;
+        const int64_t raw = s.numer_const + (s.sdy * (int64_t)px - s.sdx * (int64_t)py);
+        const double cd = fabs((double)raw) / s.denom;
+        const double ld = point_dist(px, py, s.p1x, s.p1y);
+        const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));
+        double op;
+        if (!opacity_calculate(tab, half_width, traveled, cd, sd, &op)) break;
+        if (px >= rc.x0 && px <= rc.x1 && py >= rc.y0 && py <= rc.y1) {
+            const double alpha = initial_opacity * op;
+            /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118);
+             * alpha >= +0, so the u64 order of the bit pattern is the f64 order */
+            atomicMax(&plane[(py - rc.y0) * SUB + (px - rc.x0)], (unsigned long long)__double_as_longlong(alpha));
+        }
+        /* update_error (line.rs:91-100) */
+        if (err + two_a > s.b) {
+            err -= two_b;
+            p_mn -= mul * s.mx_inc;
+        }
+        err += two_a;
+        p_mx += mul * s.mn_inc;
+    }
+}
+
+/* All perpendiculars of one segment that can reach the sub-tile (line.rs:65-158). */
+__device__ void raster_segment(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y,
+                               const osmt_dash_table* __restrict__ tab, double half_width, double traveled,
+                               double initial_opacity, int32_t reach, const SubRect& rc,
+                               unsigned long long* __restrict__ plane) {
+    if (p1x == p2x && p1y == p2y) return;
+    /* segment-level cull: every visited pixel lies within `reach` of the segment's box */
+    if (max(p1x, p2x) + reach < rc.x0 || min(p1x, p2x) - reach > rc.x1 || max(p1y, p2y) + reach < rc.y0 ||
+        min(p1y, p2y) - reach > rc.y1)
+        return;
+    osmt_seg s;
+    {
+        const double dxf = (double)abs(p2x - p1x), dyf = (double)abs(p2y - p1y);
+        osmt_seg_setup(&s, p1x, p1y, p2x, p2y, sqrt(dyf * dyf + dxf * dxf));
+    }
+    /* main-axis steps whose perpendiculars can reach the sub-tile */
+    const int32_t lo = (s.swap ? rc.x0 : rc.y0) - reach;
+    const int32_t hi = (s.swap ? rc.x1 : rc.y1) + reach;
+    int32_t k_lo, k_hi;
+    if (s.mx_inc > 0) {
+        k_lo = lo - s.mx0;
+        k_hi = hi - s.mx0;
+    } else {
+        k_lo = s.mx0 - hi;
+        k_hi = s.mx0 - lo;
+    }
+    k_lo = max(k_lo, 0);
+    k_hi = min(k_hi, s.b);
+    if (k_lo > k_hi) return;
+    const int32_t mlo = (s.swap ? rc.y0 : rc.x0) - reach;
+    const int32_t mhi = (s.swap ? rc.y1 : rc.x1) + reach;
+    const int32_t n_items = (k_hi - k_lo + 1) * 2;
+    for (int32_t it = threadIdx.x; it < n_items; it += NTHREADS) {
+        const int32_t k = k_lo + (it >> 1);
+        const int32_t mul = (it & 1) ? -1 : 1;
+        int32_t c, pe, has_extra, pe_extra;
+        osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
+        const int32_t mx = s.mx0 + k * s.mx_inc;
+        const int32_t mn = s.mn0 + c * s.mn_inc;
+        if (mn >= mlo && mn <= mhi)
+            walk_perpendicular(s, tab, half_width, traveled, initial_opacity, mn, mx, pe, mul, rc, plane);
+        if (has_extra) {
+            const int32_t mn2 = mn + s.mn_inc;
+            if (mn2 >= mlo && mn2 <= mhi)
+                walk_perpendicular(s, tab, half_width, traveled, initial_opacity, mn2, mx, pe_extra, mul, rc, plane);
+        }
+    }
+}
+
+/* point.rs:27-35 push_away_from */
+__device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by) {
+    const double dist = point_dist(self.x, self.y, other.x, other.y);
+    const double k = by / dist;
+    int2 r;
+    r.x = self.x + f64_as_i32(round((double)(self.x - other.x) * k));
+    r.y = self.y + f64_as_i32(round((double)(self.y - other.y) * k));
+    return r;
+}
+
+template <bool OUT_F64>
+__global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
+    __shared__ RasterShared sh;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t W = OSMT_TILE_SIZE * A.scale;
+    const uint32_t subs_per_row = W / SUB;
+    const uint32_t nsub = subs_per_row * subs_per_row;
+
+    /* XCD-aware block -> (tile, sub-tile): blocks b, b+8, b+16.. land on one XCD, so give
+     * them the sub-tiles of the same tiles (they share that tile's display list in L2). */
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u;
+    const uint32_t rest = b >> 3;
+    const uint32_t tile = (rest / nsub) * 8u + xcd;
+    const uint32_t sub = rest % nsub;
+    if (tile >= A.n_jobs) return;
+
+    const osmt_tile_job job = A.jobs[tile];
+    SubRect rc;
+    rc.x0 = (int32_t)((sub % subs_per_row) * SUB);
+    rc.y0 = (int32_t)((sub / subs_per_row) * SUB);
+    rc.x1 = rc.x0 + SUB - 1;
+    rc.y1 = rc.y0 + SUB - 1;
+
+    /* thread -> pixels: column lx, rows ly0 + 8*j; a wave covers two full 128-byte rows */
+    const uint32_t lx = tid & (SUB - 1);
+    const uint32_t ly0 = tid / SUB;
+
+    /* tile_pixels.rs:89-93 reset */
+    double acc[PXT][4];
+    {
+        double r = 0.0, g = 0.0, bl = 0.0;
+        if (job.has_canvas) {
+            r = 1.0 * ((double)job.canvas_rgb[0] / 255.0);
+            g = 1.0 * ((double)job.canvas_rgb[1] / 255.0);
+            bl = 1.0 * ((double)job.canvas_rgb[2] / 255.0);
+        }
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            acc[j][0] = r;
+            acc[j][1] = g;
+            acc[j][2] = bl;
+            acc[j][3] = 1.0;
+        }
+    }
+    for (uint32_t i = tid; i < 2 * SUB * SUB; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
+    if (tid < SUB) sh.rowcnt[tid] = 0u;
+    __syncthreads();
+
+    uint32_t buf = 0;
+    for (uint32_t base = 0; base < job.n_ops; base += OPCHUNK) {
+        /* ---- ordered compaction of the ops whose extent touches this sub-tile ---- */
+        const uint32_t oi_idx = base + tid;
+        bool hit = false;
+        if (oi_idx < job.n_ops) {
+            const osmt_opinfo oi = A.info[job.op_off + oi_idx];
+            hit = oi.n_edges > 0 && oi.x0 <= rc.x1 && oi.x1 >= rc.x0 && oi.y0 <= rc.y1 && oi.y1 >= rc.y0;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) sh.wcount[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NTHREADS / 64; ++w) {
+            const uint32_t cnt = sh.wcount[w];
+            if (w < wave) off += cnt;
+            total += cnt;
+        }
+        if (hit) sh.oplist[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = oi_idx;
+        __syncthreads();
+
+        for (uint32_t li = 0; li < total; ++li) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
+            const osmt_op* __restrict__ op = &A.ops[o];
+            const uint32_t kind = op->kind;
+            if (kind == OSMT_OP_STROKE) {
+                /* ---------------- draw_lines (line.rs:9-61) ---------------- */
+                const osmt_opinfo* __restrict__ oi = &A.info[o];
+                const osmt_stroke_aux* __restrict__ sa = &A.aux[oi->aux];
+                const double half_width = sa->half_width;
+                const double initial_opacity = op->opacity;
+                const int32_t reach = oi->reach;
+                const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
+                unsigned long long* plane = sh.plane[buf];
+                bool first = true;
+                const uint32_t n_edges = oi->n_edges;
+                uint32_t e_seen = 0;
+                for (uint32_t r = 0; r < op->n_rings; ++r) {
+                    const osmt_ring ring = A.rings[op->ring_off + r];
+                    for (uint32_t i = 1; i < ring.n_pts; ++i) {
+                        const int2 p1 = A.pts[ring.first_pt + i - 1];
+                        const int2 p2 = A.pts[ring.first_pt + i];
+                        const double traveled = A.trav[ring.first_pt + i - 1];
+                        raster_segment(p1.x, p1.y, p2.x, p2.y, &sa->main, half_width, traveled, initial_opacity,
+                                       reach, rc, plane);
+                        ++e_seen;
+                        if (has_caps && !(p1.x == p2.x && p1.y == p2.y)) {
+                            if (first) {
+                                const int2 ce = push_away_from(p1, p2, half_width);
+                                raster_segment(p1.x, p1.y, ce.x, ce.y, &sa->caps, half_width, 0.0, initial_opacity,
+                                               reach, rc, plane);
+                            }
+                            if (e_seen == n_edges) {
+                                const int2 ce = push_away_from(p2, p1, half_width);
+                                raster_segment(p2.x, p2.y, ce.x, ce.y, &sa->caps, half_width, 0.0, initial_opacity,
+                                               reach, rc, plane);
+                            }
+                        }
+                        first = false;
+                    }
+                }
+                __syncthreads();
+                /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
+                const double cr = (double)op->color[0] / 255.0;
+                const double cg = (double)op->color[1] / 255.0;
+                const double cb = (double)op->color[2] / 255.0;
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const uint32_t idx = (ly0 + (uint32_t)j * (NTHREADS / SUB)) * SUB + lx;
+                    const unsigned long long bits = plane[idx];
+                    if (bits != 0ull) {
+                        plane[idx] = 0ull;
+                        const double a = __longlong_as_double((long long)bits);
+                        blend_px(acc[j], a * cr, a * cg, a * cb, a); /* from_color: o * (c/255) */
+                    }
+                }
+                buf ^= 1u;
+            } else {
+                /* ---------------- fill_contour (fill.rs:16-47) ---------------- */
+                /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row */
+                uint32_t e_base = 0;
+                for (uint32_t r = 0; r < op->n_rings; ++r) {
+                    const osmt_ring ring = A.rings[op->ring_off + r];
+                    if (ring.n_pts < 2) continue;
+                    const uint32_t ne = ring.n_pts - 1;
+                    const uint32_t n_items = ne * SUB;
+                    for (uint32_t it = tid; it < n_items; it += NTHREADS) {
+                        const uint32_t e = it / SUB, row = it % SUB;
+                        const int2 p1 = A.pts[ring.first_pt + e];
+                        const int2 p2 = A.pts[ring.first_pt + e + 1];
+                        int32_t xmn, xmx;
+                        if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx)) {
+                            const uint32_t slot = atomicAdd(&sh.rowcnt[row], 1u);
+                            if (slot < ROWCAP) {
+                                sh.rec[row][slot].x_min = xmn;
+                                sh.rec[row][slot].x_max = xmx;
+                                sh.rec[row][slot].edge = e_base + e;
+                            }
+                        }
+                    }
+                    e_base += ne;
+                }
+                __syncthreads();
+                /* B: per row: order by (x_min, edge index) == stable sort_by_key(x_min) of records
+                 * inserted in edge order (fill.rs:24-25), pair (0,1),(2,3).., OR the spans */
+                if (tid < SUB) {
+                    const uint32_t row = tid;
+                    const uint32_t n = sh.rowcnt[row];
+                    uint32_t m = 0u;
+                    if (n <= ROWCAP) {
+                        RowRec* rr = sh.rec[row];
+                        for (uint32_t i = 1; i < n; ++i) {
+                            const RowRec key = rr[i];
+                            int32_t j = (int32_t)i - 1;
+                            while (j >= 0 && (rr[j].x_min > key.x_min ||
+                                              (rr[j].x_min == key.x_min && rr[j].edge > key.edge))) {
+                                rr[j + 1] = rr[j];
+                                --j;
+                            }
+                            rr[j + 1] = key;
+                        }
+                        for (uint32_t k = 0; k + 1 < n; k += 2) {
+                            const int32_t from = max(rr[k].x_min, rc.x0);
+                            const int32_t to = min(rr[k + 1].x_max, rc.x1);
+                            if (from <= to) {
+                                const uint32_t len = (uint32_t)(to - from + 1);
+                                const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                                m |= bits << (uint32_t)(from - rc.x0);
+                            }
+                        }
+                    } else {
+                        /* slow path (more than ROWCAP crossings on a row): stream the records in
+                         * (x_min, edge) order by repeated minimum search — no storage needed */
+                        int32_t last_x = INT32_MIN;
+                        int64_t last_e = -1;
+                        bool have_last = false;
+                        uint32_t k = 0;
+                        int32_t from_x = 0;
+                        for (;;) {
+                            bool found = false;
+                            int32_t bx = 0, bxm = 0;
+                            int64_t be = 0;
+                            uint32_t eb = 0;
+                            for (uint32_t r = 0; r < op->n_rings; ++r) {
+                                const osmt_ring ring = A.rings[op->ring_off + r];
+                                if (ring.n_pts < 2) continue;
+                                for (uint32_t e = 0; e + 1 < ring.n_pts; ++e) {
+                                    const int2 p1 = A.pts[ring.first_pt + e];
+                                    const int2 p2 = A.pts[ring.first_pt + e + 1];
+                                    int32_t xmn, xmx;
+                                    if (!osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx))
+                                        continue;
+                                    const int64_t ge = (int64_t)eb + e;
+                                    const bool after =
+                                        !have_last || xmn > last_x || (xmn == last_x && ge > last_e);
+                                    if (!after) continue;
+                                    if (!found || xmn < bx || (xmn == bx && ge < be)) {
+                                        found = true;
+                                        bx = xmn;
+                                        bxm = xmx;
+                                        be = ge;
+                                    }
+                                }
+                                eb += ring.n_pts - 1;
+                            }
+                            if (!found) break;
+                            if ((k & 1u) == 0u) {
+                                from_x = bx;
+                            } else {
+                                const int32_t from = max(from_x, rc.x0);
+                                const int32_t to = min(bxm, rc.x1);
+                                if (from <= to) {
+                                    const uint32_t len = (uint32_t)(to - from + 1);
+                                    const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                                    m |= bits << (uint32_t)(from - rc.x0);
+                                }
+                            }
+                            have_last = true;
+                            last_x = bx;
+                            last_e = be;
+                            ++k;
+                        }
+                    }
+                    sh.mask[buf][row] = m;
+                    sh.rowcnt[row] = 0u;
+                }
+                __syncthreads();
+                /* C: set_pixel + blend of the covered pixels */
+                if (kind == OSMT_OP_FILL_COLOR) {
+                    const double o_ = op->opacity;
+                    const double sr = o_ * ((double)op->color[0] / 255.0);
+                    const double sg = o_ * ((double)op->color[1] / 255.0);
+                    const double sb = o_ * ((double)op->color[2] / 255.0);
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) {
+                        const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
+                        if ((sh.mask[buf][row] >> lx) & 1u) blend_px(acc[j], sr, sg, sb, o_);
+                    }
+                } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
+                    const uint32_t img = op->image_id;
+                    if (img < A.n_images) {
+                        const osmt_image_desc im = A.images[img];
+                        const double4* __restrict__ ipx = A.image_pool + im.offset;
+#pragma unroll
+                        for (int j = 0; j < PXT; ++j) {
+                            const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
+                            if ((sh.mask[buf][row] >> lx) & 1u) {
+                                const uint32_t ix = (uint32_t)(rc.x0 + (int32_t)lx) % im.width;
+                                const uint32_t iy = (uint32_t)(rc.y0 + (int32_t)row) % im.height;
+                                const double4 c = ipx[(size_t)iy * im.width + ix];
+                                blend_px(acc[j], c.x, c.y, c.z, c.w);
+                            }
+                        }
+                    }
+                }
+                buf ^= 1u;
+            }
+        }
+        __syncthreads(); /* oplist is rewritten by the next chunk */
+    }
+
+    /* ---- to_rgb_triples (tile_pixels.rs:164-181) / raw canvas ---------------- */
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
+        const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx);
+        if (OUT_F64) {
+            double4* out = reinterpret_cast<double4*>(A.out) + (size_t)tile * W * W + px;
+            *out = make_double4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        } else {
+            const double a = acc[j][3];
+            const double mr = (a == 0.0) ? 0.0 : acc[j][0] / a;
+            const double mg = (a == 0.0) ? 0.0 : acc[j][1] / a;
+            const double mb = (a == 0.0) ? 0.0 : acc[j][2] / a;
+            const uint32_t v = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) |
+                               0xFF000000u;
+            uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.out) +
+                                                        (size_t)tile * A.out_tile_stride) + px;
+            *out = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Layer compositing: one pixel per lane, L resident premultiplied f64 layers, strictly
+ * in order (blend_pixel is not commutative), then to_rgb_triples.  Pure HBM stream:
+ * 32*L bytes in, 4 bytes out per pixel. */
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int LT>
+__global__ __launch_bounds__(256) void k_composite(const v4d* __restrict__ planes, double4 canvas, uint32_t n,
+                                                   uint32_t L, uint32_t npx, uint32_t* __restrict__ out) {
+    const size_t total = (size_t)n * npx;
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t p = (size_t)blockIdx.x * 256u + threadIdx.x; p < total; p += stride) {
+        const size_t t = p / npx, q = p - t * npx;
+        const v4d* src = planes + (t * (size_t)L) * npx + q;
+        double d[4] = {canvas.x, canvas.y, canvas.z, canvas.w};
+        if (LT > 0) {
+            v4d s[LT > 0 ? LT : 1];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) s[l] = __builtin_nontemporal_load(src + (size_t)l * npx);
+#pragma unroll
+            for (int l = 0; l < LT; ++l) blend_px(d, s[l].x, s[l].y, s[l].z, s[l].w);
+        } else {
+            for (uint32_t l = 0; l < L; ++l) {
+                const v4d s = __builtin_nontemporal_load(src + (size_t)l * npx);
+                blend_px(d, s.x, s.y, s.z, s.w);
+            }
+        }
+        const double a = d[3];
+        const double mr = (a == 0.0) ? 0.0 : d[0] / a;
+        const double mg = (a == 0.0) ? 0.0 : d[1] / a;
+        const double mb = (a == 0.0) ? 0.0 : d[2] / a;
+        out[p] = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) | 0xFF000000u;
+    }
+}
+
+}  // namespace
+
+/* ---- launchers (C++ internal interface, see osmt_internal.h) ---------------- */
+hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
+                               double scale, int32_t* pts, hipStream_t st) {
+    if (n_pts == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_project, dim3((n_pts + 255u) / 256u), dim3(256), 0, st, jobs, pt_job,
+                       reinterpret_cast<const double2*>(latlon), n_pts, scale, reinterpret_cast<int2*>(pts));
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
+                                      double scale, int32_t* pts, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_project_single, dim3((n + 255u) / 256u), dim3(256), 0, st,
+                       reinterpret_cast<const double2*>(latlon), n, zoom, tx, ty, scale, reinterpret_cast<int2*>(pts));
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
+                              const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
+                              osmt_stroke_aux* aux, hipStream_t st) {
+    if (n_ops == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
+                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, aux);
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st) {
+    if (a.n_jobs == 0) return hipSuccess;
+    const uint32_t W = OSMT_TILE_SIZE * a.scale;
+    const uint32_t nsub = (W / SUB) * (W / SUB);
+    const uint32_t groups = (a.n_jobs + 7u) / 8u;
+    const dim3 grid(groups * 8u * nsub);
+    if (out_f64)
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
+                                 void* out, hipStream_t st) {
+    const size_t total = (size_t)n * npx;
+    if (total == 0) return hipSuccess;
+    const double4 cv = make_double4(canvas[0], canvas[1], canvas[2], canvas[3]);
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = 256 * 16; /* 256 CUs x 16 resident blocks, grid-stride beyond */
+    if (blocks > cap) blocks = cap;
+    const v4d* p = reinterpret_cast<const v4d*>(planes);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    if (L == 8)
+        hipLaunchKernelGGL(k_composite<8>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+    else if (L == 4)
+        hipLaunchKernelGGL(k_composite<4>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+    else
+        hipLaunchKernelGGL(k_composite<0>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+    return hipGetLastError();
+}

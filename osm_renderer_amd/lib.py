@@ -1,0 +1,67 @@
+"""ctypes binding of libosmtile.so — the C ABI of include/osmtile.h.
+
+There is no fallback: if the HIP library is missing or no GPU is present the
+calls raise.  torch is imported first on purpose: it brings its own
+libamdhip64.so.7 into the process and the dynamic linker then resolves our
+NEEDED entry of the same soname to that copy, so device pointers and streams
+are shared between torch tensors and the kernels.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libosmtile.so")
+_lib = None
+
+EXPORTS = [
+    "osmt_create", "osmt_destroy", "osmt_last_error", "osmt_version", "osmt_register_image", "osmt_render_batch",
+    "osmt_scene_upload", "osmt_scene_free", "osmt_render_scene", "osmt_render_scene_f64", "osmt_render_scene_stages",
+    "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device",
+]
+
+
+class OsmtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"osmtile error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m osm_renderer_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback"
+        )
+    import torch  # noqa: F401  (loads the HIP runtime this library binds to)
+
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip, u8p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.osmt_version.restype = C.c_uint32
+    L.osmt_last_error.restype = C.c_char_p
+    L.osmt_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+    L.osmt_destroy.argtypes = [vp]
+    L.osmt_destroy.restype = None
+    L.osmt_register_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.osmt_render_batch.argtypes = [vp, C.POINTER(abi.Batch), u8p, C.c_size_t]
+    L.osmt_scene_upload.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(vp)]
+    L.osmt_scene_free.argtypes = [vp]
+    L.osmt_scene_free.restype = None
+    L.osmt_render_scene.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.osmt_render_scene_f64.argtypes = [vp, vp, vp, vp]
+    L.osmt_render_scene_stages.argtypes = [vp, vp, C.c_uint32, vp, C.c_size_t, vp]
+    L.osmt_scene_read_points.argtypes = [vp, vp, ip]
+    L.osmt_project.argtypes = [vp, dp, C.c_size_t, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double, ip]
+    L.osmt_composite.argtypes = [vp, dp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
+    L.osmt_composite_device.argtypes = [vp, vp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != abi.OK:
+        raise OsmtError(rc, load().osmt_last_error().decode("utf-8", "replace"))

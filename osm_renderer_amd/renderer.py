@@ -1,0 +1,165 @@
+"""Host-side driver over the C ABI: contexts, HBM-resident scenes, device output.
+
+torch is used for device buffers / streams only (plumbing): every pixel is
+produced by the HIP kernels behind libosmtile.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .display_list import DisplayList
+from .lib import check, load
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _stream_ptr(stream=None):
+    torch = _torch()
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+class Scene:
+    """A display-list batch resident in HBM (osmt_scene)."""
+
+    def __init__(self, ctx, dl: DisplayList):
+        self.ctx = ctx
+        self.dl = dl
+        self.n_jobs = dl.n_jobs
+        self.dim = dl.dim
+        b = dl.as_batch()
+        h = C.c_void_p()
+        check(load().osmt_scene_upload(ctx._h, C.byref(b), C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None):
+            load().osmt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU (osmt_ctx): analogue of the reference's Drawer + per-worker TilePixels."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the MI355X raster path has no CPU fallback")
+        L = load()
+        cfg = abi.Config(device=device, flags=0)
+        h = C.c_void_p()
+        check(L.osmt_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().osmt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- icons -------------------------------------------------------------------
+    def register_image(self, rgba8):
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        h, w, four = img.shape
+        assert four == 4
+        out = C.c_uint32()
+        check(load().osmt_register_image(self._h, img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, C.byref(out)))
+        return out.value
+
+    # -- whole path --------------------------------------------------------------
+    def upload(self, dl: DisplayList) -> Scene:
+        return Scene(self, dl)
+
+    def render(self, scene: Scene, out=None, stream=None):
+        """osmt_render_scene: returns a uint8 cuda tensor [n, H, W, 4] (asynchronous)."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((scene.n_jobs, scene.dim, scene.dim, 4), dtype=torch.uint8, device=self.device)
+        stride = scene.dim * scene.dim * 4
+        check(load().osmt_render_scene(self._h, scene._h, C.c_void_p(out.data_ptr()), stride, _stream_ptr(stream)))
+        return out
+
+    def render_stages(self, scene: Scene, stage_mask, out=None, stream=None):
+        stride = scene.dim * scene.dim * 4
+        ptr = C.c_void_p(out.data_ptr()) if out is not None else C.c_void_p(0)
+        check(load().osmt_render_scene_stages(self._h, scene._h, stage_mask, ptr, stride, _stream_ptr(stream)))
+        return out
+
+    def render_f64(self, scene: Scene, stream=None):
+        """osmt_render_scene_f64: premultiplied f64 canvas [n, H, W, 4]."""
+        torch = _torch()
+        out = torch.empty((scene.n_jobs, scene.dim, scene.dim, 4), dtype=torch.float64, device=self.device)
+        check(load().osmt_render_scene_f64(self._h, scene._h, C.c_void_p(out.data_ptr()), _stream_ptr(stream)))
+        return out
+
+    def read_points(self, scene: Scene):
+        out = np.empty((len(scene.dl.coords), 2), dtype=np.int32)
+        check(load().osmt_scene_read_points(self._h, scene._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def render_batch_host(self, dl: DisplayList):
+        """osmt_render_batch: host buffers in, host RGBA8 out."""
+        b = dl.as_batch()
+        out = np.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
+        check(load().osmt_render_batch(self._h, C.byref(b), out.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 4))
+        return out
+
+    # -- stages --------------------------------------------------------------------
+    def project(self, latlon, zoom, tx, ty, scale=1.0):
+        latlon = np.ascontiguousarray(latlon, dtype=np.float64).reshape(-1, 2)
+        out = np.empty((len(latlon), 2), dtype=np.int32)
+        check(
+            load().osmt_project(
+                self._h, latlon.ctypes.data_as(C.POINTER(C.c_double)), len(latlon), zoom, tx, ty, float(scale),
+                out.ctypes.data_as(C.POINTER(C.c_int32)),
+            )
+        )
+        return out
+
+    def composite_host(self, planes, canvas_rgba):
+        planes = np.ascontiguousarray(planes, dtype=np.float64)
+        n, L, H, W, four = planes.shape
+        assert four == 4
+        cv = np.ascontiguousarray(canvas_rgba, dtype=np.float64)
+        out = np.empty((n, H, W, 4), dtype=np.uint8)
+        check(
+            load().osmt_composite(
+                self._h, planes.ctypes.data_as(C.POINTER(C.c_double)), cv.ctypes.data_as(C.POINTER(C.c_double)), n, L,
+                W, H, out.ctypes.data_as(C.POINTER(C.c_uint8)),
+            )
+        )
+        return out
+
+    def composite(self, planes, canvas_rgba, out=None, stream=None):
+        """osmt_composite_device on a cuda float64 tensor [n, L, H, W, 4]."""
+        torch = _torch()
+        assert planes.is_cuda and planes.dtype == torch.float64 and planes.is_contiguous()
+        n, L, H, W, four = planes.shape
+        assert four == 4
+        if out is None:
+            out = torch.empty((n, H, W, 4), dtype=torch.uint8, device=planes.device)
+        cv = (C.c_double * 4)(*[float(v) for v in canvas_rgba])
+        check(
+            load().osmt_composite_device(
+                self._h, C.c_void_p(planes.data_ptr()), cv, n, L, W, H, C.c_void_p(out.data_ptr()), _stream_ptr(stream)
+            )
+        )
+        return out

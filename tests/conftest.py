@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+
+    oracle_py.build()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible (the raster path has no CPU fallback)")
+    from osm_renderer_amd.renderer import Context
+
+    ctx = Context(0)
+    yield ctx
+    ctx.close()
