@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — tiles/sec of the MI355X tile hot path on BASELINE.json configs[1].
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (project -> per-op pre-pass -> fused
+fill/stroke/blend raster -> RGBA8 framebuffer) over one batch of 1024 synthetic
+z=15 256x256 tiles (50 polygons + 200 stroke segments each) PER GPU, display
+lists already resident in HBM, framebuffers written to HBM.  With N > 1 (launched
+by torch.distributed.run, one rank per GPU) tile i of the global batch belongs to
+rank i mod N (weak scaling: 1024 tiles per GPU), no data-path collective; one
+RCCL all-reduce of the tile count per step is the only communication.
+
+Rank 0 prints ONE JSON line with the whole-job tiles/s plus
+  roofline            the dominant kernel (k_raster): algorithmic bytes / kernel time vs 8 TB/s
+  roofline_composite  the 8-layer @2x composite pass (the kernel the >= 40 % HBM target is on)
+  cpu_baseline        the C++ oracle (restatement of the reference's Rust CPU path, NOT the
+                      Rust binary) on the host cores, bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU per step")
+    ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--composite-tiles", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-composite", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from osm_renderer_amd import abi, synth
+    from osm_renderer_amd.renderer import Context
+
+    ctx = Context(local_rank)
+    dev = ctx.device
+
+    # ---- workload: tile i of the global batch -> rank i mod world --------------------
+    global_tiles = synth.config_tiles(args.tiles * world)
+    mine = global_tiles[rank::world]
+    dl = synth.make_tiles(mine, zoom=15, scale=args.scale)
+    scene = ctx.upload(dl)
+    out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    alg_bytes = dl.algorithmic_bytes()  # 16*N_pts + 64*N_ops + 8*N_dashes + 4*W*H per tile
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        ctx.render_stages(scene, abi.STAGE_PROJECT | abi.STAGE_OPINFO)
+        if i is not None:
+            ev[i][0].record()
+        ctx.render_stages(scene, abi.STAGE_RASTER, out)
+        if i is not None:
+            ev[i][1].record()
+        if dist is not None:
+            count.fill_(dl.n_jobs)
+            dist.all_reduce(count)  # RCCL sum of tile counts (the path's only collective)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        total_tiles_per_step = int(count.item())
+        assert total_tiles_per_step == args.tiles * world, (total_tiles_per_step, args.tiles, world)
+    else:
+        total_tiles_per_step = dl.n_jobs
+
+    raster_ms = [a.elapsed_time(b) for a, b in ev]
+    raster_avg_s = sum(raster_ms) / len(raster_ms) / 1e3
+    achieved = alg_bytes / raster_avg_s / 1e9
+
+    result = {
+        "metric": "tiles/sec (256x256 z=15)",
+        "value": total_tiles_per_step * args.steps / elapsed,
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE.json configs[1]: batch of {args.tiles} z=15 {dl.dim}x{dl.dim} tiles per GPU, "
+            "synthetic 50-poly/200-segment geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input "
+            "resident in HBM, RGBA8 framebuffers written to HBM",
+            "tiles_per_gpu": args.tiles,
+            "scale": args.scale,
+            "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
+        },
+        "roofline": {
+            "kernel": "k_raster (fused fill/stroke/blend/to_rgb; LDS/ALU-bound by construction, see DESIGN.md)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": raster_avg_s * 1e3,
+        },
+    }
+
+    # ---- composite pass (configs[2]: @2x 512x512, 8 layers) — rank 0, N = 1 only ------
+    if rank == 0 and world == 1 and not args.no_composite:
+        n, L, dim = args.composite_tiles, 8, 512
+        planes = synth.composite_planes(n, L=L, dim=dim, device=dev)
+        cout = torch.empty((n, dim, dim, 4), dtype=torch.uint8, device=dev)
+        canvas = [0xFC / 255.0, 0xF8 / 255.0, 0xE4 / 255.0, 1.0]
+        for _ in range(3):
+            ctx.composite(planes, canvas, out=cout)
+        reps = 20
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in cev:
+            a.record()
+            ctx.composite(planes, canvas, out=cout)
+            b.record()
+        torch.cuda.synchronize()
+        c_s = sum(a.elapsed_time(b) for a, b in cev) / reps / 1e3
+        c_bytes = n * (L * dim * dim * 32 + dim * dim * 4)  # B_comp, SURVEY.md §8(d)
+        result["roofline_composite"] = {
+            "kernel": "k_composite<8> (8-layer premultiplied f64 over + to_rgb, 512x512)",
+            "bound": "hbm",
+            "achieved": c_bytes / c_s / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": c_bytes / c_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": c_bytes,
+            "avg_launch_ms": c_s * 1e3,
+            "tiles_per_s": n / c_s,
+            "tiles_per_launch": n,
+        }
+        del planes, cout
+
+    # ---- CPU baseline: the oracle on the host cores (rank 0, N = 1 only) ---------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py
+
+        cores = os.cpu_count() or 1
+        probe = dl.subset(range(min(8, dl.n_jobs)))
+        t = time.perf_counter()
+        oracle_py.render_batch(probe, threads=1)
+        per_tile = (time.perf_counter() - t) / probe.n_jobs
+        # bounded sample: ~15 s of wall time if the cores scaled perfectly, at least 16 tiles per
+        # thread (so the per-thread canvas allocation is amortised), at most 16384 tiles; tiles
+        # beyond the step's own batch continue the same generator (same tile numbering).
+        n_sample = int(min(16384, max(16 * cores, 15.0 / per_tile)))
+        sample = synth.make_tiles(synth.config_tiles(n_sample * world)[rank::world], zoom=15, scale=args.scale)
+        t = time.perf_counter()
+        cpu_out = oracle_py.render_batch(sample, threads=cores)
+        cpu_s = time.perf_counter() - t
+        n_cmp = min(n_sample, dl.n_jobs)
+        cpu_out = cpu_out[:n_cmp]
+        n_sample_cmp = n_cmp
+        gpu_out = out[:n_sample_cmp].cpu().numpy()
+        result["cpu_baseline"] = {
+            "value": n_sample / cpu_s,
+            "unit": "tiles/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"{n_sample} tiles of the same workload (the batch's own tiles first), C++ oracle (restatement of the reference's Rust "
+            f"CPU path incl. its 3x3-tile canvas), {cores} threads, one canvas per thread, tiles round-robin; "
+            f"single-thread probe {1.0 / per_tile:.1f} tiles/s",
+            "single_thread_tiles_per_s": 1.0 / per_tile,
+            "gpu_matches_oracle_on_sample": bool(np.array_equal(gpu_out, cpu_out)),
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    scene.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
