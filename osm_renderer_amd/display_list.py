@@ -120,7 +120,7 @@ class DisplayList:
             ring_cursor += len(r)
             d = self.dashes[o["dashes_off"] : o["dashes_off"] + o["n_dashes"]]
             dashes_l.append(d)
-            o["dashes_off"] = dash_cursor
+            o["dashes_off"] = dash_cursor if len(d) else 0
             dash_cursor += len(d)
         job = np.array([j], dtype=JOB_DTYPE)
         job["op_off"] = 0
@@ -145,7 +145,7 @@ def concat(lists):
         j["pt_off"] += o_pt
         o = dl.ops.copy()
         o["ring_off"] += o_ring
-        o["dashes_off"] += o_dash
+        o["dashes_off"] += np.where(o["n_dashes"] > 0, o_dash, 0).astype(np.uint32)
         r = dl.rings.copy()
         r["first_pt"] += o_pt
         jobs.append(j)

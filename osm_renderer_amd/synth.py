@@ -152,7 +152,7 @@ def make_tiles(
     ops["has_dashes"][:, n_poly:] = dashed
     ops["n_dashes"][:, n_poly:] = np.where(dashed, 2, 0)
     dash_off = np.cumsum(np.where(dashed, 2, 0).reshape(-1)) - np.where(dashed, 2, 0).reshape(-1)
-    ops["dashes_off"][:, n_poly:] = dash_off.reshape(n, n_line)
+    ops["dashes_off"][:, n_poly:] = np.where(dashed, dash_off.reshape(n, n_line), 0)
     dashes = (DASH_PATTERNS[dash_idx[dashed]] * s).reshape(-1)
 
     rings = np.zeros((n, ops_per_tile), RING_DTYPE)

@@ -1,0 +1,47 @@
+// Host build of the closed forms the HIP kernels use (osm_renderer_amd/csrc/osmt_geom.h) plus
+// sizeof/offsetof probes of the C ABI structs, for the CPU-side tests.
+#include <cstddef>
+#include <cstdint>
+
+#include "../include/osmtile.h"
+#include "../osm_renderer_amd/csrc/osmt_geom.h"
+
+extern "C" {
+int shim_fill_row_extent(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t y, int32_t* xmin, int32_t* xmax) {
+    return osmt_fill_row_extent(p1x, p1y, p2x, p2y, y, xmin, xmax);
+}
+// all rows of one edge at once: out[(y - y_lo)] = {present, xmin, xmax}
+void shim_fill_rows(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t y_lo, int32_t y_hi, int32_t* out) {
+    for (int32_t y = y_lo; y <= y_hi; ++y) {
+        int32_t a = 0, b = 0;
+        const int r = osmt_fill_row_extent(p1x, p1y, p2x, p2y, y, &a, &b);
+        out[3 * (y - y_lo) + 0] = r;
+        out[3 * (y - y_lo) + 1] = a;
+        out[3 * (y - y_lo) + 2] = b;
+    }
+}
+// all steps k = 0..b of one segment: out[k] = {c, pe, has_extra, pe_extra}
+void shim_stroke_steps(int32_t a, int32_t b, int32_t* out) {
+    for (int32_t k = 0; k <= b; ++k) osmt_stroke_step(a, b, k, &out[4 * k], &out[4 * k + 1], &out[4 * k + 2], &out[4 * k + 3]);
+}
+int64_t shim_udiv(int64_t n, int64_t d) { return osmt_udiv(n, d); }
+size_t shim_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(osmt_op);
+        case 1: return sizeof(osmt_ring);
+        case 2: return sizeof(osmt_tile_job);
+        case 3: return sizeof(osmt_batch);
+        case 4: return sizeof(osmt_config);
+        case 10: return offsetof(osmt_op, opacity);
+        case 11: return offsetof(osmt_op, width);
+        case 12: return offsetof(osmt_op, n_dashes);
+        case 13: return offsetof(osmt_op, image_id);
+        case 20: return offsetof(osmt_tile_job, n_ops);
+        case 21: return offsetof(osmt_tile_job, pt_off);
+        case 30: return offsetof(osmt_batch, coord_kind);
+        case 31: return offsetof(osmt_batch, latlon);
+        case 32: return offsetof(osmt_batch, dashes);
+    }
+    return 0;
+}
+}

@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/osmtile.h declares; the ctypes /
+numpy mirrors have the header's layout.  No compute calls (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from osm_renderer_amd import abi, display_list, lib
+from tests import _shim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "osmtile.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(osmt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_lists():
+    assert _declared_symbols() == sorted(lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.fail("libosmtile.so is not built: run __graft_entry__.build()")
+    L = lib.load()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    assert L.osmt_version() >> 16 == 1
+
+
+def test_struct_layouts_match_the_header():
+    s = _shim.lib().shim_sizeof
+    assert s(0) == C.sizeof(abi.Op) == display_list.OP_DTYPE.itemsize == 64
+    assert s(1) == C.sizeof(abi.Ring) == display_list.RING_DTYPE.itemsize == 8
+    assert s(2) == C.sizeof(abi.TileJob) == display_list.JOB_DTYPE.itemsize == 32
+    assert s(3) == C.sizeof(abi.Batch)
+    assert s(4) == C.sizeof(abi.Config)
+    assert s(10) == abi.Op.opacity.offset == display_list.OP_DTYPE.fields["opacity"][1]
+    assert s(11) == abi.Op.width.offset == display_list.OP_DTYPE.fields["width"][1]
+    assert s(12) == abi.Op.n_dashes.offset == display_list.OP_DTYPE.fields["n_dashes"][1]
+    assert s(13) == abi.Op.image_id.offset == display_list.OP_DTYPE.fields["image_id"][1]
+    assert s(20) == abi.TileJob.n_ops.offset == display_list.JOB_DTYPE.fields["n_ops"][1]
+    assert s(21) == abi.TileJob.pt_off.offset == display_list.JOB_DTYPE.fields["pt_off"][1]
+    assert s(30) == abi.Batch.coord_kind.offset
+    assert s(31) == abi.Batch.latlon.offset
+    assert s(32) == abi.Batch.dashes.offset
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    """Without a GPU osmt_create must fail with OSMT_NO_DEVICE (there is no CPU path)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = lib.load()
+    h = C.c_void_p()
+    rc = L.osmt_create(None, C.byref(h))
+    assert rc == abi.NO_DEVICE and not h.value
+    assert b"no CPU path" in L.osmt_last_error()
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under osm_renderer_amd/ may import, link or call oracle/."""
+    pkg = os.path.join(ROOT, "osm_renderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_py" not in text and "liboracle" not in text and "osm_oracle" not in text, f

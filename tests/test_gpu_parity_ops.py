@@ -1,0 +1,263 @@
+"""Differential GPU-vs-oracle tests per operation, through the C ABI: the K1..K8 vectors and
+the edge cases of fill.rs / line.rs / opacity_calculator.rs / tile_pixels.rs.  Integer
+coverage and the f64 canvas must be bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from osm_renderer_amd import abi, display_list
+from osm_renderer_amd.display_list import TileBuilder
+from tests._parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+CAPS = [abi.CAP_NONE, abi.CAP_BUTT, abi.CAP_ROUND, abi.CAP_SQUARE]
+
+
+def _f64(gpu_ctx, dl):
+    scene = gpu_ctx.upload(dl)
+    out = gpu_ctx.render_f64(scene).cpu().numpy()
+    scene.free()
+    return out
+
+
+def _alpha_of_single_op(gpu_ctx, dl):
+    """With a black canvas (0,0,0,1) and a white op, canvas.r == the op's alpha exactly
+    (a*1.0 + (1-a)*0.0)."""
+    return _f64(gpu_ctx, dl)[0, :, :, 0]
+
+
+def test_k1_k2_fill_coverage(gpu_ctx):
+    for key in ("K1_fill_square", "K2_fill_triangle"):
+        tb = TileBuilder(canvas=None)
+        tb.fill(KAT[key]["ring"], (255, 255, 255), 1.0)
+        a = _alpha_of_single_op(gpu_ctx, tb.build())
+        ys, xs = np.nonzero(a)
+        got = set(zip(xs.tolist(), ys.tolist()))
+        if key == "K1_fill_square":
+            k = KAT[key]
+            want = {(x, y) for x in range(k["x"][0], k["x"][1] + 1) for y in range(k["y"][0], k["y"][1] + 1)}
+        else:
+            want = {(x, int(y)) for y, (lo, hi) in KAT[key]["row_spans"].items() for x in range(lo, hi + 1)}
+        assert got == want
+
+
+def test_k4_k5_stroke_alpha(gpu_ctx):
+    import math
+
+    k = KAT["K4_stroke_h"]
+    tb = TileBuilder(canvas=None)
+    tb.stroke([k["p1"], k["p2"]], k["width"], (255, 255, 255))
+    a = _alpha_of_single_op(gpu_ctx, tb.build())
+    ys, xs = np.nonzero(a)
+    assert set(ys.tolist()) == {9, 10, 11} and xs.min() == 10 and xs.max() == 14 and set(np.unique(a[a > 0])) == {1.0}
+    k = KAT["K5_stroke_diag"]
+    tb = TileBuilder(canvas=None)
+    tb.stroke([k["p1"], k["p2"]], k["width"], (255, 255, 255))
+    a = _alpha_of_single_op(gpu_ctx, tb.build())
+    ys, xs = np.nonzero(a)
+    assert set(zip(xs.tolist(), ys.tolist())) == {(x, int(y)) for y, xs_ in k["pixels"].items() for x in xs_}
+    for y, xs_ in k["pixels"].items():
+        for x in xs_:
+            assert abs(a[int(y), x] - min(1.0, 1.5 - abs(3 * x - 7 * int(y) + 8) / math.sqrt(58))) < 1e-12
+
+
+def test_k6_blend_chain(gpu_ctx, oracle):
+    k = KAT["K6_blend"]
+    tb = TileBuilder(canvas=tuple(k["canvas"]))
+    sq = [(0, -1), (3, -1), (3, 3), (0, 3), (0, -1)]
+    tb.fill(sq, tuple(k["steps"][0]["color"]), k["steps"][0]["alpha"])
+    tb.fill(sq, tuple(k["steps"][1]["color"]), k["steps"][1]["alpha"])
+    got = assert_parity(gpu_ctx, oracle, tb.build(), msg="K6")
+    assert got[0, 0, 0, :3].tolist() == k["steps"][1]["rgb"]
+
+
+def test_empty_and_degenerate(gpu_ctx, oracle):
+    tb = TileBuilder()
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="no ops")  # canvas only
+    tb = TileBuilder(canvas=None)
+    tb.nop()
+    tb.fill([(5, 5)], (1, 2, 3))  # single point: no edges
+    tb.fill([(5, 5), (5, 5)], (1, 2, 3))  # zero-length edge
+    tb.fill([(5, 5), (50, 5), (5, 5)], (200, 2, 3))  # horizontal only: every row poisoned
+    tb.fill([(5, 5), (5, 60), (5, 5)], (3, 200, 3))  # zero-area vertical sliver
+    tb.stroke([(7, 7)], 3.0, (9, 9, 9))
+    tb.stroke([(7, 7), (7, 7)], 3.0, (9, 9, 9), cap=abi.CAP_ROUND)
+    tb.stroke([(7, 7), (7, 7), (20, 9)], 3.0, (99, 9, 9), cap=abi.CAP_ROUND)  # degenerate first edge clears `first`
+    tb.stroke([(30, 30), (60, 30)], 0.0, (9, 99, 9))  # zero width
+    tb.fill([(100, 100), (140, 100), (140, 140), (100, 140), (100, 100)], (9, 9, 99), 0.0)  # zero opacity
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="degenerate")
+
+
+def test_fills_random_polygons(gpu_ctx, oracle):
+    rnd = np.random.default_rng(1234)
+    tiles = []
+    for t in range(6):
+        tb = TileBuilder(canvas=(rnd.integers(0, 256), rnd.integers(0, 256), rnd.integers(0, 256)))
+        for _ in range(25):
+            n = int(rnd.integers(3, 12))
+            c = rnd.integers(-40, 296, size=2)
+            pts = (c + rnd.integers(-70, 71, size=(n, 2))).tolist()  # self-intersecting, any winding
+            if rnd.random() < 0.8:
+                pts.append(pts[0])  # closed (open contours are legal too: edges are just pairs)
+            tb.fill(pts, tuple(rnd.integers(0, 256, size=3)), float(rnd.choice([1.0, 0.7, 0.33, 0.05])))
+        tiles.append(tb.build())
+    assert_parity(gpu_ctx, oracle, display_list.concat(tiles), msg="random fills")
+
+
+def test_fill_far_outside_and_huge_edges(gpu_ctx, oracle):
+    tb = TileBuilder()
+    tb.fill([(-100000, -70000), (90000, -3000), (40000, 150000), (-100000, -70000)], (10, 200, 30), 0.6)
+    tb.fill([(-5, -5), (300, -5), (300, 300), (-5, 300), (-5, -5)], (200, 20, 30), 0.4)  # covers the tile
+    tb.fill([(1000, 1000), (2000, 1000), (1500, 3000), (1000, 1000)], (1, 2, 3))  # fully outside
+    tb.fill([(-2000000, 10), (2000000, 200), (-2000000, 250), (-2000000, 10)], (0, 0, 255), 0.5)  # 4M px long
+    tb.fill([(128, -3000000), (140, 3000000), (100, 3000000), (128, -3000000)], (255, 0, 255), 0.5)
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="huge fills")
+
+
+def test_multipolygon_rings_share_one_edge_index(gpu_ctx, oracle):
+    # outer ring + hole + island in the hole: even-odd over all rings together (fill.rs:19)
+    outer = [(20, 20), (220, 25), (230, 210), (15, 200), (20, 20)]
+    hole = [(60, 60), (180, 70), (170, 160), (70, 150), (60, 60)]
+    island = [(100, 90), (140, 95), (135, 130), (100, 90)]
+    tb = TileBuilder()
+    tb.fill([outer, hole, island], (30, 90, 200), 0.8)
+    tb.fill([hole, outer], (200, 90, 30), 0.5)  # ring order changes the stable-sort tie-breaks
+    tb.fill([outer, outer], (9, 200, 9), 0.5)  # duplicated ring: pairs cancel differently
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="multipolygon")
+
+
+def test_fill_many_crossings_uses_the_streaming_path(gpu_ctx, oracle):
+    # a comb with > 32 crossings per row in one 32-px sub-tile column band (ROWCAP overflow)
+    pts = []
+    for i in range(60):
+        x = 2 + 4 * i
+        pts += [(x, 10), (x + 1, 200), (x + 2, 10)]
+    pts += [(250, 5), (2, 5), (2, 10)]
+    tb = TileBuilder(scale=1)
+    tb.fill(pts, (10, 10, 200), 0.7)
+    dense = []
+    for i in range(80):  # 160 crossings inside x in [32, 64)
+        x = 32 + (i * 31) % 32
+        dense += [(x, 20 + (i % 7)), (x + (i % 3) - 1, 230 - (i % 11))]
+    dense.append(dense[0])
+    tb.fill(dense, (200, 10, 10), 0.6)
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="comb")
+
+
+def test_image_fill(gpu_ctx, oracle):
+    rnd = np.random.default_rng(5)
+    icon = rnd.integers(0, 256, size=(7, 5, 4), dtype=np.uint8)
+    icon[0, 0, 3] = 0
+    icon[1, 1, 3] = 255
+    icon2 = rnd.integers(0, 256, size=(16, 16, 4), dtype=np.uint8)
+    ids = [gpu_ctx.register_image(icon), gpu_ctx.register_image(icon2)]
+    assert ids[1] == ids[0] + 1
+    images = [None] * ids[0] + [icon, icon2]
+    images = [im if im is not None else np.zeros((1, 1, 4), np.uint8) for im in images]
+    tb = TileBuilder(scale=2)
+    tb.fill([(10, 10), (400, 40), (300, 480), (30, 300), (10, 10)], (0, 0, 0), 1.0)
+    tb.fill_image([(50, 50), (450, 90), (350, 400), (60, 350), (50, 50)], ids[0], opacity=0.3)  # opacity ignored
+    tb.fill_image([(-20, 200), (600, 220), (300, 520), (-20, 200)], ids[1])
+    tb.fill_image([(0, 0), (10, 0), (10, 10), (0, 0)], 9999)  # unknown icon: draws nothing
+    assert_parity(gpu_ctx, oracle, tb.build(), images=images, msg="image fill")
+
+
+@pytest.mark.parametrize("scale", [1, 2])
+def test_strokes_all_caps_dashes_widths(gpu_ctx, oracle, scale):
+    rnd = np.random.default_rng(77 + scale)
+    dash_sets = [None, [3, 3], [10, 8], [6, 6], [1, 2, 3], [0.5, 0.5], [12, 3, 2, 3], [4]]
+    widths = [0.0, 0.1, 0.5, 1.0, 1.5, 2.0, 3.0, 4.5, 7.0, 15.0]
+    tiles = []
+    W = 256 * scale
+    for t in range(10):
+        tb = TileBuilder(scale=scale, canvas=(252, 248, 228))
+        for _ in range(14):
+            n = int(rnd.integers(2, 7))
+            p0 = rnd.integers(-20, W + 20, size=2)
+            pts = (p0 + np.cumsum(rnd.integers(-60 * scale, 60 * scale + 1, size=(n, 2)), axis=0)).tolist()
+            d = dash_sets[int(rnd.integers(0, len(dash_sets)))]
+            tb.stroke(
+                pts,
+                float(widths[int(rnd.integers(0, len(widths)))]) * scale,
+                tuple(rnd.integers(0, 256, size=3)),
+                float(rnd.choice([1.0, 0.6, 0.3])),
+                dashes=None if d is None else [v * scale for v in d],
+                cap=CAPS[int(rnd.integers(0, 4))],
+                use_caps_for_dashes=bool(rnd.integers(0, 2)),
+            )
+        tiles.append(tb.build())
+    assert_parity(gpu_ctx, oracle, display_list.concat(tiles), msg=f"strokes scale {scale}")
+
+
+def test_stroke_every_direction(gpu_ctx, oracle):
+    # direction sensitivity (SURVEY.md 7 "hard parts"): all octants, both orientations, steep & shallow
+    tb = TileBuilder()
+    c = (128, 128)
+    k = 0
+    for dx in range(-6, 7):
+        for dy in (-6, -3, -1, 0, 1, 3, 6):
+            if dx == 0 and dy == 0:
+                continue
+            e = (c[0] + 17 * dx, c[1] + 17 * dy)
+            tb.stroke([c, e] if k % 2 else [e, c], 1.0 + (k % 5), ((37 * k) % 256, (91 * k) % 256, (53 * k) % 256), 0.5,
+                      cap=CAPS[k % 4])
+            k += 1
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="directions")
+
+
+def test_stroke_long_segments_crossing_the_tile(gpu_ctx, oracle):
+    tb = TileBuilder(scale=2)
+    tb.stroke([(-30000, -20000), (30500, 20400)], 9.0, (200, 0, 0), 0.7, dashes=[30, 10], cap=abi.CAP_ROUND,
+              use_caps_for_dashes=True)
+    tb.stroke([(100, -400000), (130, 400000)], 5.0, (0, 0, 200), 0.7)
+    tb.stroke([(-400000, 300), (400000, 310)], 3.0, (0, 200, 0), 0.7, dashes=[7, 7])
+    tb.stroke([(1000, 1000), (5000, 5000)], 20.0, (1, 1, 1))  # outside
+    tb.stroke([(515, 100), (530, 400)], 12.0, (9, 9, 9), cap=abi.CAP_SQUARE)  # only its feather reaches the tile
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="long segments")
+
+
+def test_polyline_traveled_distance_and_caps(gpu_ctx, oracle):
+    # dash phase carries across edges (line.rs:31); caps only on the first / last edge (line.rs:33-57)
+    pts = [(20, 200), (60, 30), (60, 30), (110, 190), (160, 40), (230, 220)]
+    tb = TileBuilder()
+    for i, cap in enumerate(CAPS):
+        off = [(x, y + 6 * i - 9) for x, y in pts]
+        tb.stroke(off, 4.0, (20 + 50 * i, 10, 200 - 40 * i), 0.9, dashes=[9, 5], cap=cap, use_caps_for_dashes=(i % 2 == 0))
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="traveled")
+
+
+def test_many_ops_per_tile_more_than_one_chunk(gpu_ctx, oracle):
+    rnd = np.random.default_rng(3)
+    tb = TileBuilder()
+    for i in range(700):  # > 256 ops: several cull chunks; interleaved kinds keep the order honest
+        p = rnd.integers(0, 256, size=2)
+        if i % 3 == 0:
+            q = p + rnd.integers(-40, 41, size=2)
+            tb.stroke([p.tolist(), q.tolist()], float(rnd.choice([1, 2, 4])), tuple(rnd.integers(0, 256, size=3)), 0.6)
+        elif i % 3 == 1:
+            r = rnd.integers(4, 30)
+            tb.fill([(p[0] - r, p[1] - r), (p[0] + r, p[1] - r // 2), (p[0], p[1] + r), (p[0] - r, p[1] - r)],
+                    tuple(rnd.integers(0, 256, size=3)), 0.5)
+        else:
+            tb.nop()
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="many ops")
+
+
+def test_no_canvas_and_scales(gpu_ctx, oracle):
+    for scale in (1, 2, 3):
+        tb = TileBuilder(scale=scale, canvas=None)
+        s = scale
+        tb.fill([(10 * s, 10 * s), (200 * s, 30 * s), (120 * s, 240 * s), (10 * s, 10 * s)], (250, 120, 20), 0.75)
+        tb.stroke([(0, 0), (255 * s, 255 * s)], 3.0 * s, (255, 255, 255), 0.5, dashes=[5 * s, 5 * s])
+        assert_parity(gpu_ctx, oracle, tb.build(), msg=f"scale {scale}")
+
+
+def test_dense_config5_tile(gpu_ctx, oracle):
+    from osm_renderer_amd import synth
+
+    dl = synth.make_tiles(synth.config_tiles(1, x0=79000, y0=40000), zoom=17, n_poly=1500, n_line=1200,
+                          radius=(2.0, 12.0), step=12.0)
+    assert_parity(gpu_ctx, oracle, dl, msg="dense")
