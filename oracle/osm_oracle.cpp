@@ -10,18 +10,24 @@
  * leg — as the checker / the timed CPU baseline.  libosmtile.so never links it.
  *
  * PARITY PIN STATUS
- *   - projection (tile.rs:88-106): PINNED by the reference's own doctest
- *     known-answer values (src/tile.rs:26-28, 83-86), see tests/test_oracle_kat.py.
- *   - fill / stroke / blend / RGB (fill.rs, line.rs, opacity_calculator.rs,
- *     tile_pixels.rs): the reference cannot be built here (no rustc/cargo, crates
- *     not vendored) and its only executable pins — tests/test_rendering.rs vs
- *     tests/rendered/{14..18}_expected.png — need tests/osm/nano_moscow.osm, which is
- *     absent from the mount.  These parts are checked against (a) hand/emulation
- *     derived known-answer fixtures K1..K8 (tests/golden/kat_*.json, derived from
- *     the reference SOURCE, not from running it) and (b) patches of the
- *     reference's real golden PNGs re-synthesised by tests/golden/fit_*.json
- *     where such fits exist (see DESIGN.md "Oracle pinning").  Where neither
- *     applies the status is: PARITY UNPINNED.
+ *   - projection (tile.rs:88-106): PINNED by the reference's own doctest known-answer
+ *     values (src/tile.rs:26-28, 83-86) — tests/test_oracle_kat.py.
+ *   - stroke walk + across-feathering + round caps + two-generation "over" blend + u8
+ *     truncation (line.rs, opacity_calculator.rs:171-185,98-143 with the [0.0] cap pattern,
+ *     tile_pixels.rs): PINNED by a crop of the reference's real golden image
+ *     tests/rendered/18_expected.png (852 pixels of a service-road stub, 24 distinct
+ *     colours, reproduced with 0 differing pixels; +-1 px / reversed inputs do not match).
+ *   - polygon fill rule (fill.rs: fat Bresenham extents, smaller-y-row exclusion, pairing):
+ *     PINNED by a second crop of the same golden (3411-pixel opaque polygon reproduced
+ *     exactly by a fitted 16-vertex ring).  Both crops: tests/golden/ref_z18_patches.json,
+ *     tests/test_reference_golden_patches.py; inputs were FITTED (the .osm is missing), see
+ *     tests/golden/make_ref_patches.py for what that does and does not prove.
+ *   - NOT pinned by any reference output (the reference cannot be built here — no
+ *     rustc/cargo, crates not vendored — and tests/osm/nano_moscow.osm is absent): dash
+ *     patterns, square/butt caps, use_caps_for_dashes, image fills, translucent fills,
+ *     multipolygon rings.  For these the oracle is checked only against the hand-derived
+ *     vectors K1..K8 (tests/golden/kat.json, derived from the reference SOURCE).  Status of
+ *     those parts: PARITY UNPINNED.
  *
  * Rust -> C++ semantics kept on purpose:
  *   f64::round -> std::round (half away from zero); `as i32` / `as u8` ->
