@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU per step")
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--composite-tiles", type=int, default=64)
+    ap.add_argument("--n-poly", type=int, default=50, help="diagnostic: polygons per tile (default = the named config)")
+    ap.add_argument("--n-line", type=int, default=40, help="diagnostic: polylines per tile (default = the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     args = ap.parse_args()
@@ -69,7 +71,7 @@ def main():
     # ---- workload: tile i of the global batch -> rank i mod world --------------------
     global_tiles = synth.config_tiles(args.tiles * world)
     mine = global_tiles[rank::world]
-    dl = synth.make_tiles(mine, zoom=15, scale=args.scale)
+    dl = synth.make_tiles(mine, zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
     scene = ctx.upload(dl)
     out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -134,6 +136,8 @@ def main():
             "synthetic 50-poly/200-segment geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input "
             "resident in HBM, RGBA8 framebuffers written to HBM",
             "tiles_per_gpu": args.tiles,
+            "polygons_per_tile": args.n_poly,
+            "polylines_per_tile": args.n_line,
             "scale": args.scale,
             "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
         },

@@ -177,7 +177,8 @@ int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, ui
 /* planes: [n][L][H][W][4] premultiplied f64 RGBA (NextPixel.color of L
  * successive generations); canvas_rgba: premultiplied f64[4]; result per pixel:
  * dst = canvas; for l in 0..L: dst = src_l + (1 - src_l.a) * dst; then
- * un-premultiply + truncate to u8 -> out_rgba [n][H][W][4], A = 255. */
+ * un-premultiply + truncate to u8 -> out_rgba [n][H][W][4], A = 255.
+ * W*H must be a multiple of 64 (true for every (256*scale)^2 tile). */
 int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas_rgba[4], uint32_t n, uint32_t L,
                    uint32_t W, uint32_t H, uint8_t* out_rgba);
 /* DEVICE pointers; asynchronous on `stream`. */

@@ -27,6 +27,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Experimental kernel variant: libosmtile_<name>.so built with extra -D flags (see tools/)."""
+    out = os.path.join(HERE, f"libosmtile_{name}.so")
+    cmd = [_hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

@@ -71,6 +71,7 @@ struct osmt_scene {
     osmt_opinfo* d_info = nullptr;
     double* d_trav = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
+    uint32_t* d_submask = nullptr;
 };
 
 namespace {
@@ -159,7 +160,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_aux, st));
+                                   sc->d_trav, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / 32, st));
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
@@ -174,6 +175,8 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.pts = reinterpret_cast<const int2*>(sc->d_pts);
         a.trav = sc->d_trav;
         a.aux = sc->d_aux;
+        a.submask = sc->d_submask;
+        a.sub_rows = OSMT_TILE_SIZE * sc->scale / 32;
         a.images = ctx->d_images;
         a.image_pool = ctx->d_image_pool;
         a.n_images = (uint32_t)ctx->images.size();
@@ -289,6 +292,8 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
+    const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / 32;
+    const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     s->bytes = off + 256;
     hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
@@ -307,6 +312,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->d_info = (osmt_opinfo*)(s->d_base + o_info);
     s->d_trav = (double*)(s->d_base + o_trav);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
+    s->d_submask = (uint32_t*)(s->d_base + o_submask);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
@@ -413,6 +419,7 @@ int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canv
                           uint32_t W, uint32_t H, void* d_out, void* stream) {
     if (!ctx || !canvas) return fail(OSMT_INVALID_ARG, "NULL argument");
     if ((uint64_t)W * H >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "tile too large");
+    if (((uint64_t)W * H) % 64u) return fail(OSMT_INVALID_ARG, "W*H must be a multiple of 64 (tiles are (256*scale)^2)");
     if ((size_t)n * W * H && (!d_planes || !d_out)) return fail(OSMT_INVALID_ARG, "NULL device pointer");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(osmt_launch_composite(d_planes, canvas, n, L, W * H, d_out, (hipStream_t)stream));

@@ -27,6 +27,9 @@ struct osmt_dash_table {
 /* the two calculators of draw_lines (line.rs:21-22) */
 struct osmt_stroke_aux {
     double half_width;
+    /* get_opacity_by_center_distance terms for cap_dist == 0 (opacity_calculator.rs:36,171-176):
+     * hlw0 = sqrt(h*h - 0*0), feather_from/to/dist and opacity_mul of hlw0 */
+    double hlw0, ff0, ft0, fd0, mul0;
     osmt_dash_table main;
     osmt_dash_table caps;
 };
@@ -54,6 +57,9 @@ struct osmt_raster_args {
     const int2* pts;
     const double* trav;
     const osmt_stroke_aux* aux;
+    const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
+    uint32_t sub_rows;       /* W / 32 */
+    uint32_t _pad0;
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -68,7 +74,7 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
                                       double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              osmt_stroke_aux* aux, hipStream_t st);
+                              osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);

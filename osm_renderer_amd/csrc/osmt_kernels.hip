@@ -126,6 +126,30 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
     t->total_len = len_before;
 }
 
+/* Marks the sub-tiles whose rectangle grown by g pixels intersects the segment a-b
+ * (separating axes: x, y and the segment's normal; exact in int64). */
+__device__ void mark_segment(uint32_t* __restrict__ sm, int32_t n_sub, int32_t ax, int32_t ay, int32_t bx, int32_t by,
+                             int32_t g) {
+    const int32_t sx0 = max((min(ax, bx) - g) >> 5, 0), sx1 = min((max(ax, bx) + g) >> 5, n_sub - 1);
+    const int32_t sy0 = max((min(ay, by) - g) >> 5, 0), sy1 = min((max(ay, by) + g) >> 5, n_sub - 1);
+    if (sx0 > sx1 || sy0 > sy1) return;
+    const int64_t dx = (int64_t)bx - ax, dy = (int64_t)by - ay;
+    for (int32_t sy = sy0; sy <= sy1; ++sy) {
+        const int64_t y0 = (int64_t)sy * 32 - g - ay, y1 = (int64_t)sy * 32 + 31 + g - ay;
+        uint32_t bits = 0u;
+        for (int32_t sx = sx0; sx <= sx1; ++sx) {
+            const int64_t x0 = (int64_t)sx * 32 - g - ax, x1 = (int64_t)sx * 32 + 31 + g - ax;
+            /* cross(d, corner - a) for the four corners */
+            const int64_t c00 = dx * y0 - dy * x0, c10 = dx * y0 - dy * x1;
+            const int64_t c01 = dx * y1 - dy * x0, c11 = dx * y1 - dy * x1;
+            const bool all_pos = c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0;
+            const bool all_neg = c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0;
+            if (!(all_pos || all_neg)) bits |= 1u << sx;
+        }
+        sm[sy] |= bits;
+    }
+}
+
 /* Per-op pre-pass: pixel extents (for sub-tile culling), traveled distance before every
  * edge of a stroke (line.rs:31: add_traveled_distance, summed in edge order), and the two
  * dash tables of draw_lines (line.rs:21-22). One thread per op. */
@@ -133,10 +157,13 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                                                const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
                                                const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
                                                osmt_opinfo* __restrict__ info, double* __restrict__ trav,
-                                               osmt_stroke_aux* __restrict__ aux) {
+                                               osmt_stroke_aux* __restrict__ aux, uint32_t* __restrict__ submask,
+                                               uint32_t sub_rows) {
     const uint32_t o = blockIdx.x * 64u + threadIdx.x;
     if (o >= n_ops) return;
     const osmt_op op = ops[o];
+    uint32_t* __restrict__ sm = submask + (size_t)o * sub_rows;
+    for (uint32_t r = 0; r < sub_rows; ++r) sm[r] = 0u;
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
     oi.x1 = oi.y1 = INT32_MIN;
@@ -181,8 +208,31 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
             oi.x1 += reach + cap_reach;
             oi.y1 += reach + cap_reach;
         }
+        /* sub-tile coverage: a sub-tile is marked when its rectangle grown by reach+1 (the
+         * Bresenham centre is within 0.5 px of the ideal segment) meets the segment; the cap
+         * stubs (length <= hw + 1) are covered by growing the first/last edge's test further */
+        {
+            const int32_t n_sub = (int32_t)sub_rows;
+            uint32_t e_seen = 0;
+            for (uint32_t r = 0; r < op.n_rings; ++r) {
+                const osmt_ring ring = rings[op.ring_off + r];
+                for (uint32_t i = 1; i < ring.n_pts; ++i) {
+                    const int2 a = pts[ring.first_pt + i - 1];
+                    const int2 b = pts[ring.first_pt + i];
+                    ++e_seen;
+                    const bool endcap = caps && (e_seen == 1 || e_seen == n_edges);
+                    const int32_t g = reach + 1 + (endcap ? cap_reach : 0);
+                    mark_segment(sm, n_sub, a.x, a.y, b.x, b.y, g);
+                }
+            }
+        }
         osmt_stroke_aux* sa = &aux[oi.aux];
         sa->half_width = hw;
+        sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
+        sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
+        sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
+        sa->fd0 = sa->ft0 - sa->ff0;
+        sa->mul0 = fmin(2.0 * sa->hlw0, 1.0);
         const int cap_for_dashes = op.use_caps_for_dashes ? op.cap : OSMT_CAP_NONE;
         if (op.has_dashes) {
             compute_segments(hw, dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes, &sa->main);
@@ -198,6 +248,16 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         sa->caps.n_segs = 1;
     } else {
         oi.reach = 0;
+        /* fills: every sub-tile of the extent (rows ytop+1..ybot only carry records) */
+        if (oi.x0 <= oi.x1) {
+            const int32_t n_sub = (int32_t)sub_rows;
+            const int32_t sx0 = max(oi.x0 >> 5, 0), sx1 = min(oi.x1 >> 5, n_sub - 1);
+            const int32_t sy0 = max((oi.y0 + 1) >> 5, 0), sy1 = min(oi.y1 >> 5, n_sub - 1);
+            if (sx0 <= sx1) {
+                const uint32_t bits = (uint32_t)((((uint64_t)1 << (sx1 - sx0 + 1)) - 1) << sx0);
+                for (int32_t sy = sy0; sy <= sy1; ++sy) sm[sy] |= bits;
+            }
+        }
     }
     info[o] = oi;
 }
@@ -271,7 +331,10 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
 constexpr int SUB = 32;            /* sub-tile edge in pixels */
 constexpr int NTHREADS = 256;      /* 4 waves */
 constexpr int PXT = SUB * SUB / NTHREADS; /* pixels per thread = 4 */
-constexpr int ROWCAP = 32;         /* crossing records kept per row before the slow path */
+#ifndef OSMT_V_ROWCAP
+#define OSMT_V_ROWCAP 32
+#endif
+constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path */
 constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
 
 struct RowRec {
@@ -301,24 +364,52 @@ __device__ __forceinline__ void blend_px(double* acc, double sr, double sg, doub
     acc[3] = sa + k * acc[3];
 }
 
-/* One perpendicular run (line.rs:108-137). */
-__device__ __forceinline__ void walk_perpendicular(const osmt_seg& s, const osmt_dash_table* __restrict__ tab,
-                                                   double half_width, double traveled, double initial_opacity,
-                                                   int32_t mn, int32_t mx, int32_t p_error, int32_t mul,
-                                                   const SubRect& rc, unsigned long long* __restrict__ plane) {
+/* One perpendicular run (line.rs:108-137).  PLAIN = the calculator has no dash segments
+ * (get_opacity_by_start_distance returns (1.0, None) without looking at the distance,
+ * opacity_calculator.rs:50-55), so long_start_dist / short_start_dist are dead values and
+ * the feather terms are the per-op constants of osmt_stroke_aux. */
+__device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_seg& s,
+                                                   const osmt_stroke_aux* __restrict__ sa,
+                                                   const osmt_dash_table* __restrict__ tab, double traveled,
+                                                   double initial_opacity, int32_t mn, int32_t mx, int32_t p_error,
+                                                   int32_t mul, const SubRect& rc,
+                                                   unsigned long long* __restrict__ plane) {
     int32_t p_mn = mx;
     int32_t p_mx = mn;
     int32_t err = mul * p_error;
     const int32_t two_a = 2 * s.a, two_b = 2 * s.b;
+    int32_t px = s.swap ? p_mn : p_mx;
+    int32_t py = s.swap ? p_mx : p_mn;
+    /* center_dist_raw (line.rs:116-117) kept incrementally: exact int64 arithmetic */
+    int64_t raw = s.numer_const + (s.sdy * (int64_t)px - s.sdx * (int64_t)py);
+    const int32_t step_mx = mul * s.mn_inc;  /* p_mx += */
+    const int32_t step_mn = -mul * s.mx_inc; /* p_mn += (when corrected) */
+    const int64_t raw_step = s.swap ? -s.sdx * step_mx : s.sdy * step_mx;
+    const int64_t raw_corr = s.swap ? s.sdy * step_mn : -s.sdx * step_mn;
+    const double half_width = sa->half_width;
+    const double ff0 = sa->ff0, ft0 = sa->ft0, fd0 = sa->fd0, mul0 = sa->mul0;
     for (;;) {
-        const int32_t px = s.swap ? p_mn : p_mx;
-        const int32_t py = s.swap ? p_mx : p_mn;
-        const int64_t raw = s.numer_const + (s.sdy * (int64_t)px - s.sdx * (int64_t)py);
         const double cd = fabs((double)raw) / s.denom;
-        const double ld = point_dist(px, py, s.p1x, s.p1y);
-        const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));
         double op;
-        if (!opacity_calculate(tab, half_width, traveled, cd, sd, &op)) break;
+        bool in_line;
+        if (PLAIN) {
+            /* opacity_calculator.rs:171-185 with half_line_width = sqrt(h*h - 0*0) */
+            double v;
+            if (cd < ff0)
+                v = 1.0;
+            else if (cd < ft0)
+                v = (ft0 - cd) / fd0;
+            else
+                v = 0.0;
+            const double cdop = mul0 * v;
+            op = fmin(1.0, cdop);
+            in_line = cdop > 0.0;
+        } else {
+            const double ld = point_dist(px, py, s.p1x, s.p1y);
+            const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));
+            in_line = opacity_calculate(tab, half_width, traveled, cd, sd, &op);
+        }
+        if (!in_line) break;
         if (px >= rc.x0 && px <= rc.x1 && py >= rc.y0 && py <= rc.y1) {
             const double alpha = initial_opacity * op;
             /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118);
@@ -328,17 +419,19 @@ __device__ __forceinline__ void walk_perpendicular(const osmt_seg& s, const osmt
         /* update_error (line.rs:91-100) */
         if (err + two_a > s.b) {
             err -= two_b;
-            p_mn -= mul * s.mx_inc;
+            if (s.swap) px += step_mn; else py += step_mn;
+            raw += raw_corr;
         }
         err += two_a;
-        p_mx += mul * s.mn_inc;
+        if (s.swap) py += step_mx; else px += step_mx;
+        raw += raw_step;
     }
 }
 
 /* All perpendiculars of one segment that can reach the sub-tile (line.rs:65-158). */
-__device__ void raster_segment(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y,
-                               const osmt_dash_table* __restrict__ tab, double half_width, double traveled,
-                               double initial_opacity, int32_t reach, const SubRect& rc,
+__device__ __forceinline__ void raster_segment(const bool PLAIN, int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y,
+                               const osmt_stroke_aux* __restrict__ sa, const osmt_dash_table* __restrict__ tab,
+                               double traveled, double initial_opacity, int32_t reach, const SubRect& rc,
                                unsigned long long* __restrict__ plane) {
     if (p1x == p2x && p1y == p2y) return;
     /* segment-level cull: every visited pixel lies within `reach` of the segment's box */
@@ -373,13 +466,13 @@ __device__ void raster_segment(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2
         int32_t c, pe, has_extra, pe_extra;
         osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
         const int32_t mx = s.mx0 + k * s.mx_inc;
-        const int32_t mn = s.mn0 + c * s.mn_inc;
-        if (mn >= mlo && mn <= mhi)
-            walk_perpendicular(s, tab, half_width, traveled, initial_opacity, mn, mx, pe, mul, rc, plane);
-        if (has_extra) {
-            const int32_t mn2 = mn + s.mn_inc;
-            if (mn2 >= mlo && mn2 <= mhi)
-                walk_perpendicular(s, tab, half_width, traveled, initial_opacity, mn2, mx, pe_extra, mul, rc, plane);
+        int32_t mn = s.mn0 + c * s.mn_inc;
+        /* the main pair, then the extra pair of line.rs:152-154 when it fires: one call site */
+        for (int32_t w = 0; w <= has_extra; ++w) {
+            if (mn >= mlo && mn <= mhi)
+                walk_perpendicular(PLAIN, s, sa, tab, traveled, initial_opacity, mn, mx, w ? pe_extra : pe, mul, rc,
+                                   plane);
+            mn += s.mn_inc;
         }
     }
 }
@@ -394,13 +487,35 @@ __device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by)
     return r;
 }
 
+#ifndef OSMT_V_WAVES
+#define OSMT_V_WAVES 5
+#endif
+#if OSMT_V_WAVES > 0
+#define OSMT_RASTER_BOUNDS __launch_bounds__(NTHREADS, OSMT_V_WAVES)
+#else
+#define OSMT_RASTER_BOUNDS __launch_bounds__(NTHREADS)
+#endif
+#ifdef OSMT_V_NORESTRICT
+#define OSMT_R
+#else
+#define OSMT_R __restrict__
+#endif
+
 template <bool OUT_F64>
-__global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
+__global__ OSMT_RASTER_BOUNDS void k_raster(
+    /* separate __restrict__ const pointers (not a struct): lets the compiler prove the display
+     * list is read-only and fetch wave-uniform records with scalar loads */
+    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_op* OSMT_R g_ops,
+    const osmt_opinfo* OSMT_R g_info, const osmt_ring* OSMT_R g_rings, const int2* OSMT_R g_pts,
+    const double* OSMT_R g_trav, const osmt_stroke_aux* OSMT_R g_aux,
+    const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
+    const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
+    size_t g_out_tile_stride) {
     __shared__ RasterShared sh;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t W = OSMT_TILE_SIZE * A.scale;
+    const uint32_t W = OSMT_TILE_SIZE * g_scale;
     const uint32_t subs_per_row = W / SUB;
     const uint32_t nsub = subs_per_row * subs_per_row;
 
@@ -411,12 +526,13 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
     const uint32_t rest = b >> 3;
     const uint32_t tile = (rest / nsub) * 8u + xcd;
     const uint32_t sub = rest % nsub;
-    if (tile >= A.n_jobs) return;
+    if (tile >= g_n_jobs) return;
 
-    const osmt_tile_job job = A.jobs[tile];
+    const osmt_tile_job job = g_jobs[tile];
     SubRect rc;
-    rc.x0 = (int32_t)((sub % subs_per_row) * SUB);
-    rc.y0 = (int32_t)((sub / subs_per_row) * SUB);
+    const uint32_t sub_x = sub % subs_per_row, sub_y = sub / subs_per_row;
+    rc.x0 = (int32_t)(sub_x * SUB);
+    rc.y0 = (int32_t)(sub_y * SUB);
     rc.x1 = rc.x0 + SUB - 1;
     rc.y1 = rc.y0 + SUB - 1;
 
@@ -450,10 +566,8 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
         /* ---- ordered compaction of the ops whose extent touches this sub-tile ---- */
         const uint32_t oi_idx = base + tid;
         bool hit = false;
-        if (oi_idx < job.n_ops) {
-            const osmt_opinfo oi = A.info[job.op_off + oi_idx];
-            hit = oi.n_edges > 0 && oi.x0 <= rc.x1 && oi.x1 >= rc.x0 && oi.y0 <= rc.y1 && oi.y1 >= rc.y0;
-        }
+        if (oi_idx < job.n_ops)
+            hit = (g_submask[(size_t)(job.op_off + oi_idx) * g_sub_rows + sub_y] >> sub_x) & 1u;
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) sh.wcount[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -466,16 +580,18 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
         }
         if (hit) sh.oplist[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = oi_idx;
         __syncthreads();
+        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
 
         for (uint32_t li = 0; li < total; ++li) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
-            const osmt_op* __restrict__ op = &A.ops[o];
+            const osmt_op* __restrict__ op = &g_ops[o];
             const uint32_t kind = op->kind;
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
-                const osmt_opinfo* __restrict__ oi = &A.info[o];
-                const osmt_stroke_aux* __restrict__ sa = &A.aux[oi->aux];
+                const osmt_opinfo* __restrict__ oi = &g_info[o];
+                const osmt_stroke_aux* __restrict__ sa = &g_aux[oi->aux];
                 const double half_width = sa->half_width;
+                const bool plain_main = sa->main.n_segs == 0;
                 const double initial_opacity = op->opacity;
                 const int32_t reach = oi->reach;
                 const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
@@ -484,25 +600,36 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
                 const uint32_t n_edges = oi->n_edges;
                 uint32_t e_seen = 0;
                 for (uint32_t r = 0; r < op->n_rings; ++r) {
-                    const osmt_ring ring = A.rings[op->ring_off + r];
+                    const osmt_ring ring = g_rings[op->ring_off + r];
                     for (uint32_t i = 1; i < ring.n_pts; ++i) {
-                        const int2 p1 = A.pts[ring.first_pt + i - 1];
-                        const int2 p2 = A.pts[ring.first_pt + i];
-                        const double traveled = A.trav[ring.first_pt + i - 1];
-                        raster_segment(p1.x, p1.y, p2.x, p2.y, &sa->main, half_width, traveled, initial_opacity,
-                                       reach, rc, plane);
+                        const int2 p1 = g_pts[ring.first_pt + i - 1];
+                        const int2 p2 = g_pts[ring.first_pt + i];
+                        const double traveled = g_trav[ring.first_pt + i - 1];
                         ++e_seen;
-                        if (has_caps && !(p1.x == p2.x && p1.y == p2.y)) {
-                            if (first) {
-                                const int2 ce = push_away_from(p1, p2, half_width);
-                                raster_segment(p1.x, p1.y, ce.x, ce.y, &sa->caps, half_width, 0.0, initial_opacity,
-                                               reach, rc, plane);
+                        const bool degenerate = (p1.x == p2.x && p1.y == p2.y);
+                        /* j = 0: the edge; 1: cap stub at the first edge's start; 2: cap stub at the
+                         * last edge's end (line.rs:33-57).  One raster_segment call site keeps the
+                         * kernel small enough for the instruction cache. */
+                        for (int j = 0; j < 3; ++j) {
+                            int2 a = p1, b = p2;
+                            const osmt_dash_table* tab = &sa->main;
+                            double tr = traveled;
+                            bool plain = plain_main;
+                            if (j > 0) {
+                                if (!has_caps || degenerate) break;
+                                if (j == 1) {
+                                    if (!first) continue;
+                                    b = push_away_from(p1, p2, half_width);
+                                } else {
+                                    if (e_seen != n_edges) continue;
+                                    a = p2;
+                                    b = push_away_from(p2, p1, half_width);
+                                }
+                                tab = &sa->caps;
+                                tr = 0.0;
+                                plain = false;
                             }
-                            if (e_seen == n_edges) {
-                                const int2 ce = push_away_from(p2, p1, half_width);
-                                raster_segment(p2.x, p2.y, ce.x, ce.y, &sa->caps, half_width, 0.0, initial_opacity,
-                                               reach, rc, plane);
-                            }
+                            raster_segment(plain, a.x, a.y, b.x, b.y, sa, tab, tr, initial_opacity, reach, rc, plane);
                         }
                         first = false;
                     }
@@ -528,14 +655,14 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
                 /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row */
                 uint32_t e_base = 0;
                 for (uint32_t r = 0; r < op->n_rings; ++r) {
-                    const osmt_ring ring = A.rings[op->ring_off + r];
+                    const osmt_ring ring = g_rings[op->ring_off + r];
                     if (ring.n_pts < 2) continue;
                     const uint32_t ne = ring.n_pts - 1;
                     const uint32_t n_items = ne * SUB;
                     for (uint32_t it = tid; it < n_items; it += NTHREADS) {
                         const uint32_t e = it / SUB, row = it % SUB;
-                        const int2 p1 = A.pts[ring.first_pt + e];
-                        const int2 p2 = A.pts[ring.first_pt + e + 1];
+                        const int2 p1 = g_pts[ring.first_pt + e];
+                        const int2 p2 = g_pts[ring.first_pt + e + 1];
                         int32_t xmn, xmx;
                         if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx)) {
                             const uint32_t slot = atomicAdd(&sh.rowcnt[row], 1u);
@@ -590,11 +717,11 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
                             int64_t be = 0;
                             uint32_t eb = 0;
                             for (uint32_t r = 0; r < op->n_rings; ++r) {
-                                const osmt_ring ring = A.rings[op->ring_off + r];
+                                const osmt_ring ring = g_rings[op->ring_off + r];
                                 if (ring.n_pts < 2) continue;
                                 for (uint32_t e = 0; e + 1 < ring.n_pts; ++e) {
-                                    const int2 p1 = A.pts[ring.first_pt + e];
-                                    const int2 p2 = A.pts[ring.first_pt + e + 1];
+                                    const int2 p1 = g_pts[ring.first_pt + e];
+                                    const int2 p2 = g_pts[ring.first_pt + e + 1];
                                     int32_t xmn, xmx;
                                     if (!osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx))
                                         continue;
@@ -646,9 +773,9 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
                     }
                 } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
                     const uint32_t img = op->image_id;
-                    if (img < A.n_images) {
-                        const osmt_image_desc im = A.images[img];
-                        const double4* __restrict__ ipx = A.image_pool + im.offset;
+                    if (img < g_n_images) {
+                        const osmt_image_desc im = g_images[img];
+                        const double4* __restrict__ ipx = g_image_pool + im.offset;
 #pragma unroll
                         for (int j = 0; j < PXT; ++j) {
                             const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
@@ -673,7 +800,7 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
         const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
         const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx);
         if (OUT_F64) {
-            double4* out = reinterpret_cast<double4*>(A.out) + (size_t)tile * W * W + px;
+            double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
             *out = make_double4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
         } else {
             const double a = acc[j][3];
@@ -682,45 +809,86 @@ __global__ __launch_bounds__(NTHREADS) void k_raster(osmt_raster_args A) {
             const double mb = (a == 0.0) ? 0.0 : acc[j][2] / a;
             const uint32_t v = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) |
                                0xFF000000u;
-            uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.out) +
-                                                        (size_t)tile * A.out_tile_stride) + px;
+            uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
+                                                        (size_t)tile * g_out_tile_stride) + px;
             *out = v;
         }
     }
 }
 
 /* ------------------------------------------------------------------------- */
-/* Layer compositing: one pixel per lane, L resident premultiplied f64 layers, strictly
- * in order (blend_pixel is not commutative), then to_rgb_triples.  Pure HBM stream:
- * 32*L bytes in, 4 bytes out per pixel. */
-typedef double v4d __attribute__((ext_vector_type(4)));
+/* Layer compositing (tile_pixels.rs:205-223 over L resident layers, then :164-181).
+ * Pure HBM stream: 32*L bytes in, 4 bytes out per pixel.
+ *
+ * Access pattern: a wave owns 64 consecutive pixels = one 2 KiB run per layer.  Every load is
+ * a fully coalesced 16 B-per-lane instruction (lane i reads bytes [16i, 16i+16) of the first
+ * or the second KiB), so lane pair (2j, 2j+1) holds the two halves of pixel j (first KiB) and
+ * of pixel 32+j (second KiB).  One quad_perm DPP swap per half gives lane 2j all of pixel j
+ * and lane 2j+1 all of pixel 32+j; from there each lane blends one pixel strictly in layer
+ * order (blend_pixel is not commutative) and stores one RGBA8 word. */
+typedef double v2d __attribute__((ext_vector_type(2)));
 
-template <int LT>
-__global__ __launch_bounds__(256) void k_composite(const v4d* __restrict__ planes, double4 canvas, uint32_t n,
+__device__ __forceinline__ double dpp_swap_pair(double x) {
+    /* quad_perm:[1,0,3,2] = 0xB1: exchange with the neighbouring lane (lane ^ 1) */
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int LT, bool NT>
+__global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ planes, double4 canvas, uint32_t n,
                                                    uint32_t L, uint32_t npx, uint32_t* __restrict__ out) {
-    const size_t total = (size_t)n * npx;
-    const size_t stride = (size_t)gridDim.x * 256u;
-    for (size_t p = (size_t)blockIdx.x * 256u + threadIdx.x; p < total; p += stride) {
-        const size_t t = p / npx, q = p - t * npx;
-        const v4d* src = planes + (t * (size_t)L) * npx + q;
+    /* npx is a multiple of 64 (checked by the launcher), so a 64-pixel run never straddles tiles */
+    const size_t total_runs = (size_t)n * (npx / 64u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave0 = ((size_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * 256u) >> 6;
+    const bool odd = lane & 1u;
+    for (size_t run = wave0; run < total_runs; run += nwaves) {
+        const size_t t = run / (npx / 64u);
+        const size_t q0 = (run - t * (npx / 64u)) * 64u; /* first pixel of the run inside tile t */
+        const v2d* src = planes + ((t * (size_t)L) * npx + q0) * 2u + lane;
+        const size_t layer_stride = (size_t)npx * 2u; /* v2d units */
         double d[4] = {canvas.x, canvas.y, canvas.z, canvas.w};
+        auto blend_layer = [&](v2d h0, v2d h1) {
+            /* even lane: h0 = (r,g) of pixel j, h1 = (r,g) of pixel 32+j
+             * odd  lane: h0 = (b,a) of pixel j, h1 = (b,a) of pixel 32+j */
+            const v2d give = odd ? h0 : h1; /* what the partner lane needs */
+            v2d got;
+            got.x = dpp_swap_pair(give.x);
+            got.y = dpp_swap_pair(give.y);
+            const v2d rg = odd ? got : h0;
+            const v2d ba = odd ? h1 : got;
+            blend_px(d, rg.x, rg.y, ba.x, ba.y);
+        };
         if (LT > 0) {
-            v4d s[LT > 0 ? LT : 1];
+            v2d h0[LT > 0 ? LT : 1], h1[LT > 0 ? LT : 1];
 #pragma unroll
-            for (int l = 0; l < LT; ++l) s[l] = __builtin_nontemporal_load(src + (size_t)l * npx);
+            for (int l = 0; l < LT; ++l) {
+                if (NT) {
+                    h0[l] = __builtin_nontemporal_load(src + (size_t)l * layer_stride);
+                    h1[l] = __builtin_nontemporal_load(src + (size_t)l * layer_stride + 64);
+                } else {
+                    h0[l] = src[(size_t)l * layer_stride];
+                    h1[l] = src[(size_t)l * layer_stride + 64];
+                }
+            }
 #pragma unroll
-            for (int l = 0; l < LT; ++l) blend_px(d, s[l].x, s[l].y, s[l].z, s[l].w);
+            for (int l = 0; l < LT; ++l) blend_layer(h0[l], h1[l]);
         } else {
             for (uint32_t l = 0; l < L; ++l) {
-                const v4d s = __builtin_nontemporal_load(src + (size_t)l * npx);
-                blend_px(d, s.x, s.y, s.z, s.w);
+                const v2d a0 = __builtin_nontemporal_load(src + (size_t)l * layer_stride);
+                const v2d a1 = __builtin_nontemporal_load(src + (size_t)l * layer_stride + 64);
+                blend_layer(a0, a1);
             }
         }
         const double a = d[3];
         const double mr = (a == 0.0) ? 0.0 : d[0] / a;
         const double mg = (a == 0.0) ? 0.0 : d[1] / a;
         const double mb = (a == 0.0) ? 0.0 : d[2] / a;
-        out[p] = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) | 0xFF000000u;
+        const size_t px = t * npx + q0 + (lane >> 1) + (odd ? 32u : 0u);
+        out[px] = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) | 0xFF000000u;
     }
 }
 
@@ -745,10 +913,10 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
 
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              osmt_stroke_aux* aux, hipStream_t st) {
+                              osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
     if (n_ops == 0) return hipSuccess;
     hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
-                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, aux);
+                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, aux, submask, sub_rows);
     return hipGetLastError();
 }
 
@@ -759,27 +927,39 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
     if (out_f64)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a);
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
+                           a.pts, a.trav, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.out_tile_stride);
     else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a);
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
+                           a.pts, a.trav, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.out_tile_stride);
     return hipGetLastError();
 }
 
+#ifndef OSMT_V_COMP_NT
+#define OSMT_V_COMP_NT 1
+#endif
+#ifndef OSMT_V_COMP_BLOCKS
+#define OSMT_V_COMP_BLOCKS 16
+#endif
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st) {
     const size_t total = (size_t)n * npx;
     if (total == 0) return hipSuccess;
+    if (npx % 64u) return hipErrorInvalidValue; /* W*H must be a multiple of the wave size */
     const double4 cv = make_double4(canvas[0], canvas[1], canvas[2], canvas[3]);
     size_t blocks = (total + 255) / 256;
-    const size_t cap = 256 * 16; /* 256 CUs x 16 resident blocks, grid-stride beyond */
+    const size_t cap = 256 * OSMT_V_COMP_BLOCKS; /* 256 CUs x resident blocks, grid-stride beyond */
     if (blocks > cap) blocks = cap;
-    const v4d* p = reinterpret_cast<const v4d*>(planes);
+    const v2d* p = reinterpret_cast<const v2d*>(planes);
     uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    constexpr bool NT = OSMT_V_COMP_NT != 0;
     if (L == 8)
-        hipLaunchKernelGGL(k_composite<8>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+        hipLaunchKernelGGL((k_composite<8, NT>), dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
     else if (L == 4)
-        hipLaunchKernelGGL(k_composite<4>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+        hipLaunchKernelGGL((k_composite<4, NT>), dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
     else
-        hipLaunchKernelGGL(k_composite<0>, dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
+        hipLaunchKernelGGL((k_composite<0, NT>), dim3((uint32_t)blocks), dim3(256), 0, st, p, cv, n, L, npx, o);
     return hipGetLastError();
 }

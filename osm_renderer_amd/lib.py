@@ -12,7 +12,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libosmtile.so")
+# OSMT_LIB selects an alternative build of the same library (kernel-variant experiments only)
+LIB_PATH = os.environ.get("OSMT_LIB") or os.path.join(_HERE, "libosmtile.so")
 _lib = None
 
 EXPORTS = [
