@@ -125,8 +125,8 @@ int validate_batch(const osmt_batch* b) {
                 if (ring.first_pt < job.pt_off || (size_t)ring.first_pt + ring.n_pts > (size_t)job.pt_off + job.n_pts)
                     return fail(OSMT_INVALID_ARG, "job %zu op %u ring %u: points outside the job's pool range", j, k, r);
             }
-            if (!(op.opacity >= 0.0) || !std::isfinite(op.opacity))
-                return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be finite and >= 0", j, k);
+            if (!(op.opacity >= 0.0) || !(op.opacity <= 4503599627370496.0))
+                return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be in [0, 2^52]", j, k);
             if (op.kind == OSMT_OP_STROKE) {
                 if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
                 if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
@@ -160,7 +160,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / 32, st));
+                                   sc->d_trav, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
@@ -176,7 +176,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.trav = sc->d_trav;
         a.aux = sc->d_aux;
         a.submask = sc->d_submask;
-        a.sub_rows = OSMT_TILE_SIZE * sc->scale / 32;
+        a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
         a.images = ctx->d_images;
         a.image_pool = ctx->d_image_pool;
         a.n_images = (uint32_t)ctx->images.size();
@@ -292,7 +292,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
-    const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / 32;
+    const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     s->bytes = off + 256;
     hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);

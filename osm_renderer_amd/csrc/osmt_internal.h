@@ -7,6 +7,14 @@
 
 #include "../../include/osmtile.h"
 
+/* Sub-tile geometry of k_raster: OSMT_SUB_W x OSMT_SUB_H pixels per workgroup.  Sub-tile
+ * coverage masks (osmt_raster_args.submask) have one 32-bit word per sub-tile ROW. */
+#define OSMT_SUB_W 32
+#ifndef OSMT_SUB_H_LOG2
+#define OSMT_SUB_H_LOG2 4
+#endif
+#define OSMT_SUB_H (1 << OSMT_SUB_H_LOG2)
+
 /* even dash indices (<= 8) + the first dash repeated (opacity_calculator.rs:105-106) */
 #define OSMT_MAX_DASH_SEGS 10
 
@@ -58,7 +66,7 @@ struct osmt_raster_args {
     const double* trav;
     const osmt_stroke_aux* aux;
     const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
-    uint32_t sub_rows;       /* W / 32 */
+    uint32_t sub_rows;       /* W / OSMT_SUB_H */
     uint32_t _pad0;
     const osmt_image_desc* images;
     const double4* image_pool;

@@ -128,14 +128,15 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
 
 /* Marks the sub-tiles whose rectangle grown by g pixels intersects the segment a-b
  * (separating axes: x, y and the segment's normal; exact in int64). */
-__device__ void mark_segment(uint32_t* __restrict__ sm, int32_t n_sub, int32_t ax, int32_t ay, int32_t bx, int32_t by,
-                             int32_t g) {
-    const int32_t sx0 = max((min(ax, bx) - g) >> 5, 0), sx1 = min((max(ax, bx) + g) >> 5, n_sub - 1);
-    const int32_t sy0 = max((min(ay, by) - g) >> 5, 0), sy1 = min((max(ay, by) + g) >> 5, n_sub - 1);
+__device__ void mark_segment(uint32_t* __restrict__ sm, int32_t n_sub_x, int32_t n_sub_y, int32_t ax, int32_t ay,
+                             int32_t bx, int32_t by, int32_t g) {
+    const int32_t sx0 = max((min(ax, bx) - g) >> 5, 0), sx1 = min((max(ax, bx) + g) >> 5, n_sub_x - 1);
+    const int32_t sy0 = max((min(ay, by) - g) >> OSMT_SUB_H_LOG2, 0);
+    const int32_t sy1 = min((max(ay, by) + g) >> OSMT_SUB_H_LOG2, n_sub_y - 1);
     if (sx0 > sx1 || sy0 > sy1) return;
     const int64_t dx = (int64_t)bx - ax, dy = (int64_t)by - ay;
     for (int32_t sy = sy0; sy <= sy1; ++sy) {
-        const int64_t y0 = (int64_t)sy * 32 - g - ay, y1 = (int64_t)sy * 32 + 31 + g - ay;
+        const int64_t y0 = (int64_t)sy * OSMT_SUB_H - g - ay, y1 = (int64_t)sy * OSMT_SUB_H + (OSMT_SUB_H - 1) + g - ay;
         uint32_t bits = 0u;
         for (int32_t sx = sx0; sx <= sx1; ++sx) {
             const int64_t x0 = (int64_t)sx * 32 - g - ax, x1 = (int64_t)sx * 32 + 31 + g - ax;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
          * Bresenham centre is within 0.5 px of the ideal segment) meets the segment; the cap
          * stubs (length <= hw + 1) are covered by growing the first/last edge's test further */
         {
-            const int32_t n_sub = (int32_t)sub_rows;
+            const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = (int32_t)(sub_rows * OSMT_SUB_H / OSMT_SUB_W);
             uint32_t e_seen = 0;
             for (uint32_t r = 0; r < op.n_rings; ++r) {
                 const osmt_ring ring = rings[op.ring_off + r];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                     ++e_seen;
                     const bool endcap = caps && (e_seen == 1 || e_seen == n_edges);
                     const int32_t g = reach + 1 + (endcap ? cap_reach : 0);
-                    mark_segment(sm, n_sub, a.x, a.y, b.x, b.y, g);
+                    mark_segment(sm, n_sub_x, n_sub_y, a.x, a.y, b.x, b.y, g);
                 }
             }
         }
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         oi.reach = 0;
         /* fills: every sub-tile of the extent (rows ytop+1..ybot only carry records) */
         if (oi.x0 <= oi.x1) {
-            const int32_t n_sub = (int32_t)sub_rows;
-            const int32_t sx0 = max(oi.x0 >> 5, 0), sx1 = min(oi.x1 >> 5, n_sub - 1);
-            const int32_t sy0 = max((oi.y0 + 1) >> 5, 0), sy1 = min(oi.y1 >> 5, n_sub - 1);
+            const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = (int32_t)(sub_rows * OSMT_SUB_H / OSMT_SUB_W);
+            const int32_t sx0 = max(oi.x0 >> 5, 0), sx1 = min(oi.x1 >> 5, n_sub_x - 1);
+            const int32_t sy0 = max((oi.y0 + 1) >> OSMT_SUB_H_LOG2, 0), sy1 = min(oi.y1 >> OSMT_SUB_H_LOG2, n_sub_y - 1);
             if (sx0 <= sx1) {
                 const uint32_t bits = (uint32_t)((((uint64_t)1 << (sx1 - sx0 + 1)) - 1) << sx0);
                 for (int32_t sy = sy0; sy <= sy1; ++sy) sm[sy] |= bits;
@@ -328,9 +329,15 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
 }
 
 /* ---- the fused raster kernel ---------------------------------------------- */
-constexpr int SUB = 32;            /* sub-tile edge in pixels */
-constexpr int NTHREADS = 256;      /* 4 waves */
-constexpr int PXT = SUB * SUB / NTHREADS; /* pixels per thread = 4 */
+constexpr int SUB = OSMT_SUB_W;    /* sub-tile width in pixels (one 32-bit coverage word per row) */
+constexpr int SUBH = OSMT_SUB_H;   /* sub-tile height */
+#ifndef OSMT_V_NTHREADS
+#define OSMT_V_NTHREADS 64
+#endif
+constexpr int NTHREADS = OSMT_V_NTHREADS; /* 64 = one wave per sub-tile: no cross-wave barrier anywhere */
+constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
+constexpr int NBUF = NTHREADS > 64 ? 2 : 1; /* multi-wave groups double-buffer planes/masks to save a barrier */
+constexpr int ROWSTEP = NTHREADS / SUB;     /* rows between a thread's consecutive pixels */
 #ifndef OSMT_V_ROWCAP
 #define OSMT_V_ROWCAP 32
 #endif
@@ -343,12 +350,12 @@ struct RowRec {
 };
 
 struct RasterShared {
-    unsigned long long plane[2][SUB * SUB]; /* generation alpha planes (f64 bit patterns) */
-    uint32_t mask[2][SUB];                  /* fill coverage per row */
-    RowRec rec[SUB][ROWCAP];
-    uint32_t rowcnt[SUB];
+    unsigned long long plane[NBUF][SUB * SUBH]; /* generation alpha planes (f64 bit patterns) */
+    uint32_t mask[NBUF][SUBH];                  /* fill coverage per row */
+    RowRec rec[SUBH][ROWCAP];
+    uint32_t rowcnt[SUBH];
     uint32_t oplist[OPCHUNK];
-    uint32_t wcount[NTHREADS / 64];
+    uint32_t wcount[(NTHREADS + 63) / 64];
 };
 
 struct SubRect {
@@ -362,6 +369,13 @@ __device__ __forceinline__ void blend_px(double* acc, double sr, double sg, doub
     acc[1] = sg + k * acc[1];
     acc[2] = sb + k * acc[2];
     acc[3] = sa + k * acc[3];
+}
+/* the same for the raster kernel's r,g,b-only accumulators (alpha is the constant 1.0) */
+__device__ __forceinline__ void blend_rgb(double* acc, double sr, double sg, double sb, double sa) {
+    const double k = 1.0 - sa;
+    acc[0] = sr + k * acc[0];
+    acc[1] = sg + k * acc[1];
+    acc[2] = sb + k * acc[2];
 }
 
 /* One perpendicular run (line.rs:108-137).  PLAIN = the calculator has no dash segments
@@ -488,10 +502,11 @@ __device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by)
 }
 
 #ifndef OSMT_V_WAVES
-#define OSMT_V_WAVES 5
+#define OSMT_V_WAVES 4
 #endif
 #if OSMT_V_WAVES > 0
-#define OSMT_RASTER_BOUNDS __launch_bounds__(NTHREADS, OSMT_V_WAVES)
+/* waves per SIMD the register allocator must leave room for */
+#define OSMT_RASTER_BOUNDS __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OSMT_V_WAVES, OSMT_V_WAVES)))
 #else
 #define OSMT_RASTER_BOUNDS __launch_bounds__(NTHREADS)
 #endif
@@ -517,7 +532,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t W = OSMT_TILE_SIZE * g_scale;
     const uint32_t subs_per_row = W / SUB;
-    const uint32_t nsub = subs_per_row * subs_per_row;
+    const uint32_t nsub = subs_per_row * (W / SUBH);
 
     /* XCD-aware block -> (tile, sub-tile): blocks b, b+8, b+16.. land on one XCD, so give
      * them the sub-tiles of the same tiles (they share that tile's display list in L2). */
@@ -532,16 +547,19 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     SubRect rc;
     const uint32_t sub_x = sub % subs_per_row, sub_y = sub / subs_per_row;
     rc.x0 = (int32_t)(sub_x * SUB);
-    rc.y0 = (int32_t)(sub_y * SUB);
+    rc.y0 = (int32_t)(sub_y * SUBH);
     rc.x1 = rc.x0 + SUB - 1;
-    rc.y1 = rc.y0 + SUB - 1;
+    rc.y1 = rc.y0 + SUBH - 1;
 
     /* thread -> pixels: column lx, rows ly0 + 8*j; a wave covers two full 128-byte rows */
     const uint32_t lx = tid & (SUB - 1);
     const uint32_t ly0 = tid / SUB;
 
-    /* tile_pixels.rs:89-93 reset */
-    double acc[PXT][4];
+    /* tile_pixels.rs:89-93 reset.  Only r,g,b are carried: the canvas alpha starts at 1.0 and
+     * blend_pixel keeps it at exactly 1.0 — fl(a + fl(1-a)*1.0) == 1.0 for every alpha in
+     * [0, 2^52] (1-a is exact for a >= 0.5; below, the rounding error of 1-a is <= 2^-54 and
+     * 1 + e rounds to 1.0) — so it is a constant, checked bit-for-bit by the f64 parity tests. */
+    double acc[PXT][3];
     {
         double r = 0.0, g = 0.0, bl = 0.0;
         if (job.has_canvas) {
@@ -554,11 +572,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             acc[j][0] = r;
             acc[j][1] = g;
             acc[j][2] = bl;
-            acc[j][3] = 1.0;
         }
     }
-    for (uint32_t i = tid; i < 2 * SUB * SUB; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
-    if (tid < SUB) sh.rowcnt[tid] = 0u;
+    for (uint32_t i = tid; i < NBUF * SUB * SUBH; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
+    if (tid < SUBH) sh.rowcnt[tid] = 0u;
     __syncthreads();
 
     uint32_t buf = 0;
@@ -573,7 +590,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         __syncthreads();
         uint32_t off = 0, total = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < NTHREADS / 64; ++w) {
+        for (uint32_t w = 0; w < (NTHREADS + 63) / 64; ++w) {
             const uint32_t cnt = sh.wcount[w];
             if (w < wave) off += cnt;
             total += cnt;
@@ -641,15 +658,16 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const double cb = (double)op->color[2] / 255.0;
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) {
-                    const uint32_t idx = (ly0 + (uint32_t)j * (NTHREADS / SUB)) * SUB + lx;
+                    const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * SUB + lx;
                     const unsigned long long bits = plane[idx];
                     if (bits != 0ull) {
                         plane[idx] = 0ull;
                         const double a = __longlong_as_double((long long)bits);
-                        blend_px(acc[j], a * cr, a * cg, a * cb, a); /* from_color: o * (c/255) */
+                        blend_rgb(acc[j], a * cr, a * cg, a * cb, a); /* from_color: o * (c/255) */
                     }
                 }
-                buf ^= 1u;
+                if (NBUF == 1) __syncthreads(); /* plane/mask reused by the next op */
+                buf = (buf + 1u) % NBUF;
             } else {
                 /* ---------------- fill_contour (fill.rs:16-47) ---------------- */
                 /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row */
@@ -658,9 +676,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     const osmt_ring ring = g_rings[op->ring_off + r];
                     if (ring.n_pts < 2) continue;
                     const uint32_t ne = ring.n_pts - 1;
-                    const uint32_t n_items = ne * SUB;
+                    const uint32_t n_items = ne * SUBH;
                     for (uint32_t it = tid; it < n_items; it += NTHREADS) {
-                        const uint32_t e = it / SUB, row = it % SUB;
+                        const uint32_t e = it / SUBH, row = it % SUBH;
                         const int2 p1 = g_pts[ring.first_pt + e];
                         const int2 p2 = g_pts[ring.first_pt + e + 1];
                         int32_t xmn, xmx;
@@ -678,7 +696,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 __syncthreads();
                 /* B: per row: order by (x_min, edge index) == stable sort_by_key(x_min) of records
                  * inserted in edge order (fill.rs:24-25), pair (0,1),(2,3).., OR the spans */
-                if (tid < SUB) {
+                if (tid < SUBH) {
                     const uint32_t row = tid;
                     const uint32_t n = sh.rowcnt[row];
                     uint32_t m = 0u;
@@ -768,8 +786,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     const double sb = o_ * ((double)op->color[2] / 255.0);
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
-                        const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
-                        if ((sh.mask[buf][row] >> lx) & 1u) blend_px(acc[j], sr, sg, sb, o_);
+                        const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
+                        if ((sh.mask[buf][row] >> lx) & 1u) blend_rgb(acc[j], sr, sg, sb, o_);
                     }
                 } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
                     const uint32_t img = op->image_id;
@@ -778,17 +796,18 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         const double4* __restrict__ ipx = g_image_pool + im.offset;
 #pragma unroll
                         for (int j = 0; j < PXT; ++j) {
-                            const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
+                            const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
                             if ((sh.mask[buf][row] >> lx) & 1u) {
                                 const uint32_t ix = (uint32_t)(rc.x0 + (int32_t)lx) % im.width;
                                 const uint32_t iy = (uint32_t)(rc.y0 + (int32_t)row) % im.height;
                                 const double4 c = ipx[(size_t)iy * im.width + ix];
-                                blend_px(acc[j], c.x, c.y, c.z, c.w);
+                                blend_rgb(acc[j], c.x, c.y, c.z, c.w);
                             }
                         }
                     }
                 }
-                buf ^= 1u;
+                if (NBUF == 1) __syncthreads(); /* plane/mask reused by the next op */
+                buf = (buf + 1u) % NBUF;
             }
         }
         __syncthreads(); /* oplist is rewritten by the next chunk */
@@ -797,18 +816,15 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* ---- to_rgb_triples (tile_pixels.rs:164-181) / raw canvas ---------------- */
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
-        const uint32_t row = ly0 + (uint32_t)j * (NTHREADS / SUB);
+        const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
         const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx);
         if (OUT_F64) {
             double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
-            *out = make_double4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            *out = make_double4(acc[j][0], acc[j][1], acc[j][2], 1.0);
         } else {
-            const double a = acc[j][3];
-            const double mr = (a == 0.0) ? 0.0 : acc[j][0] / a;
-            const double mg = (a == 0.0) ? 0.0 : acc[j][1] / a;
-            const double mb = (a == 0.0) ? 0.0 : acc[j][2] / a;
-            const uint32_t v = f64_as_u8(255.0 * mr) | (f64_as_u8(255.0 * mg) << 8) | (f64_as_u8(255.0 * mb) << 16) |
-                               0xFF000000u;
+            /* postdivide (tile_pixels.rs:171-175) with p.a == 1.0: val / 1.0 == val */
+            const uint32_t v = f64_as_u8(255.0 * acc[j][0]) | (f64_as_u8(255.0 * acc[j][1]) << 8) |
+                               (f64_as_u8(255.0 * acc[j][2]) << 16) | 0xFF000000u;
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
                                                         (size_t)tile * g_out_tile_stride) + px;
             *out = v;
@@ -923,7 +939,7 @@ hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_rin
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st) {
     if (a.n_jobs == 0) return hipSuccess;
     const uint32_t W = OSMT_TILE_SIZE * a.scale;
-    const uint32_t nsub = (W / SUB) * (W / SUB);
+    const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
     if (out_f64)
