@@ -46,8 +46,8 @@ struct osmt_opinfo {
     int32_t x0, y0, x1, y1; /* inclusive extent of pixels the op can touch (empty: x0 > x1) */
     uint32_t aux;           /* STROKE: index into the stroke_aux table */
     uint32_t n_edges;       /* total edges over all rings */
-    int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its segment's box */
-    int32_t _pad[1];
+    int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its Bresenham centre */
+    int32_t reach_major;    /* STROKE: the same along the segment's major axis only (tighter) */
 };
 
 struct osmt_image_desc {

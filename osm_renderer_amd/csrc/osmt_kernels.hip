@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
     oi.x1 = oi.y1 = INT32_MIN;
     oi.aux = op_aux[o];
     oi.n_edges = 0;
-    oi._pad[0] = 0;
+    oi.reach_major = 0;
     if (op.kind == OSMT_OP_NONE) {
         info[o] = oi;
         return;
@@ -198,8 +198,15 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
     if (op.kind == OSMT_OP_STROKE) {
         const double hw = op.width / 2.0;
         const double ft = fmax(hw + 0.5, 1.0);
-        /* a perpendicular run leaves the Bresenham centre by < ft + 3.3 px per axis */
-        int32_t reach = (int32_t)fmin(ceil(ft), 1.0e6) + 4;
+        /* How far a SET pixel can be from the Bresenham centre its perpendicular starts at.  At walk
+         * step t the pixel is t px along the minor axis and cc_t <= t*a/b + 1 px along the major
+         * axis from the centre; its distance from the ideal line is >= t*len/b - a/len - |d0|, with
+         * |d0| <= 0.5 for a main perpendicular and <= 1.5 for the extra one of line.rs:152-154; it
+         * is set only while that distance is < ft' <= ft.  Hence t < (ft + 2.21) * b/len <= ft + 2.21
+         * and cc_t < (a/len)*(ft + 2.21) + 1 <= 0.7072*(ft + 2.21) + 1. */
+        int32_t reach = (int32_t)fmin(ceil(ft + 2.21), 1.0e6);
+        int32_t reach_major = (int32_t)fmin(ceil(0.7072 * (ft + 2.21)), 1.0e6) + 1;
+        oi.reach_major = reach_major;
         const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
         int32_t cap_reach = caps ? (int32_t)fmin(ceil(fabs(hw)), 1.0e6) + 1 : 0;
         oi.reach = reach;
@@ -445,8 +452,8 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
 /* All perpendiculars of one segment that can reach the sub-tile (line.rs:65-158). */
 __device__ __forceinline__ void raster_segment(const bool PLAIN, int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y,
                                const osmt_stroke_aux* __restrict__ sa, const osmt_dash_table* __restrict__ tab,
-                               double traveled, double initial_opacity, int32_t reach, const SubRect& rc,
-                               unsigned long long* __restrict__ plane) {
+                               double traveled, double initial_opacity, int32_t reach, int32_t reach_major,
+                               const SubRect& rc, unsigned long long* __restrict__ plane) {
     if (p1x == p2x && p1y == p2y) return;
     /* segment-level cull: every visited pixel lies within `reach` of the segment's box */
     if (max(p1x, p2x) + reach < rc.x0 || min(p1x, p2x) - reach > rc.x1 || max(p1y, p2y) + reach < rc.y0 ||
@@ -457,30 +464,43 @@ __device__ __forceinline__ void raster_segment(const bool PLAIN, int32_t p1x, in
         const double dxf = (double)abs(p2x - p1x), dyf = (double)abs(p2y - p1y);
         osmt_seg_setup(&s, p1x, p1y, p2x, p2y, sqrt(dyf * dyf + dxf * dxf));
     }
-    /* main-axis steps whose perpendiculars can reach the sub-tile */
-    const int32_t lo = (s.swap ? rc.x0 : rc.y0) - reach;
-    const int32_t hi = (s.swap ? rc.x1 : rc.y1) + reach;
-    int32_t k_lo, k_hi;
-    if (s.mx_inc > 0) {
-        k_lo = lo - s.mx0;
-        k_hi = hi - s.mx0;
-    } else {
-        k_lo = s.mx0 - hi;
-        k_hi = s.mx0 - lo;
+    /* Main-axis steps whose perpendicular on side `mul` can reach the sub-tile.  The run on side
+     * mul moves mul*mn_inc per step along the minor axis and -mul*mx_inc per correction along
+     * the major axis, so both tests are one-sided. */
+    const int32_t LO = s.swap ? rc.x0 : rc.y0, HI = s.swap ? rc.x1 : rc.y1;     /* major axis */
+    const int32_t MLO = s.swap ? rc.y0 : rc.x0, MHI = s.swap ? rc.y1 : rc.x1;   /* minor axis */
+    int32_t k_lo[2], k_n[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int32_t mul = side ? -1 : 1;
+        /* pixel major = mx_k - mul*mx_inc*cc, 0 <= cc <= reach_major */
+        int32_t lo = LO, hi = HI;
+        if (mul * s.mx_inc > 0) hi += reach_major; else lo -= reach_major;
+        int32_t a, b;
+        if (s.mx_inc > 0) {
+            a = lo - s.mx0;
+            b = hi - s.mx0;
+        } else {
+            a = s.mx0 - hi;
+            b = s.mx0 - lo;
+        }
+        a = max(a, 0);
+        b = min(b, s.b);
+        k_lo[side] = a;
+        k_n[side] = max(b - a + 1, 0);
     }
-    k_lo = max(k_lo, 0);
-    k_hi = min(k_hi, s.b);
-    if (k_lo > k_hi) return;
-    const int32_t mlo = (s.swap ? rc.y0 : rc.x0) - reach;
-    const int32_t mhi = (s.swap ? rc.y1 : rc.x1) + reach;
-    const int32_t n_items = (k_hi - k_lo + 1) * 2;
+    const int32_t n_items = k_n[0] + k_n[1];
     for (int32_t it = threadIdx.x; it < n_items; it += NTHREADS) {
-        const int32_t k = k_lo + (it >> 1);
-        const int32_t mul = (it & 1) ? -1 : 1;
+        const int32_t side = it >= k_n[0];
+        const int32_t k = side ? k_lo[1] + (it - k_n[0]) : k_lo[0] + it;
+        const int32_t mul = side ? -1 : 1;
         int32_t c, pe, has_extra, pe_extra;
         osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
         const int32_t mx = s.mx0 + k * s.mx_inc;
         int32_t mn = s.mn0 + c * s.mn_inc;
+        /* pixel minor = mn + mul*mn_inc*t, 0 <= t <= reach */
+        int32_t mlo = MLO, mhi = MHI;
+        if (mul * s.mn_inc > 0) mlo -= reach; else mhi += reach;
         /* the main pair, then the extra pair of line.rs:152-154 when it fires: one call site */
         for (int32_t w = 0; w <= has_extra; ++w) {
             if (mn >= mlo && mn <= mhi)
@@ -611,6 +631,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const bool plain_main = sa->main.n_segs == 0;
                 const double initial_opacity = op->opacity;
                 const int32_t reach = oi->reach;
+                const int32_t reach_major = oi->reach_major;
                 const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
                 unsigned long long* plane = sh.plane[buf];
                 bool first = true;
@@ -646,7 +667,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                                 tr = 0.0;
                                 plain = false;
                             }
-                            raster_segment(plain, a.x, a.y, b.x, b.y, sa, tab, tr, initial_opacity, reach, rc, plane);
+                            raster_segment(plain, a.x, a.y, b.x, b.y, sa, tab, tr, initial_opacity, reach, reach_major, rc, plane);
                         }
                         first = false;
                     }
