@@ -120,6 +120,53 @@ OSMT_HD void osmt_seg_setup(osmt_seg* s, int32_t p1x, int32_t p1y, int32_t p2x, 
     s->denom = denom;
 }
 
+/* floor(n / d) for 0 <= n < 2^24, d > 0 in 32-bit arithmetic: approximate quotient from the
+ * f32 reciprocal (v_rcp_f32 on the GPU), then an exact integer remainder fix-up, so the result
+ * does not depend on how good the approximation is. */
+OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf((float)d);
+#else
+    const float r = 1.0f / (float)d;
+#endif
+    int32_t q = (int32_t)((float)n * r);
+    int32_t rem = n - q * d;
+    /* |q - floor(n/d)| <= 1 for n < 2^24 (reciprocal and product are each within one f32
+     * rounding of the exact value, q <= 2^23); two branch-free correction rounds cover +-2 */
+    for (int round = 0; round < 2; ++round) {
+        const int32_t up = rem >= d, down = rem < 0;
+        q += up - down;
+        rem += (down - up) * d;
+    }
+    return q;
+}
+OSMT_HD int32_t osmt_ceil_div_pos24(int32_t n, int32_t d) {
+    if (n <= 0) return 0;
+    return osmt_udiv24(n + d - 1, d);
+}
+
+/* osmt_stroke_step for short segments (b < 2048): every intermediate is < 2^23, so the two
+ * ceil-divisions run in 32-bit arithmetic (gfx950 has no integer divider; the generic path
+ * below goes through f64).  Same outputs as osmt_stroke_step. */
+#define OSMT_STEP24_MAX_B 2048
+OSMT_HD void osmt_stroke_step24(int32_t a, int32_t b, int32_t k, int32_t* c_out, int32_t* pe, int32_t* has_extra,
+                                int32_t* pe_extra) {
+    const int32_t c = osmt_ceil_div_pos24(2 * a * k - b, 2 * b);
+    const int32_t d = osmt_ceil_div_pos24(2 * a * c - b, 2 * b);
+    const int32_t pe_now = 2 * a * c - 2 * b * d;
+    *c_out = c;
+    *pe = pe_now;
+    *has_extra = 0;
+    *pe_extra = 0;
+    if (k < b) {
+        const int32_t e = 2 * a * k - 2 * b * c;
+        if (e + 2 * a > b && pe_now + 2 * a > b) {
+            *has_extra = 1;
+            *pe_extra = pe_now - 2 * b + 2 * a;
+        }
+    }
+}
+
 /* Number of corrections after k calls of update_error (line.rs:91-100) starting from 0:
  * c_k = max(0, ceil((2ak - b) / 2b)). */
 OSMT_HD int64_t osmt_corrections(int64_t a, int64_t b, int64_t k) { return osmt_ceil_div_pos(2 * a * k - b, 2 * b); }

@@ -342,6 +342,7 @@ constexpr int SUBH = OSMT_SUB_H;   /* sub-tile height */
 #define OSMT_V_NTHREADS 64
 #endif
 constexpr int NTHREADS = OSMT_V_NTHREADS; /* 64 = one wave per sub-tile: no cross-wave barrier anywhere */
+static_assert(NTHREADS == 64, "the stroke path packs items with wave-level scans");
 constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int NBUF = NTHREADS > 64 ? 2 : 1; /* multi-wave groups double-buffer planes/masks to save a barrier */
 constexpr int ROWSTEP = NTHREADS / SUB;     /* rows between a thread's consecutive pixels */
@@ -356,7 +357,22 @@ struct RowRec {
     uint32_t edge;
 };
 
+/* One stroke segment (an edge or a cap stub) that survived the sub-tile cull, with the step
+ * ranges of its two perpendicular sides; the items of all records of an op are walked together. */
+struct SegRec {
+    int32_t p1x, p1y, p2x, p2y;
+    double traveled;
+    double denom;         /* center_dist_denom (line.rs:104) */
+    int64_t numer_const;  /* line.rs:102 */
+    int32_t k_lo0, k_n0, k_lo1, k_n1;
+    uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
+    uint32_t count;
+};
+constexpr int SEGCAP = 64 + 2;
+
 struct RasterShared {
+    SegRec seg[SEGCAP];
+    uint32_t seg_prefix[SEGCAP + 1];
     unsigned long long plane[NBUF][SUB * SUBH]; /* generation alpha planes (f64 bit patterns) */
     uint32_t mask[NBUF][SUBH];                  /* fill coverage per row */
     RowRec rec[SUBH][ROWCAP];
@@ -449,65 +465,77 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     }
 }
 
-/* All perpendiculars of one segment that can reach the sub-tile (line.rs:65-158). */
-__device__ __forceinline__ void raster_segment(const bool PLAIN, int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y,
-                               const osmt_stroke_aux* __restrict__ sa, const osmt_dash_table* __restrict__ tab,
-                               double traveled, double initial_opacity, int32_t reach, int32_t reach_major,
-                               const SubRect& rc, unsigned long long* __restrict__ plane) {
-    if (p1x == p2x && p1y == p2y) return;
-    /* segment-level cull: every visited pixel lies within `reach` of the segment's box */
+/* Step ranges [k_lo, k_lo + k_n) of the two perpendicular sides of segment p1->p2 whose runs can
+ * reach the sub-tile; returns the total number of (step, side) items, 0 when culled.
+ * The run on side `mul` moves mul*mn_inc per step along the minor axis and -mul*mx_inc per
+ * correction along the major axis, so the major-axis test is one-sided. */
+__device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
+                                               int32_t reach_major, const SubRect& rc, int32_t* k_lo0, int32_t* k_n0,
+                                               int32_t* k_lo1, int32_t* k_n1) {
+    *k_lo0 = *k_n0 = *k_lo1 = *k_n1 = 0;
+    if (p1x == p2x && p1y == p2y) return 0u; /* line.rs:73-75 */
+    /* every set pixel lies within `reach` (per axis) of the segment's box */
     if (max(p1x, p2x) + reach < rc.x0 || min(p1x, p2x) - reach > rc.x1 || max(p1y, p2y) + reach < rc.y0 ||
         min(p1y, p2y) - reach > rc.y1)
-        return;
-    osmt_seg s;
-    {
-        const double dxf = (double)abs(p2x - p1x), dyf = (double)abs(p2y - p1y);
-        osmt_seg_setup(&s, p1x, p1y, p2x, p2y, sqrt(dyf * dyf + dxf * dxf));
-    }
-    /* Main-axis steps whose perpendicular on side `mul` can reach the sub-tile.  The run on side
-     * mul moves mul*mn_inc per step along the minor axis and -mul*mx_inc per correction along
-     * the major axis, so both tests are one-sided. */
-    const int32_t LO = s.swap ? rc.x0 : rc.y0, HI = s.swap ? rc.x1 : rc.y1;     /* major axis */
-    const int32_t MLO = s.swap ? rc.y0 : rc.x0, MHI = s.swap ? rc.y1 : rc.x1;   /* minor axis */
-    int32_t k_lo[2], k_n[2];
+        return 0u;
+    const int32_t dx = abs(p2x - p1x), dy = abs(p2y - p1y);
+    const bool swap = dx > dy;
+    const int32_t mx0 = swap ? p1x : p1y;
+    const int32_t bmax = swap ? dx : dy;
+    const int32_t mx_inc = swap ? (p1x <= p2x ? 1 : -1) : (p1y <= p2y ? 1 : -1);
+    const int32_t LO = swap ? rc.x0 : rc.y0, HI = swap ? rc.x1 : rc.y1;
+    uint32_t total = 0;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
         const int32_t mul = side ? -1 : 1;
-        /* pixel major = mx_k - mul*mx_inc*cc, 0 <= cc <= reach_major */
-        int32_t lo = LO, hi = HI;
-        if (mul * s.mx_inc > 0) hi += reach_major; else lo -= reach_major;
+        int32_t lo = LO, hi = HI; /* pixel major = mx_k - mul*mx_inc*cc, 0 <= cc <= reach_major */
+        if (mul * mx_inc > 0) hi += reach_major; else lo -= reach_major;
         int32_t a, b;
-        if (s.mx_inc > 0) {
-            a = lo - s.mx0;
-            b = hi - s.mx0;
+        if (mx_inc > 0) {
+            a = lo - mx0;
+            b = hi - mx0;
         } else {
-            a = s.mx0 - hi;
-            b = s.mx0 - lo;
+            a = mx0 - hi;
+            b = mx0 - lo;
         }
         a = max(a, 0);
-        b = min(b, s.b);
-        k_lo[side] = a;
-        k_n[side] = max(b - a + 1, 0);
-    }
-    const int32_t n_items = k_n[0] + k_n[1];
-    for (int32_t it = threadIdx.x; it < n_items; it += NTHREADS) {
-        const int32_t side = it >= k_n[0];
-        const int32_t k = side ? k_lo[1] + (it - k_n[0]) : k_lo[0] + it;
-        const int32_t mul = side ? -1 : 1;
-        int32_t c, pe, has_extra, pe_extra;
-        osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
-        const int32_t mx = s.mx0 + k * s.mx_inc;
-        int32_t mn = s.mn0 + c * s.mn_inc;
-        /* pixel minor = mn + mul*mn_inc*t, 0 <= t <= reach */
-        int32_t mlo = MLO, mhi = MHI;
-        if (mul * s.mn_inc > 0) mlo -= reach; else mhi += reach;
-        /* the main pair, then the extra pair of line.rs:152-154 when it fires: one call site */
-        for (int32_t w = 0; w <= has_extra; ++w) {
-            if (mn >= mlo && mn <= mhi)
-                walk_perpendicular(PLAIN, s, sa, tab, traveled, initial_opacity, mn, mx, w ? pe_extra : pe, mul, rc,
-                                   plane);
-            mn += s.mn_inc;
+        b = min(b, bmax);
+        const int32_t n = max(b - a + 1, 0);
+        if (side == 0) {
+            *k_lo0 = a;
+            *k_n0 = n;
+        } else {
+            *k_lo1 = a;
+            *k_n1 = n;
         }
+        total += (uint32_t)n;
+    }
+    return total;
+}
+
+/* One (step, side) item of a segment record: the closed-form walk state at the step, then the
+ * main perpendicular and, when it fires, the extra one of line.rs:152-154. */
+__device__ __forceinline__ void walk_item(const SegRec& r, int32_t k, int32_t mul, const bool plain,
+                                          const osmt_stroke_aux* __restrict__ sa,
+                                          const osmt_dash_table* __restrict__ tab, double initial_opacity,
+                                          int32_t reach, const SubRect& rc, unsigned long long* __restrict__ plane) {
+    osmt_seg s;
+    osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom);
+    s.numer_const = r.numer_const;
+    int32_t c, pe, has_extra, pe_extra;
+    if (s.b < OSMT_STEP24_MAX_B)
+        osmt_stroke_step24(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
+    else
+        osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
+    const int32_t mx = s.mx0 + k * s.mx_inc;
+    int32_t mn = s.mn0 + c * s.mn_inc;
+    /* pixel minor = mn + mul*mn_inc*t, 0 <= t <= reach */
+    int32_t mlo = s.swap ? rc.y0 : rc.x0, mhi = s.swap ? rc.y1 : rc.x1;
+    if (mul * s.mn_inc > 0) mlo -= reach; else mhi += reach;
+    for (int32_t w = 0; w <= has_extra; ++w) { /* one call site for both perpendiculars */
+        if (mn >= mlo && mn <= mhi)
+            walk_perpendicular(plain, s, sa, tab, r.traveled, initial_opacity, mn, mx, w ? pe_extra : pe, mul, rc, plane);
+        mn += s.mn_inc;
     }
 }
 
@@ -522,7 +550,7 @@ __device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by)
 }
 
 #ifndef OSMT_V_WAVES
-#define OSMT_V_WAVES 4
+#define OSMT_V_WAVES 3
 #endif
 #if OSMT_V_WAVES > 0
 /* waves per SIMD the register allocator must leave room for */
@@ -634,43 +662,95 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const int32_t reach_major = oi->reach_major;
                 const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
                 unsigned long long* plane = sh.plane[buf];
-                bool first = true;
                 const uint32_t n_edges = oi->n_edges;
-                uint32_t e_seen = 0;
+                uint32_t e_base = 0;
                 for (uint32_t r = 0; r < op->n_rings; ++r) {
                     const osmt_ring ring = g_rings[op->ring_off + r];
-                    for (uint32_t i = 1; i < ring.n_pts; ++i) {
-                        const int2 p1 = g_pts[ring.first_pt + i - 1];
-                        const int2 p2 = g_pts[ring.first_pt + i];
-                        const double traveled = g_trav[ring.first_pt + i - 1];
-                        ++e_seen;
-                        const bool degenerate = (p1.x == p2.x && p1.y == p2.y);
-                        /* j = 0: the edge; 1: cap stub at the first edge's start; 2: cap stub at the
-                         * last edge's end (line.rs:33-57).  One raster_segment call site keeps the
-                         * kernel small enough for the instruction cache. */
-                        for (int j = 0; j < 3; ++j) {
-                            int2 a = p1, b = p2;
-                            const osmt_dash_table* tab = &sa->main;
-                            double tr = traveled;
-                            bool plain = plain_main;
-                            if (j > 0) {
-                                if (!has_caps || degenerate) break;
-                                if (j == 1) {
-                                    if (!first) continue;
-                                    b = push_away_from(p1, p2, half_width);
-                                } else {
-                                    if (e_seen != n_edges) continue;
-                                    a = p2;
-                                    b = push_away_from(p2, p1, half_width);
-                                }
-                                tab = &sa->caps;
-                                tr = 0.0;
-                                plain = false;
-                            }
-                            raster_segment(plain, a.x, a.y, b.x, b.y, sa, tab, tr, initial_opacity, reach, reach_major, rc, plane);
+                    if (ring.n_pts < 2) continue;
+                    const uint32_t ne = ring.n_pts - 1;
+                    for (uint32_t cb = 0; cb < ne; cb += 64u) {
+                        /* ---- one lane per edge: cull, step ranges, record -------------------- */
+                        const uint32_t e = cb + lane;
+                        const bool valid = e < ne;
+                        int2 p1 = make_int2(0, 0), p2 = make_int2(0, 0);
+                        double trav = 0.0;
+                        if (valid) {
+                            p1 = g_pts[ring.first_pt + e];
+                            p2 = g_pts[ring.first_pt + e + 1];
+                            trav = g_trav[ring.first_pt + e];
                         }
-                        first = false;
+                        const uint32_t ge = e_base + e; /* running edge index over all rings */
+                        const bool live = valid && !(p1.x == p2.x && p1.y == p2.y);
+                        SegRec rec;
+                        rec.count = 0;
+                        if (live)
+                            rec.count = seg_ranges(p1.x, p1.y, p2.x, p2.y, reach, reach_major, rc, &rec.k_lo0, &rec.k_n0,
+                                                   &rec.k_lo1, &rec.k_n1);
+                        const unsigned long long bal = __ballot(rec.count > 0u);
+                        uint32_t m = (uint32_t)__popcll(bal);
+                        if (rec.count > 0u) {
+                            rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
+                            rec.traveled = trav;
+                            rec.caps_table = 0u;
+                            sh.seg[__popcll(bal & ((1ull << lane) - 1ull))] = rec;
+                        }
+                        /* cap stubs: start of the first edge, end of the last edge (line.rs:33-57) */
+#pragma unroll
+                        for (int which = 0; which < 2; ++which) {
+                            const bool mine = live && has_caps && (which == 0 ? ge == 0u : ge + 1u == n_edges);
+                            SegRec cr;
+                            cr.count = 0;
+                            if (mine) {
+                                const int2 from = which == 0 ? p1 : p2;
+                                const int2 ce = which == 0 ? push_away_from(p1, p2, half_width)
+                                                           : push_away_from(p2, p1, half_width);
+                                cr.count = seg_ranges(from.x, from.y, ce.x, ce.y, reach, reach_major, rc, &cr.k_lo0,
+                                                      &cr.k_n0, &cr.k_lo1, &cr.k_n1);
+                                if (cr.count > 0u) {
+                                    cr.p1x = from.x; cr.p1y = from.y; cr.p2x = ce.x; cr.p2y = ce.y;
+                                    cr.traveled = 0.0;
+                                    cr.caps_table = 1u;
+                                    sh.seg[m] = cr;
+                                }
+                            }
+                            m += __ballot(cr.count > 0u) != 0ull ? 1u : 0u;
+                        }
+                        m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+                        __syncthreads();
+                        /* ---- per record: line constants once; exclusive prefix of item counts ---- */
+                        uint32_t cnt = 0;
+                        if (lane < m) {
+                            SegRec& q = sh.seg[lane];
+                            cnt = q.count;
+                            const double dxf = (double)abs(q.p2x - q.p1x), dyf = (double)abs(q.p2y - q.p1y);
+                            q.denom = sqrt(dyf * dyf + dxf * dxf);
+                            q.numer_const = (int64_t)q.p2x * (int64_t)q.p1y - (int64_t)q.p2y * (int64_t)q.p1x;
+                        }
+                        uint32_t incl = cnt;
+#pragma unroll
+                        for (uint32_t d = 1; d < 64u; d <<= 1) {
+                            const uint32_t y = __shfl_up(incl, d);
+                            if (lane >= d) incl += y;
+                        }
+                        if (lane < m) sh.seg_prefix[lane + 1] = incl;
+                        if (lane == 0) sh.seg_prefix[0] = 0u;
+                        const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63));
+                        __syncthreads();
+                        /* ---- all (record, step, side) items of this chunk, lanes packed -------------- */
+                        for (uint32_t it = lane; it < total_items; it += 64u) {
+                            uint32_t j = 0;
+                            while (it >= sh.seg_prefix[j + 1]) ++j;
+                            const SegRec q = sh.seg[j];
+                            const uint32_t local = it - sh.seg_prefix[j];
+                            const bool side1 = local >= (uint32_t)q.k_n0;
+                            const int32_t k = side1 ? q.k_lo1 + (int32_t)(local - (uint32_t)q.k_n0) : q.k_lo0 + (int32_t)local;
+                            const bool use_caps = q.caps_table != 0u;
+                            walk_item(q, k, side1 ? -1 : 1, plain_main && !use_caps, sa, use_caps ? &sa->caps : &sa->main,
+                                      initial_opacity, reach, rc, plane);
+                        }
+                        __syncthreads(); /* records are rewritten by the next chunk */
                     }
+                    e_base += ne;
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */

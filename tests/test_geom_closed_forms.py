@@ -76,10 +76,15 @@ def test_stroke_step_closed_form():
     rnd = random.Random(5)
     cases = [(a, b) for b in range(1, 40) for a in range(0, b + 1)]
     cases += [(rnd.randint(0, b), b) for b in (rnd.randint(1, 4000) for _ in range(400))]
+    cases += [(2047, 2047), (2046, 2047), (1, 2047), (0, 2047), (1024, 2047)]
     for a, b in cases:
         out = np.zeros((b + 1, 4), dtype=np.int32)
         _shim.lib().shim_stroke_steps(a, b, out.ctypes.data_as(C.POINTER(C.c_int32)))
         assert out.tolist() == _main_loop(a, b), (a, b)
+        if b < 2048:  # the 32-bit variant used for short segments
+            out24 = np.zeros((b + 1, 4), dtype=np.int32)
+            _shim.lib().shim_stroke_steps24(a, b, out24.ctypes.data_as(C.POINTER(C.c_int32)))
+            assert np.array_equal(out24, out), (a, b)
 
 
 def test_udiv_matches_integer_division():
