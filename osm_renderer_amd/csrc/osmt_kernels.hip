@@ -347,7 +347,7 @@ constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int NBUF = NTHREADS > 64 ? 2 : 1; /* multi-wave groups double-buffer planes/masks to save a barrier */
 constexpr int ROWSTEP = NTHREADS / SUB;     /* rows between a thread's consecutive pixels */
 #ifndef OSMT_V_ROWCAP
-#define OSMT_V_ROWCAP 32
+#define OSMT_V_ROWCAP 16
 #endif
 constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path */
 constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
