@@ -44,6 +44,31 @@ OSMT_HD int64_t osmt_ceil_div_pos(int64_t n, int64_t d) {
     return osmt_udiv(n + d - 1, d);
 }
 
+/* floor(n / d) for 0 <= n < 2^24, d > 0 in 32-bit arithmetic: approximate quotient from the
+ * f32 reciprocal (v_rcp_f32 on the GPU), then an exact integer remainder fix-up, so the result
+ * does not depend on how good the approximation is. */
+OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf((float)d);
+#else
+    const float r = 1.0f / (float)d;
+#endif
+    int32_t q = (int32_t)((float)n * r);
+    int32_t rem = n - q * d;
+    /* |q - floor(n/d)| <= 1 for n < 2^24 (reciprocal and product are each within one f32
+     * rounding of the exact value, q <= 2^23); two branch-free correction rounds cover +-2 */
+    for (int round = 0; round < 2; ++round) {
+        const int32_t up = rem >= d, down = rem < 0;
+        q += up - down;
+        rem += (down - up) * d;
+    }
+    return q;
+}
+OSMT_HD int32_t osmt_ceil_div_pos24(int32_t n, int32_t d) {
+    if (n <= 0) return 0;
+    return osmt_udiv24(n + d - 1, d);
+}
+
 /* ---- fill.rs:51-104 ------------------------------------------------------
  * The walk from p1 to p2 visits, on the row reached after j y-steps (0 <= j <= DY),
  * the columns i_first(j) .. i_last(j) (counted in x-steps from p1).  With a = |dx|,
@@ -65,7 +90,26 @@ OSMT_HD int osmt_fill_row_extent(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
     const int32_t sx = p1x < p2x ? 1 : -1;
     const int64_t j = p1y < p2y ? (int64_t)y - p1y : (int64_t)p1y - y;
     int64_t i0, i1;
-    if (a >= b) {
+    if (a < 2048 && b < 2048) {
+        /* short edge: (2j+1)a + 2b - 1 < 2^24, both divisions in 32-bit arithmetic */
+        const int32_t a32 = (int32_t)a, b32 = (int32_t)b, j32 = (int32_t)j;
+        int32_t q0, q1;
+        if (a32 >= b32) {
+            q0 = (j32 == 0) ? 0 : osmt_ceil_div_pos24((2 * j32 - 1) * a32, 2 * b32);
+            q1 = (j32 == b32) ? a32 : osmt_ceil_div_pos24((2 * j32 + 1) * a32, 2 * b32) - 1;
+        } else {
+            q0 = osmt_udiv24(2 * j32 * a32 + b32, 2 * b32);
+            if (j32 == b32) {
+                q1 = a32;
+            } else {
+                q1 = osmt_ceil_div_pos24((2 * j32 + 1) * a32, 2 * b32) - 1;
+                if (q1 < q0) q1 = q0;
+            }
+        }
+        i0 = q0;
+        i1 = q1;
+    } else if (a >= b) {
+
         i0 = (j == 0) ? 0 : osmt_ceil_div_pos((2 * j - 1) * a, 2 * b); /* L(j-1) + 1 */
         i1 = (j == b) ? a : osmt_ceil_div_pos((2 * j + 1) * a, 2 * b) - 1;
     } else {
@@ -118,31 +162,6 @@ OSMT_HD void osmt_seg_setup(osmt_seg* s, int32_t p1x, int32_t p1y, int32_t p2x, 
     s->sdx = (int64_t)p2x - (int64_t)p1x;
     s->sdy = (int64_t)p2y - (int64_t)p1y;
     s->denom = denom;
-}
-
-/* floor(n / d) for 0 <= n < 2^24, d > 0 in 32-bit arithmetic: approximate quotient from the
- * f32 reciprocal (v_rcp_f32 on the GPU), then an exact integer remainder fix-up, so the result
- * does not depend on how good the approximation is. */
-OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float r = __builtin_amdgcn_rcpf((float)d);
-#else
-    const float r = 1.0f / (float)d;
-#endif
-    int32_t q = (int32_t)((float)n * r);
-    int32_t rem = n - q * d;
-    /* |q - floor(n/d)| <= 1 for n < 2^24 (reciprocal and product are each within one f32
-     * rounding of the exact value, q <= 2^23); two branch-free correction rounds cover +-2 */
-    for (int round = 0; round < 2; ++round) {
-        const int32_t up = rem >= d, down = rem < 0;
-        q += up - down;
-        rem += (down - up) * d;
-    }
-    return q;
-}
-OSMT_HD int32_t osmt_ceil_div_pos24(int32_t n, int32_t d) {
-    if (n <= 0) return 0;
-    return osmt_udiv24(n + d - 1, d);
 }
 
 /* osmt_stroke_step for short segments (b < 2048): every intermediate is < 2^23, so the two
