@@ -231,6 +231,20 @@ def main():
             "gpu_matches_oracle_on_sample": bool(np.array_equal(gpu_out, cpu_out)),
         }
 
+    # HBM bytes per launch from the PMC counters cannot be read in-process: they are collected by
+    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command and
+    # committed as profiles/r01_hbm_traffic.json (with the gfx950 FETCH_SIZE correction noted there).
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            tr = json.load(f)
+        if args.tiles == 1024 and args.scale == 1 and args.n_poly == 50 and args.n_line == 40:
+            result["roofline"]["traffic"] = tr["k_raster"]["traffic_bytes_per_launch_fetch_x2"]
+            result["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC pass of an earlier run of this command"
+        if "roofline_composite" in result and args.composite_tiles == 64:
+            result["roofline_composite"]["traffic"] = tr["k_composite"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         print(json.dumps(result))
     scene.free()
