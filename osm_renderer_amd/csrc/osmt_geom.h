@@ -69,6 +69,27 @@ OSMT_HD int32_t osmt_ceil_div_pos24(int32_t n, int32_t d) {
     return osmt_udiv24(n + d - 1, d);
 }
 
+/* Exact fmod(x, y) for x >= 0, y > 0, x / y < 2^52 (the dash phase `dist_rem %= total_dash_len`,
+ * opacity_calculator.rs:57-60).  fmod's result x - n*y (n = trunc(x/y)) is always exactly
+ * representable, so one fma with the right n returns it without rounding; the rounded quotient
+ * can only be off by one, which the sign / range of the remainder reveals.  Several times
+ * shorter than the generic library routine (brute-forced against libm: tests/). */
+#if defined(__HIPCC__) || defined(__cplusplus)
+#include <math.h>
+#endif
+OSMT_HD double osmt_fmod_pos(double x, double y) {
+    double n = trunc(x / y);
+    double r = fma(-n, y, x);
+    if (r < 0.0) {
+        n -= 1.0;
+        r = fma(-n, y, x);
+    } else if (r >= y) {
+        n += 1.0;
+        r = fma(-n, y, x);
+    }
+    return r;
+}
+
 /* ---- fill.rs:51-104 ------------------------------------------------------
  * The walk from p1 to p2 visits, on the row reached after j y-steps (0 <= j <= DY),
  * the columns i_first(j) .. i_last(j) (counted in x-steps from p1).  With a = |dx|,

@@ -287,16 +287,22 @@ __device__ __forceinline__ double opacity_by_center_distance(double cd, double h
     return opacity_mul * v;
 }
 
-/* opacity_calculator.rs:32-80 calculate (+ get_opacity_by_start_distance) */
-__device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restrict__ t, double half_width,
-                                                  double traveled, double cd, double sd, double* opacity) {
+/* x / d with the (very common) d == 1.0 short-cut: x / 1.0 == x exactly */
+__device__ __forceinline__ double div_or_same(double x, double d) { return d == 1.0 ? x : x / d; }
+
+/* opacity_calculator.rs:32-80 calculate (+ get_opacity_by_start_distance).  `sa` carries the
+ * per-op constants of the cap_dist == 0 case (half_line_width = sqrt(h*h - 0*0) and its
+ * feather terms), which is every pixel unless a Round cap shrinks the line. */
+__device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restrict__ t,
+                                                  const osmt_stroke_aux* __restrict__ sa, double traveled, double cd,
+                                                  double sd, double* opacity) {
     double sd_op = 1.0;
     double cap_dist = 0.0;
     const int n = t->n_segs;
     if (n > 0) {
         double dist_rem = traveled + sd;
         const double total = t->total_len;
-        if (total > 0.0) dist_rem = fmod(dist_rem, total);
+        if (total > 0.0) dist_rem = osmt_fmod_pos(dist_rem, total); /* dist_rem >= 0: exact `%` */
         sd_op = 0.0;
         bool has = false;
         double dic = 0.0;
@@ -307,11 +313,11 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
             if (dist_rem < s->start_from || dist_rem > s->end_to) continue;
             double base;
             if (dist_rem <= s->start_to)
-                base = (dist_rem - s->start_from) / (s->start_to - s->start_from);
+                base = div_or_same(dist_rem - s->start_from, s->start_to - s->start_from);
             else if (dist_rem < s->end_from)
                 base = 1.0;
             else
-                base = (s->end_to - dist_rem) / (s->end_to - s->end_from);
+                base = div_or_same(s->end_to - dist_rem, s->end_to - s->end_from);
             sd_op = fmax(sd_op, s->opacity_mul * base);
             if (has_orig) { /* :159-169 */
                 double d;
@@ -329,8 +335,21 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
         }
         cap_dist = has ? dic : 0.0;
     }
-    const double hlw = sqrt(half_width * half_width - cap_dist * cap_dist);
-    const double cdop = opacity_by_center_distance(cd, hlw);
+    double cdop;
+    if (cap_dist == 0.0) {
+        /* sqrt(h*h - 0*0) and its feather terms: the per-op constants (opacity_calculator.rs:36,171-176) */
+        double v;
+        if (cd < sa->ff0)
+            v = 1.0;
+        else if (cd < sa->ft0)
+            v = div_or_same(sa->ft0 - cd, sa->fd0);
+        else
+            v = 0.0;
+        cdop = sa->mul0 * v;
+    } else {
+        const double hw = sa->half_width;
+        cdop = opacity_by_center_distance(cd, sqrt(hw * hw - cap_dist * cap_dist));
+    }
     *opacity = fmin(sd_op, cdop);
     return cdop > 0.0;
 }
@@ -423,7 +442,6 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     const int32_t step_mn = -mul * s.mx_inc; /* p_mn += (when corrected) */
     const int64_t raw_step = s.swap ? -s.sdx * step_mx : s.sdy * step_mx;
     const int64_t raw_corr = s.swap ? s.sdy * step_mn : -s.sdx * step_mn;
-    const double half_width = sa->half_width;
     const double ff0 = sa->ff0, ft0 = sa->ft0, fd0 = sa->fd0, mul0 = sa->mul0;
     for (;;) {
         const double cd = fabs((double)raw) / s.denom;
@@ -435,7 +453,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
             if (cd < ff0)
                 v = 1.0;
             else if (cd < ft0)
-                v = (ft0 - cd) / fd0;
+                v = div_or_same(ft0 - cd, fd0);
             else
                 v = 0.0;
             const double cdop = mul0 * v;
@@ -444,7 +462,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
         } else {
             const double ld = point_dist(px, py, s.p1x, s.p1y);
             const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));
-            in_line = opacity_calculate(tab, half_width, traveled, cd, sd, &op);
+            in_line = opacity_calculate(tab, sa, traveled, cd, sd, &op);
         }
         if (!in_line) break;
         if (px >= rc.x0 && px <= rc.x1 && py >= rc.y0 && py <= rc.y1) {

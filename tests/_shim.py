@@ -22,6 +22,8 @@ def lib():
         L.shim_fill_rows.argtypes = [C.c_int32] * 6 + [ip]
         L.shim_stroke_steps.argtypes = [C.c_int32, C.c_int32, ip]
         L.shim_stroke_steps24.argtypes = [C.c_int32, C.c_int32, ip]
+        L.shim_fmod_pos.argtypes = [C.c_double, C.c_double]
+        L.shim_fmod_pos.restype = C.c_double
         L.shim_udiv.argtypes = [C.c_int64, C.c_int64]
         L.shim_udiv.restype = C.c_int64
         L.shim_sizeof.argtypes = [C.c_int]

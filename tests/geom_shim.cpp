@@ -27,6 +27,7 @@ void shim_stroke_steps(int32_t a, int32_t b, int32_t* out) {
 void shim_stroke_steps24(int32_t a, int32_t b, int32_t* out) {
     for (int32_t k = 0; k <= b; ++k) osmt_stroke_step24(a, b, k, &out[4 * k], &out[4 * k + 1], &out[4 * k + 2], &out[4 * k + 3]);
 }
+double shim_fmod_pos(double x, double y) { return osmt_fmod_pos(x, y); }
 int64_t shim_udiv(int64_t n, int64_t d) { return osmt_udiv(n, d); }
 size_t shim_sizeof(int which) {
     switch (which) {

@@ -95,3 +95,19 @@ def test_udiv_matches_integer_division():
         assert _shim.lib().shim_udiv(n, d) == n // d
     for n, d in [(0, 1), ((1 << 52) - 1, 1), ((1 << 52) - 1, 3), (1 << 52, 7), ((1 << 59), (1 << 29) - 1)]:
         assert _shim.lib().shim_udiv(n, d) == n // d
+
+
+def test_fmod_pos_is_bit_exact_with_libm():
+    import math
+    import struct
+
+    rnd = random.Random(21)
+    f = _shim.lib().shim_fmod_pos
+    cases = []
+    for _ in range(60000):
+        y = rnd.choice([6.0, 18.0, 12.0, 3.0, 7.5, 0.1, 1e-3, rnd.uniform(0.01, 500.0)])
+        x = rnd.choice([rnd.uniform(0, 10 * y), rnd.uniform(0, 1e6), y * rnd.randint(0, 1000), y * rnd.randint(0, 1000) * (1 + 2**-52)])
+        cases.append((x, y))
+    cases += [(0.0, 1.0), (5.0, 5.0), (4.999999999999999, 5.0), (1e15, 3.0), (0.3, 0.1), (0.7, 0.1), (2**52 - 1.0, 1.0)]
+    for x, y in cases:
+        assert struct.pack("d", f(x, y)) == struct.pack("d", math.fmod(x, y)), (x, y)
