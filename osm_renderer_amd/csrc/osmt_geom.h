@@ -237,4 +237,52 @@ OSMT_HD void osmt_stroke_step(int32_t a32, int32_t b32, int32_t k32, int32_t* c_
     }
 }
 
+/* Main perpendicular of step k only: c = corrections so far, pe = p_error (see osmt_stroke_step). */
+OSMT_HD void osmt_stroke_main(int32_t a, int32_t b, int32_t k, int32_t* c_out, int32_t* pe) {
+    if (b < OSMT_STEP24_MAX_B) {
+        const int32_t c = osmt_ceil_div_pos24(2 * a * k - b, 2 * b);
+        const int32_t d = osmt_ceil_div_pos24(2 * a * c - b, 2 * b);
+        *c_out = c;
+        *pe = 2 * a * c - 2 * b * d;
+    } else {
+        const int64_t c = osmt_corrections(a, b, k);
+        const int64_t d = osmt_corrections(a, b, c);
+        *c_out = (int32_t)c;
+        *pe = (int32_t)(2 * (int64_t)a * c - 2 * (int64_t)b * d);
+    }
+}
+
+/* ---- the extra perpendiculars of line.rs:152-154 as directly enumerable events -------------
+ * An extra pair fires at step k < b exactly when both the main error and p_error are corrected
+ * (c and d = corrections(c) both increment).  d grows by at most one per correction, hence:
+ *   - the number of events at steps k < K is E(K) = d(c_K);
+ *   - the m-th event (m >= 1, needs a > 0) happens at c = c_m = floor((2bm - b) / 2a) + 1 (the
+ *     smallest c with d(c) >= m), on step k = floor((2b*c_m - b) / 2a) (the step whose update
+ *     brings the correction count to c_m), at (mn0 + c_m*mn_inc, mx0 + k*mx_inc), with
+ *     p_error = 2a*c_m - 2b*m.
+ * Brute-forced against the literal loop in tests/test_geom_closed_forms.py. */
+OSMT_HD int32_t osmt_extra_count(int32_t a, int32_t b, int32_t K) {
+    if (a <= 0 || K <= 0) return 0;
+    if (b < OSMT_STEP24_MAX_B) {
+        const int32_t c = osmt_ceil_div_pos24(2 * a * K - b, 2 * b);
+        return osmt_ceil_div_pos24(2 * a * c - b, 2 * b);
+    }
+    const int64_t c = osmt_corrections(a, b, K);
+    return (int32_t)osmt_corrections(a, b, c);
+}
+OSMT_HD void osmt_extra_event(int32_t a, int32_t b, int32_t m, int32_t* c_out, int32_t* k_out, int32_t* pe_out) {
+    if (b < OSMT_STEP24_MAX_B) {
+        const int32_t c = osmt_udiv24(2 * b * m - b, 2 * a) + 1;
+        *c_out = c;
+        *k_out = osmt_udiv24(2 * b * c - b, 2 * a);
+        *pe_out = 2 * a * c - 2 * b * m;
+    } else {
+        const int64_t A = a, B = b, M = m;
+        const int64_t c = osmt_udiv(2 * B * M - B, 2 * A) + 1;
+        *c_out = (int32_t)c;
+        *k_out = (int32_t)osmt_udiv(2 * B * c - B, 2 * A);
+        *pe_out = (int32_t)(2 * A * c - 2 * B * M);
+    }
+}
+
 #endif /* OSMT_GEOM_H */

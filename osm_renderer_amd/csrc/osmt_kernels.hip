@@ -383,7 +383,8 @@ struct SegRec {
     double traveled;
     double denom;         /* center_dist_denom (line.rs:104) */
     int64_t numer_const;  /* line.rs:102 */
-    int32_t k_lo0, k_n0, k_lo1, k_n1;
+    int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
+    int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
     uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
     uint32_t count;
 };
@@ -483,14 +484,15 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     }
 }
 
-/* Step ranges [k_lo, k_lo + k_n) of the two perpendicular sides of segment p1->p2 whose runs can
- * reach the sub-tile; returns the total number of (step, side) items, 0 when culled.
- * The run on side `mul` moves mul*mn_inc per step along the minor axis and -mul*mx_inc per
- * correction along the major axis, so the major-axis test is one-sided. */
+/* Items of segment p1->p2 for this sub-tile: per side the main-axis steps [k_lo, k_lo + k_n)
+ * whose perpendicular run can reach the sub-tile, and the extra-perpendicular events that fire on
+ * those steps; returns the total item count (0 when culled).  The run on side `mul` moves
+ * mul*mn_inc per step along the minor axis and -mul*mx_inc per correction along the major axis,
+ * so the major-axis test is one-sided.  Every item is exactly ONE perpendicular run. */
 __device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
-                                               int32_t reach_major, const SubRect& rc, int32_t* k_lo0, int32_t* k_n0,
-                                               int32_t* k_lo1, int32_t* k_n1) {
-    *k_lo0 = *k_n0 = *k_lo1 = *k_n1 = 0;
+                                               int32_t reach_major, const SubRect& rc, SegRec* q) {
+    q->k_lo0 = q->k_n0 = q->k_lo1 = q->k_n1 = 0;
+    q->m_lo0 = q->n_x0 = q->m_lo1 = q->n_x1 = 0;
     if (p1x == p2x && p1y == p2y) return 0u; /* line.rs:73-75 */
     /* every set pixel lies within `reach` (per axis) of the segment's box */
     if (max(p1x, p2x) + reach < rc.x0 || min(p1x, p2x) - reach > rc.x1 || max(p1y, p2y) + reach < rc.y0 ||
@@ -499,7 +501,7 @@ __device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t
     const int32_t dx = abs(p2x - p1x), dy = abs(p2y - p1y);
     const bool swap = dx > dy;
     const int32_t mx0 = swap ? p1x : p1y;
-    const int32_t bmax = swap ? dx : dy;
+    const int32_t bmax = swap ? dx : dy, amin = swap ? dy : dx;
     const int32_t mx_inc = swap ? (p1x <= p2x ? 1 : -1) : (p1y <= p2y ? 1 : -1);
     const int32_t LO = swap ? rc.x0 : rc.y0, HI = swap ? rc.x1 : rc.y1;
     uint32_t total = 0;
@@ -519,42 +521,55 @@ __device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t
         a = max(a, 0);
         b = min(b, bmax);
         const int32_t n = max(b - a + 1, 0);
-        if (side == 0) {
-            *k_lo0 = a;
-            *k_n0 = n;
-        } else {
-            *k_lo1 = a;
-            *k_n1 = n;
+        int32_t m_lo = 0, n_x = 0;
+        if (n > 0) { /* events on steps a .. min(b, bmax-1): E(min(b, bmax-1) + 1) - E(a) */
+            const int32_t e0 = osmt_extra_count(amin, bmax, a);
+            const int32_t e1 = osmt_extra_count(amin, bmax, min(b, bmax - 1) + 1);
+            m_lo = e0 + 1;
+            n_x = max(e1 - e0, 0);
         }
-        total += (uint32_t)n;
+        if (side == 0) {
+            q->k_lo0 = a; q->k_n0 = n; q->m_lo0 = m_lo; q->n_x0 = n_x;
+        } else {
+            q->k_lo1 = a; q->k_n1 = n; q->m_lo1 = m_lo; q->n_x1 = n_x;
+        }
+        total += (uint32_t)(n + n_x);
     }
     return total;
 }
 
-/* One (step, side) item of a segment record: the closed-form walk state at the step, then the
- * main perpendicular and, when it fires, the extra one of line.rs:152-154. */
-__device__ __forceinline__ void walk_item(const SegRec& r, int32_t k, int32_t mul, const bool plain,
-                                          const osmt_stroke_aux* __restrict__ sa,
-                                          const osmt_dash_table* __restrict__ tab, double initial_opacity,
+/* One item of a segment record = one perpendicular run (line.rs:108-137): items [0, k_n0 + k_n1)
+ * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
+ * of line.rs:152-154, located directly by osmt_extra_event. */
+__device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const bool plain_main,
+                                          const osmt_stroke_aux* __restrict__ sa, double initial_opacity,
                                           int32_t reach, const SubRect& rc, unsigned long long* __restrict__ plane) {
     osmt_seg s;
     osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom);
     s.numer_const = r.numer_const;
-    int32_t c, pe, has_extra, pe_extra;
-    if (s.b < OSMT_STEP24_MAX_B)
-        osmt_stroke_step24(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
-    else
-        osmt_stroke_step(s.a, s.b, k, &c, &pe, &has_extra, &pe_extra);
+    const uint32_t n_main = (uint32_t)(r.k_n0 + r.k_n1);
+    int32_t k, c, pe, mul;
+    if (local < n_main) {
+        const bool side1 = local >= (uint32_t)r.k_n0;
+        k = side1 ? r.k_lo1 + (int32_t)(local - (uint32_t)r.k_n0) : r.k_lo0 + (int32_t)local;
+        mul = side1 ? -1 : 1;
+        osmt_stroke_main(s.a, s.b, k, &c, &pe);
+    } else {
+        const uint32_t x = local - n_main;
+        const bool side1 = x >= (uint32_t)r.n_x0;
+        const int32_t m = side1 ? r.m_lo1 + (int32_t)(x - (uint32_t)r.n_x0) : r.m_lo0 + (int32_t)x;
+        mul = side1 ? -1 : 1;
+        osmt_extra_event(s.a, s.b, m, &c, &k, &pe);
+    }
     const int32_t mx = s.mx0 + k * s.mx_inc;
-    int32_t mn = s.mn0 + c * s.mn_inc;
+    const int32_t mn = s.mn0 + c * s.mn_inc;
     /* pixel minor = mn + mul*mn_inc*t, 0 <= t <= reach */
     int32_t mlo = s.swap ? rc.y0 : rc.x0, mhi = s.swap ? rc.y1 : rc.x1;
     if (mul * s.mn_inc > 0) mlo -= reach; else mhi += reach;
-    for (int32_t w = 0; w <= has_extra; ++w) { /* one call site for both perpendiculars */
-        if (mn >= mlo && mn <= mhi)
-            walk_perpendicular(plain, s, sa, tab, r.traveled, initial_opacity, mn, mx, w ? pe_extra : pe, mul, rc, plane);
-        mn += s.mn_inc;
-    }
+    const bool use_caps = r.caps_table != 0u;
+    if (mn >= mlo && mn <= mhi)
+        walk_perpendicular(plain_main && !use_caps, s, sa, use_caps ? &sa->caps : &sa->main, r.traveled,
+                           initial_opacity, mn, mx, pe, mul, rc, plane);
 }
 
 /* point.rs:27-35 push_away_from */
@@ -702,8 +717,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         SegRec rec;
                         rec.count = 0;
                         if (live)
-                            rec.count = seg_ranges(p1.x, p1.y, p2.x, p2.y, reach, reach_major, rc, &rec.k_lo0, &rec.k_n0,
-                                                   &rec.k_lo1, &rec.k_n1);
+                            rec.count = seg_ranges(p1.x, p1.y, p2.x, p2.y, reach, reach_major, rc, &rec);
                         const unsigned long long bal = __ballot(rec.count > 0u);
                         uint32_t m = (uint32_t)__popcll(bal);
                         if (rec.count > 0u) {
@@ -722,8 +736,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                                 const int2 from = which == 0 ? p1 : p2;
                                 const int2 ce = which == 0 ? push_away_from(p1, p2, half_width)
                                                            : push_away_from(p2, p1, half_width);
-                                cr.count = seg_ranges(from.x, from.y, ce.x, ce.y, reach, reach_major, rc, &cr.k_lo0,
-                                                      &cr.k_n0, &cr.k_lo1, &cr.k_n1);
+                                cr.count = seg_ranges(from.x, from.y, ce.x, ce.y, reach, reach_major, rc, &cr);
                                 if (cr.count > 0u) {
                                     cr.p1x = from.x; cr.p1y = from.y; cr.p2x = ce.x; cr.p2y = ce.y;
                                     cr.traveled = 0.0;
@@ -759,12 +772,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             uint32_t j = 0;
                             while (it >= sh.seg_prefix[j + 1]) ++j;
                             const SegRec q = sh.seg[j];
-                            const uint32_t local = it - sh.seg_prefix[j];
-                            const bool side1 = local >= (uint32_t)q.k_n0;
-                            const int32_t k = side1 ? q.k_lo1 + (int32_t)(local - (uint32_t)q.k_n0) : q.k_lo0 + (int32_t)local;
-                            const bool use_caps = q.caps_table != 0u;
-                            walk_item(q, k, side1 ? -1 : 1, plain_main && !use_caps, sa, use_caps ? &sa->caps : &sa->main,
-                                      initial_opacity, reach, rc, plane);
+                            walk_item(q, it - sh.seg_prefix[j], plain_main, sa, initial_opacity, reach, rc, plane);
                         }
                         __syncthreads(); /* records are rewritten by the next chunk */
                     }

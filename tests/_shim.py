@@ -22,6 +22,8 @@ def lib():
         L.shim_fill_rows.argtypes = [C.c_int32] * 6 + [ip]
         L.shim_stroke_steps.argtypes = [C.c_int32, C.c_int32, ip]
         L.shim_stroke_steps24.argtypes = [C.c_int32, C.c_int32, ip]
+        L.shim_extra_events.argtypes = [C.c_int32, C.c_int32, ip, ip]
+        L.shim_extra_events.restype = C.c_int32
         L.shim_fmod_pos.argtypes = [C.c_double, C.c_double]
         L.shim_fmod_pos.restype = C.c_double
         L.shim_udiv.argtypes = [C.c_int64, C.c_int64]

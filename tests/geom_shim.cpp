@@ -27,6 +27,13 @@ void shim_stroke_steps(int32_t a, int32_t b, int32_t* out) {
 void shim_stroke_steps24(int32_t a, int32_t b, int32_t* out) {
     for (int32_t k = 0; k <= b; ++k) osmt_stroke_step24(a, b, k, &out[4 * k], &out[4 * k + 1], &out[4 * k + 2], &out[4 * k + 3]);
 }
+// all extra events of a segment: out[i] = {c, k, pe}; returns the count E(b)
+int32_t shim_extra_events(int32_t a, int32_t b, int32_t* out, int32_t* counts /* [b+1]: E(K) */) {
+    for (int32_t K = 0; K <= b; ++K) counts[K] = osmt_extra_count(a, b, K);
+    const int32_t n = counts[b];
+    for (int32_t m = 1; m <= n; ++m) osmt_extra_event(a, b, m, &out[3 * (m - 1)], &out[3 * (m - 1) + 1], &out[3 * (m - 1) + 2]);
+    return n;
+}
 double shim_fmod_pos(double x, double y) { return osmt_fmod_pos(x, y); }
 int64_t shim_udiv(int64_t n, int64_t d) { return osmt_udiv(n, d); }
 size_t shim_sizeof(int which) {

@@ -111,3 +111,21 @@ def test_fmod_pos_is_bit_exact_with_libm():
     cases += [(0.0, 1.0), (5.0, 5.0), (4.999999999999999, 5.0), (1e15, 3.0), (0.3, 0.1), (0.7, 0.1), (2**52 - 1.0, 1.0)]
     for x, y in cases:
         assert struct.pack("d", f(x, y)) == struct.pack("d", math.fmod(x, y)), (x, y)
+
+
+def test_extra_perpendicular_events_enumeration():
+    """osmt_extra_count / osmt_extra_event against the events of the literal main loop."""
+    rnd = random.Random(31)
+    cases = [(a, b) for b in range(1, 36) for a in range(0, b + 1)]
+    cases += [(rnd.randint(0, b), b) for b in (rnd.randint(1, 5000) for _ in range(300))]
+    cases += [(2047, 2047), (2046, 2047), (1, 2047), (2048, 2048), (1500, 2049)]
+    for a, b in cases:
+        loop = _main_loop(a, b)
+        events = [(rec[0] + 1, k, rec[3]) for k, rec in enumerate(loop) if rec[2]]  # (c after update, k, p_error)
+        out = np.zeros((b + 2, 3), dtype=np.int32)
+        counts = np.zeros(b + 1, dtype=np.int32)
+        n = _shim.lib().shim_extra_events(a, b, out.ctypes.data_as(C.POINTER(C.c_int32)), counts.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert n == len(events), (a, b)
+        assert [tuple(r) for r in out[:n].tolist()] == events, (a, b)
+        want_counts = np.cumsum([0] + [rec[2] for rec in loop[:-1]])  # events at steps k < K
+        assert counts.tolist() == want_counts.tolist(), (a, b)
