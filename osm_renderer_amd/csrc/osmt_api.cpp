@@ -70,6 +70,7 @@ struct osmt_scene {
     uint32_t* d_op_aux = nullptr;
     osmt_opinfo* d_info = nullptr;
     double* d_trav = nullptr;
+    double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     uint32_t* d_submask = nullptr;
 };
@@ -160,7 +161,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
+                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
@@ -174,6 +175,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.rings = sc->d_rings;
         a.pts = reinterpret_cast<const int2*>(sc->d_pts);
         a.trav = sc->d_trav;
+        a.den = sc->d_den;
         a.aux = sc->d_aux;
         a.submask = sc->d_submask;
         a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
@@ -291,6 +293,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t o_opaux = carve(b->n_ops * 4);
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
+    const size_t o_den = carve(b->n_pts * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
@@ -311,6 +314,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->d_op_aux = (uint32_t*)(s->d_base + o_opaux);
     s->d_info = (osmt_opinfo*)(s->d_base + o_info);
     s->d_trav = (double*)(s->d_base + o_trav);
+    s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
 

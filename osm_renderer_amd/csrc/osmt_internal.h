@@ -33,8 +33,18 @@ struct osmt_dash_table {
 };
 
 /* the two calculators of draw_lines (line.rs:21-22) */
+/* A cap stub of draw_lines (line.rs:33-57): p1 -> p1.push_away_from(p2, half_width) of the first
+ * edge, p2 -> p2.push_away_from(p1, half_width) of the last one; computed once per op. */
+struct osmt_cap_seg {
+    int32_t p1x, p1y, p2x, p2y;
+    int32_t valid; /* the edge is not degenerate and the cap is Round/Square */
+    int32_t _pad;
+    double denom;  /* center_dist_denom of the stub */
+};
+
 struct osmt_stroke_aux {
     double half_width;
+    osmt_cap_seg cap_seg[2];
     /* get_opacity_by_center_distance terms for cap_dist == 0 (opacity_calculator.rs:36,171-176):
      * hlw0 = sqrt(h*h - 0*0), feather_from/to/dist and opacity_mul of hlw0 */
     double hlw0, ff0, ft0, fd0, mul0;
@@ -64,6 +74,7 @@ struct osmt_raster_args {
     const osmt_ring* rings;
     const int2* pts;
     const double* trav;
+    const double* den; /* per edge (indexed by its first point): center_dist_denom = |p2 - p1| */
     const osmt_stroke_aux* aux;
     const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
@@ -82,7 +93,7 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
                                       double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st);
+                              double* den, osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);

@@ -94,6 +94,16 @@ __device__ __forceinline__ double point_dist(int32_t ax, int32_t ay, int32_t bx,
     return sqrt(dx * dx + dy * dy);
 }
 
+/* point.rs:27-35 push_away_from */
+__device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by) {
+    const double dist = point_dist(self.x, self.y, other.x, other.y);
+    const double k = by / dist;
+    int2 r;
+    r.x = self.x + f64_as_i32(round((double)(self.x - other.x) * k));
+    r.y = self.y + f64_as_i32(round((double)(self.y - other.y) * k));
+    return r;
+}
+
 /* opacity_calculator.rs:98-143 compute_segments, for one calculator. */
 __device__ void compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap,
                                  osmt_dash_table* t) {
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                                                const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
                                                const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
                                                osmt_opinfo* __restrict__ info, double* __restrict__ trav,
-                                               osmt_stroke_aux* __restrict__ aux, uint32_t* __restrict__ submask,
+                                               double* __restrict__ den, osmt_stroke_aux* __restrict__ aux,
+                                               uint32_t* __restrict__ submask,
                                                uint32_t sub_rows) {
     const uint32_t o = blockIdx.x * 64u + threadIdx.x;
     if (o >= n_ops) return;
@@ -187,7 +198,13 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
             oi.y0 = min(oi.y0, p.y);
             oi.y1 = max(oi.y1, p.y);
             if (op.kind == OSMT_OP_STROKE) {
-                if (i > 0) traveled += point_dist(prev.x, prev.y, p.x, p.y);
+                if (i > 0) {
+                    /* |p2 - p1| is both the traveled increment (line.rs:31) and center_dist_denom
+                     * (line.rs:104: sqrt(dy*dy + dx*dx) of the absolute deltas — the same f64) */
+                    const double len = point_dist(prev.x, prev.y, p.x, p.y);
+                    den[ring.first_pt + i - 1] = len;
+                    traveled += len;
+                }
                 trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
             }
             prev = p;
@@ -236,6 +253,32 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         }
         osmt_stroke_aux* sa = &aux[oi.aux];
         sa->half_width = hw;
+        /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
+         * degenerate (`first` is consumed by a degenerate first edge) */
+        {
+            osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0, 1.0}, c1 = {0, 0, 0, 0, 0, 0, 1.0};
+            uint32_t seen = 0;
+            for (uint32_t r = 0; r < op.n_rings && caps; ++r) {
+                const osmt_ring ring = rings[op.ring_off + r];
+                for (uint32_t i = 1; i < ring.n_pts; ++i) {
+                    ++seen;
+                    if (seen != 1 && seen != n_edges) continue;
+                    const int2 a = pts[ring.first_pt + i - 1];
+                    const int2 b = pts[ring.first_pt + i];
+                    if (a.x == b.x && a.y == b.y) continue;
+                    if (seen == 1) {
+                        const int2 ce = push_away_from(a, b, hw);
+                        c0 = {a.x, a.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, a.x, a.y)};
+                    }
+                    if (seen == n_edges) {
+                        const int2 ce = push_away_from(b, a, hw);
+                        c1 = {b.x, b.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, b.x, b.y)};
+                    }
+                }
+            }
+            sa->cap_seg[0] = c0;
+            sa->cap_seg[1] = c1;
+        }
         sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
         sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
@@ -382,13 +425,12 @@ struct SegRec {
     int32_t p1x, p1y, p2x, p2y;
     double traveled;
     double denom;         /* center_dist_denom (line.rs:104) */
-    int64_t numer_const;  /* line.rs:102 */
     int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
     int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
     uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
     uint32_t count;
 };
-constexpr int SEGCAP = 64 + 2;
+constexpr int SEGCAP = 64;
 
 struct RasterShared {
     SegRec seg[SEGCAP];
@@ -546,7 +588,6 @@ __device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const
                                           int32_t reach, const SubRect& rc, unsigned long long* __restrict__ plane) {
     osmt_seg s;
     osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom);
-    s.numer_const = r.numer_const;
     const uint32_t n_main = (uint32_t)(r.k_n0 + r.k_n1);
     int32_t k, c, pe, mul;
     if (local < n_main) {
@@ -572,16 +613,6 @@ __device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const
                            initial_opacity, mn, mx, pe, mul, rc, plane);
 }
 
-/* point.rs:27-35 push_away_from */
-__device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by) {
-    const double dist = point_dist(self.x, self.y, other.x, other.y);
-    const double k = by / dist;
-    int2 r;
-    r.x = self.x + f64_as_i32(round((double)(self.x - other.x) * k));
-    r.y = self.y + f64_as_i32(round((double)(self.y - other.y) * k));
-    return r;
-}
-
 #ifndef OSMT_V_WAVES
 #define OSMT_V_WAVES 3
 #endif
@@ -603,7 +634,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * list is read-only and fetch wave-uniform records with scalar loads */
     const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_op* OSMT_R g_ops,
     const osmt_opinfo* OSMT_R g_info, const osmt_ring* OSMT_R g_rings, const int2* OSMT_R g_pts,
-    const double* OSMT_R g_trav, const osmt_stroke_aux* OSMT_R g_aux,
+    const double* OSMT_R g_trav, const double* OSMT_R g_den, const osmt_stroke_aux* OSMT_R g_aux,
     const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
     const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
     size_t g_out_tile_stride) {
@@ -688,7 +719,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
                 const osmt_opinfo* __restrict__ oi = &g_info[o];
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[oi->aux];
-                const double half_width = sa->half_width;
                 const bool plain_main = sa->main.n_segs == 0;
                 const double initial_opacity = op->opacity;
                 const int32_t reach = oi->reach;
@@ -701,73 +731,51 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     const osmt_ring ring = g_rings[op->ring_off + r];
                     if (ring.n_pts < 2) continue;
                     const uint32_t ne = ring.n_pts - 1;
-                    for (uint32_t cb = 0; cb < ne; cb += 64u) {
-                        /* ---- one lane per edge: cull, step ranges, record -------------------- */
-                        const uint32_t e = cb + lane;
-                        const bool valid = e < ne;
-                        int2 p1 = make_int2(0, 0), p2 = make_int2(0, 0);
-                        double trav = 0.0;
-                        if (valid) {
-                            p1 = g_pts[ring.first_pt + e];
-                            p2 = g_pts[ring.first_pt + e + 1];
-                            trav = g_trav[ring.first_pt + e];
-                        }
-                        const uint32_t ge = e_base + e; /* running edge index over all rings */
-                        const bool live = valid && !(p1.x == p2.x && p1.y == p2.y);
+                    /* virtual segments of this ring: its edges, and after the last edge of the op
+                     * the two cap stubs precomputed by k_opinfo (line.rs:33-57) */
+                    const uint32_t nv = ne + ((has_caps && e_base + ne == n_edges) ? 2u : 0u);
+                    for (uint32_t cb = 0; cb < nv; cb += 64u) {
+                        /* ---- one lane per virtual segment: cull, item ranges, record ------------- */
+                        const uint32_t v = cb + lane;
                         SegRec rec;
                         rec.count = 0;
-                        if (live)
-                            rec.count = seg_ranges(p1.x, p1.y, p2.x, p2.y, reach, reach_major, rc, &rec);
-                        const unsigned long long bal = __ballot(rec.count > 0u);
-                        uint32_t m = (uint32_t)__popcll(bal);
-                        if (rec.count > 0u) {
+                        rec.p1x = rec.p1y = rec.p2x = rec.p2y = 0;
+                        rec.traveled = 0.0;
+                        rec.denom = 1.0;
+                        rec.caps_table = 0u;
+                        bool live = false;
+                        if (v < ne) {
+                            const int2 p1 = g_pts[ring.first_pt + v];
+                            const int2 p2 = g_pts[ring.first_pt + v + 1];
                             rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
-                            rec.traveled = trav;
-                            rec.caps_table = 0u;
-                            sh.seg[__popcll(bal & ((1ull << lane) - 1ull))] = rec;
+                            rec.traveled = g_trav[ring.first_pt + v];
+                            rec.denom = g_den[ring.first_pt + v];
+                            live = true;
+                        } else if (v < nv) {
+                            const osmt_cap_seg cs = sa->cap_seg[v - ne];
+                            rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
+                            rec.denom = cs.denom;
+                            rec.caps_table = 1u;
+                            live = cs.valid != 0;
                         }
-                        /* cap stubs: start of the first edge, end of the last edge (line.rs:33-57) */
-#pragma unroll
-                        for (int which = 0; which < 2; ++which) {
-                            const bool mine = live && has_caps && (which == 0 ? ge == 0u : ge + 1u == n_edges);
-                            SegRec cr;
-                            cr.count = 0;
-                            if (mine) {
-                                const int2 from = which == 0 ? p1 : p2;
-                                const int2 ce = which == 0 ? push_away_from(p1, p2, half_width)
-                                                           : push_away_from(p2, p1, half_width);
-                                cr.count = seg_ranges(from.x, from.y, ce.x, ce.y, reach, reach_major, rc, &cr);
-                                if (cr.count > 0u) {
-                                    cr.p1x = from.x; cr.p1y = from.y; cr.p2x = ce.x; cr.p2y = ce.y;
-                                    cr.traveled = 0.0;
-                                    cr.caps_table = 1u;
-                                    sh.seg[m] = cr;
-                                }
-                            }
-                            m += __ballot(cr.count > 0u) != 0ull ? 1u : 0u;
-                        }
-                        m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-                        __syncthreads();
-                        /* ---- per record: line constants once; exclusive prefix of item counts ---- */
-                        uint32_t cnt = 0;
-                        if (lane < m) {
-                            SegRec& q = sh.seg[lane];
-                            cnt = q.count;
-                            const double dxf = (double)abs(q.p2x - q.p1x), dyf = (double)abs(q.p2y - q.p1y);
-                            q.denom = sqrt(dyf * dyf + dxf * dxf);
-                            q.numer_const = (int64_t)q.p2x * (int64_t)q.p1y - (int64_t)q.p2y * (int64_t)q.p1x;
-                        }
-                        uint32_t incl = cnt;
+                        if (live) rec.count = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, reach, reach_major, rc, &rec);
+                        const unsigned long long bal = __ballot(rec.count > 0u);
+                        const uint32_t m = (uint32_t)__popcll(bal);
+                        if (m == 0u) continue; /* wave-uniform */
+                        const uint32_t slot = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                        if (rec.count > 0u) sh.seg[slot] = rec;
+                        /* exclusive prefix of the item counts of the compacted records */
+                        uint32_t incl = rec.count;
 #pragma unroll
                         for (uint32_t d = 1; d < 64u; d <<= 1) {
                             const uint32_t y = __shfl_up(incl, d);
                             if (lane >= d) incl += y;
                         }
-                        if (lane < m) sh.seg_prefix[lane + 1] = incl;
+                        if (rec.count > 0u) sh.seg_prefix[slot + 1] = incl;
                         if (lane == 0) sh.seg_prefix[0] = 0u;
                         const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63));
                         __syncthreads();
-                        /* ---- all (record, step, side) items of this chunk, lanes packed -------------- */
+                        /* ---- all (record, item) pairs of this chunk, lanes packed --------------------- */
                         for (uint32_t it = lane; it < total_items; it += 64u) {
                             uint32_t j = 0;
                             while (it >= sh.seg_prefix[j + 1]) ++j;
@@ -1056,10 +1064,10 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
 
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
+                              double* den, osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
     if (n_ops == 0) return hipSuccess;
     hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
-                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, aux, submask, sub_rows);
+                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, submask, sub_rows);
     return hipGetLastError();
 }
 
@@ -1071,11 +1079,11 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const dim3 grid(groups * 8u * nsub);
     if (out_f64)
         hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.pts, a.trav, a.den, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
                            a.out_tile_stride);
     else
         hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.pts, a.trav, a.den, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
                            a.out_tile_stride);
     return hipGetLastError();
 }
