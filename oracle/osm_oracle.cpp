@@ -12,22 +12,22 @@
  * PARITY PIN STATUS
  *   - projection (tile.rs:88-106): PINNED by the reference's own doctest known-answer
  *     values (src/tile.rs:26-28, 83-86) — tests/test_oracle_kat.py.
- *   - stroke walk + across-feathering + round caps + two-generation "over" blend + u8
- *     truncation (line.rs, opacity_calculator.rs:171-185,98-143 with the [0.0] cap pattern,
- *     tile_pixels.rs): PINNED by a crop of the reference's real golden image
- *     tests/rendered/18_expected.png (852 pixels of a service-road stub, 24 distinct
- *     colours, reproduced with 0 differing pixels; +-1 px / reversed inputs do not match).
- *   - polygon fill rule (fill.rs: fat Bresenham extents, smaller-y-row exclusion, pairing):
- *     PINNED by a second crop of the same golden (3411-pixel opaque polygon reproduced
- *     exactly by a fitted 16-vertex ring).  Both crops: tests/golden/ref_z18_patches.json,
- *     tests/test_reference_golden_patches.py; inputs were FITTED (the .osm is missing), see
+ *   - fill / stroke / blend / RGB: PINNED by four crops of the reference's REAL golden images
+ *     (tests/rendered/17_expected.png, 18_expected.png) that the oracle reproduces with ZERO
+ *     differing pixels from stylesheet parameters + fitted integer vertices
+ *     (tests/golden/ref_golden_patches.json, tests/test_reference_golden_patches.py):
+ *       stub     852 px   thick AA stroke walk, across-feather, Round caps, 2-generation over, u8
+ *       dashed  1239 px   dash pattern 6,8 with Round caps for dashes (use_caps_for_dashes),
+ *                         traveled phase, 0.5-opacity third generation (161 colours)
+ *       building 990 px   fill-opacity 0.9 polygon + 0.2-px outline of a closed 8-vertex ring
+ *       wood    3411 px   opaque 16-vertex polygon: fat Bresenham extents, top-row exclusion, pairing
+ *     Inputs were FITTED (the .osm is missing); +-1 px / reversed inputs do not match — see
  *     tests/golden/make_ref_patches.py for what that does and does not prove.
- *   - NOT pinned by any reference output (the reference cannot be built here — no
- *     rustc/cargo, crates not vendored — and tests/osm/nano_moscow.osm is absent): dash
- *     patterns, square/butt caps, use_caps_for_dashes, image fills, translucent fills,
- *     multipolygon rings.  For these the oracle is checked only against the hand-derived
- *     vectors K1..K8 (tests/golden/kat.json, derived from the reference SOURCE).  Status of
- *     those parts: PARITY UNPINNED.
+ *   - NOT pinned by any reference output (the reference cannot be built here — no rustc/cargo,
+ *     crates not vendored — and tests/osm/nano_moscow.osm is absent): Square/Butt caps,
+ *     use_caps_for_dashes = false, image fills, multipolygon (multi-ring) fills.  For these the
+ *     oracle is checked only against the hand-derived vectors K1..K8 (tests/golden/kat.json,
+ *     derived from the reference SOURCE).  Status of those parts: PARITY UNPINNED.
  *
  * Rust -> C++ semantics kept on purpose:
  *   f64::round -> std::round (half away from zero); `as i32` / `as u8` ->

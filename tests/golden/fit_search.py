@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The searches that recovered the inputs of tests/golden/ref_z18_patches.json (kept for
+"""The searches that recovered the inputs of tests/golden/ref_golden_patches.json (kept for
 reproducibility; build container only — reads /root/reference and uses the CPU oracle).
 
   stub : brute force over both endpoints (13x13 x 9x11 candidates, both directions) of the
@@ -9,6 +9,13 @@ reproducibility; build container only — reads /root/reference and uses the CPU
   wood : convex hull of the exact-colour pixels -> Douglas-Peucker -> coordinate descent on
          vertices (+-2), then "insert one vertex near a differing pixel, wiggling both
          neighbours +-1" until the symmetric difference of fill masks is empty (16 vertices).
+
+  dashed   : same brute force for the three-stroke access=private service way (7x7 x 12x12 endpoint
+             candidates, both directions): E=(230,181) -> J=(130,119) gives 0 differing pixels in the
+             1239-px mask, the reversed direction 111, every other candidate >= 215.
+  building : start from eye-balled corners; exhaustive search of the two vertices that lie outside the
+             comparison window (16x10 x 10x8 positions, both ring directions), then coordinate descent
+             (+-2) on all eight: 0 differing pixels in the 30x33 window; reversed ring 8; any +-1 move >= 29.
 """
 import itertools
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Builds tests/golden/ref_z18_patches.json: two small crops of the reference's OWN golden
+"""Builds tests/golden/ref_golden_patches.json: two small crops of the reference's OWN golden
 image tests/rendered/18_expected.png (the expected output of its integration test
 tests/test_rendering.rs:166-170, z18 mosaic, 256-px tiles with a red grid) together with
 display-list inputs that re-synthesise them.
@@ -17,6 +17,16 @@ the reversed segment differs in 1), so they pin the oracle to the reference's re
                  ::roads-casing  color #999999 width 7 linecap round   (mapnik.mapcss:2138-2144)
                  main            color white   width 6 linecap round   (mapnik.mapcss:3546-3551)
                  over landuse=residential fill #dddddd, opaque          (mapnik.mapcss:83-85)
+  patch "dashed": a highway=service way with access=private of mosaic tile (col 0, row 0): the same casing +
+                 white strokes, then the ::access overlay color #efa9a9 width 6 opacity 0.5 dashes 6,8
+                 linecap round (mapnik.mapcss:4171-4180) with use_caps_for_dashes = true (Josm style type,
+                 src/mapcss/styler.rs:95), over landuse=retail fill #efc8c8 (mapnik.mapcss:232).  The way runs
+                 from the junction (230,181) to the free end (130,119); the reversed direction differs in 111 px.
+  patch "building": z17 golden (tests/rendered/17_expected.png), mosaic tile (col 1, row 3): a building
+                 polygon, fill #bca9a9 fill-opacity 0.9 (mapnik.mapcss:2349-2353) in the Fill pass, then its
+                 outline color #330066 width 0.2 (mapnik.mapcss:2355-2359; no linecap) in the Stroke pass, over
+                 the canvas #f1eee8.  8 fitted vertices; the whole 30x33 window matches (66 colours); the other
+                 ring direction differs in 8 px, every +-1 vertex move in >= 29.
   patch "wood":  natural=wood / landuse=wood polygon, fill #aed1a0 opaque (mapnik.mapcss:243-246)
                  over the same #dddddd.
 
@@ -33,6 +43,11 @@ SRC = "/root/reference/tests/rendered/18_expected.png"
 TILE_COL, TILE_ROW = 0, 1
 
 STUB = dict(J=(180, 120), E=(252, 162), window=(200, 254, 130, 170))  # x0, x1, y0, y1 inclusive, tile coords
+DASHED = dict(J=(130, 119), E=(230, 181), window=(118, 226, 108, 190))  # drawn E -> J
+BUILDING = dict(  # drawn in this vertex order (closed)
+    ring=[(197, 77), (195, 84), (202, 86), (198, 102), (208, 104), (210, 95), (226, 99), (230, 85), (197, 77)],
+    window=(194, 223, 74, 106),
+)
 WOOD = dict(
     ring=[(201, 158), (190, 181), (171, 171), (155, 163), (148, 156), (141, 151), (129, 142), (124, 138), (120, 131),
           (120, 117), (126, 111), (130, 108), (134, 104), (138, 101), (153, 105), (159, 109), (201, 158)],
@@ -66,6 +81,49 @@ def main():
         "expected_rgb": tile[y0 : y1 + 1, x0 : x1 + 1].tolist(),
     }
 
+    tile00 = im[0:256, 0:256]
+    x0, x1, y0, y1 = DASHED["window"]
+    ys, xs = np.mgrid[y0 : y1 + 1, x0 : x1 + 1]
+    P = np.stack([xs, ys], -1).astype(float)
+    J, E = np.array(DASHED["J"], float), np.array(DASHED["E"], float)
+    d = E - J
+    t = np.clip(((P - J) @ d) / (d @ d), 0, 1)
+    dist = np.linalg.norm(P - (J + t[..., None] * d), axis=-1)
+    # whole width near the free end; further on (building outlines touch the casing) only the opaque core
+    dmask = ((dist <= 7.5) & (xs <= 185)) | ((dist <= 2.2) & (xs <= 218))
+    pts = [list(DASHED["E"]), list(DASHED["J"])]
+    dashed = {
+        "source": "tests/rendered/18_expected.png, mosaic tile (col 0, row 0), tile-relative pixel coordinates",
+        "window_x0_x1_y0_y1": list(DASHED["window"]),
+        "canvas": [0xEF, 0xC8, 0xC8],
+        "ops": [
+            {"kind": "stroke", "points": pts, "width": 7.0, "color": [0x99, 0x99, 0x99], "opacity": 1.0, "cap": "round",
+             "use_caps_for_dashes": True},
+            {"kind": "stroke", "points": pts, "width": 6.0, "color": [255, 255, 255], "opacity": 1.0, "cap": "round",
+             "use_caps_for_dashes": True},
+            {"kind": "stroke", "points": pts, "width": 6.0, "color": [0xEF, 0xA9, 0xA9], "opacity": 0.5, "cap": "round",
+             "dashes": [6.0, 8.0], "use_caps_for_dashes": True},
+        ],
+        "mask_rows": ["".join("1" if v else "0" for v in row) for row in dmask],
+        "expected_rgb": tile00[y0 : y1 + 1, x0 : x1 + 1].tolist(),
+    }
+
+    im17 = np.array(Image.open("/root/reference/tests/rendered/17_expected.png").convert("RGB"))
+    tile17 = im17[3 * 256 : 4 * 256, 1 * 256 : 2 * 256]
+    x0, x1, y0, y1 = BUILDING["window"]
+    ring = [list(p) for p in BUILDING["ring"]]
+    building = {
+        "source": "tests/rendered/17_expected.png, mosaic tile (col 1, row 3), tile-relative pixel coordinates",
+        "window_x0_x1_y0_y1": list(BUILDING["window"]),
+        "canvas": [0xF1, 0xEE, 0xE8],
+        "ops": [
+            {"kind": "fill", "ring": ring, "color": [0xBC, 0xA9, 0xA9], "opacity": 0.9},
+            {"kind": "stroke", "points": ring, "width": 0.2, "color": [0x33, 0x00, 0x66], "opacity": 1.0, "cap": "none"},
+        ],
+        "mask_rows": ["1" * (x1 - x0 + 1) for _ in range(y0, y1 + 1)],
+        "expected_rgb": tile17[y0 : y1 + 1, x0 : x1 + 1].tolist(),
+    }
+
     x0, x1, y0, y1 = WOOD["window"]
     green = (tile[y0 : y1 + 1, x0 : x1 + 1] == np.array([174, 209, 160])).all(-1)
     wood = {
@@ -76,10 +134,10 @@ def main():
         "fill_rgb": [174, 209, 160],
         "expected_fill_mask_rows": ["".join("1" if v else "0" for v in row) for row in green],
     }
-    out = {"_provenance": __doc__, "stub": stub, "wood": wood}
-    with open(os.path.join(HERE, "ref_z18_patches.json"), "w") as f:
+    out = {"_provenance": __doc__, "stub": stub, "dashed": dashed, "building": building, "wood": wood}
+    with open(os.path.join(HERE, "ref_golden_patches.json"), "w") as f:
         json.dump(out, f)
-    print("stub mask px", int(mask.sum()), "wood px", int(green.sum()))
+    print("stub mask px", int(mask.sum()), "dashed mask px", int(dmask.sum()), "wood px", int(green.sum()))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Pins against the reference's REAL output: crops of its golden image
-tests/rendered/18_expected.png (committed as data in tests/golden/ref_z18_patches.json, made by
+tests/rendered/18_expected.png (committed as data in tests/golden/ref_golden_patches.json, made by
 tests/golden/make_ref_patches.py) must be reproduced pixel-exactly
   - by the CPU oracle (this is what pins the oracle's stroke / cap / blend / u8 / fill rules), and
   - by the HIP path through the C ABI (GPU vs the reference's own pixels, no oracle in between)."""
@@ -12,31 +12,41 @@ import pytest
 from osm_renderer_amd import abi
 from osm_renderer_amd.display_list import TileBuilder
 
-FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_z18_patches.json")))
+FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_golden_patches.json")))
 CAP = {"none": abi.CAP_NONE, "butt": abi.CAP_BUTT, "round": abi.CAP_ROUND, "square": abi.CAP_SQUARE}
 
 
 def _display_list(patch):
-    tb = TileBuilder(zoom=18, scale=1, canvas=tuple(patch["canvas"]))
+    tb = TileBuilder(zoom=18, scale=1, canvas=tuple(patch["canvas"]))  # zoom is irrelevant for integer points
     for op in patch["ops"]:
         if op["kind"] == "stroke":
-            tb.stroke(op["points"], op["width"], tuple(op["color"]), op["opacity"], cap=CAP[op["cap"]])
+            tb.stroke(op["points"], op["width"], tuple(op["color"]), op["opacity"], dashes=op.get("dashes"),
+                      cap=CAP[op["cap"]], use_caps_for_dashes=op.get("use_caps_for_dashes", False))
         else:
             tb.fill(op["ring"], tuple(op["color"]), op["opacity"])
     return tb.build()
 
 
-def _check_stub(rgb):
-    p = FIX["stub"]
+def _check_masked(name, rgb, n_mask, min_cov, min_colours):
+    p = FIX[name]
     x0, x1, y0, y1 = p["window_x0_x1_y0_y1"]
     mask = np.array([[c == "1" for c in row] for row in p["mask_rows"]])
     want = np.array(p["expected_rgb"], dtype=np.uint8)
     got = rgb[y0 : y1 + 1, x0 : x1 + 1]
     diff = (got != want).any(-1) & mask
-    assert mask.sum() == 852 and diff.sum() == 0, f"{int(diff.sum())} of {int(mask.sum())} stub pixels differ from the reference golden"
-    # the patch is not trivial: hundreds of covered pixels, > 100 anti-aliased ones, 20+ distinct colours
+    assert mask.sum() == n_mask and diff.sum() == 0, f"{name}: {int(diff.sum())} of {int(mask.sum())} pixels differ from the reference golden"
+    # the patch is not trivial: many covered pixels, many distinct (anti-aliased / blended) colours
     cov = (want != np.array(p["canvas"], dtype=np.uint8)).any(-1) & mask
-    assert cov.sum() > 400 and len(np.unique(want[mask].reshape(-1, 3), axis=0)) >= 20
+    assert cov.sum() > min_cov and len(np.unique(want[mask].reshape(-1, 3), axis=0)) >= min_colours
+
+
+def _check_stub(rgb):
+    _check_masked("stub", rgb, 852, 400, 20)
+
+
+def _check_dashed(rgb):
+    # three generations, the last one a half-transparent round-capped dash pattern: 161 distinct colours
+    _check_masked("dashed", rgb, 1239, 700, 150)
 
 
 def _check_wood(rgb):
@@ -51,6 +61,30 @@ def _check_wood(rgb):
 
 def test_oracle_reproduces_reference_stroke_patch(oracle):
     _check_stub(oracle.render_job(_display_list(FIX["stub"]), 0)[..., :3])
+
+
+def test_oracle_reproduces_reference_dashed_patch(oracle):
+    """dash pattern + round caps for dashes (use_caps_for_dashes) + traveled distance + 0.5-opacity blend."""
+    _check_dashed(oracle.render_job(_display_list(FIX["dashed"]), 0)[..., :3])
+    q = json.loads(json.dumps(FIX["dashed"]))
+    for op in q["ops"]:
+        op["points"] = op["points"][::-1]  # the dash phase starts at the other end: must NOT match
+    with pytest.raises(AssertionError):
+        _check_dashed(oracle.render_job(_display_list(q), 0)[..., :3])
+
+
+def _check_building(rgb):
+    # translucent fill (0.9) + 0.2-px outline of a closed 8-vertex ring: every pixel of the window
+    _check_masked("building", rgb, 990, 500, 60)
+
+
+def test_oracle_reproduces_reference_building_patch(oracle):
+    """fill-opacity < 1 blend, thin (mul < 1) stroke on a closed multi-edge ring, fill/stroke pass order."""
+    _check_building(oracle.render_job(_display_list(FIX["building"]), 0)[..., :3])
+    q = json.loads(json.dumps(FIX["building"]))
+    q["ops"][1]["points"] = q["ops"][1]["points"][::-1]  # the stroke walk is direction sensitive
+    with pytest.raises(AssertionError):
+        _check_building(oracle.render_job(_display_list(q), 0)[..., :3])
 
 
 def test_oracle_reproduces_reference_fill_patch(oracle):
@@ -75,6 +109,6 @@ def test_stroke_patch_is_selective(oracle):
 
 @pytest.mark.gpu
 def test_gpu_reproduces_reference_patches(gpu_ctx):
-    for name, check in (("stub", _check_stub), ("wood", _check_wood)):
+    for name, check in (("stub", _check_stub), ("dashed", _check_dashed), ("building", _check_building), ("wood", _check_wood)):
         out = gpu_ctx.render_batch_host(_display_list(FIX[name]))
         check(out[0, :, :, :3])
