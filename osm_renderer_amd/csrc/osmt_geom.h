@@ -47,12 +47,15 @@ OSMT_HD int64_t osmt_ceil_div_pos(int64_t n, int64_t d) {
 /* floor(n / d) for 0 <= n < 2^24, d > 0 in 32-bit arithmetic: approximate quotient from the
  * f32 reciprocal (v_rcp_f32 on the GPU), then an exact integer remainder fix-up, so the result
  * does not depend on how good the approximation is. */
-OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) {
+OSMT_HD float osmt_rcp24(int32_t d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float r = __builtin_amdgcn_rcpf((float)d);
+    return __builtin_amdgcn_rcpf((float)d);
 #else
-    const float r = 1.0f / (float)d;
+    return 1.0f / (float)d;
 #endif
+}
+/* the same with the reciprocal of d supplied (several quotients share one divisor) */
+OSMT_HD int32_t osmt_udiv24r(int32_t n, int32_t d, float r) {
     int32_t q = (int32_t)((float)n * r);
     int32_t rem = n - q * d;
     /* |q - floor(n/d)| <= 1 for n < 2^24 (reciprocal and product are each within one f32
@@ -63,6 +66,11 @@ OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) {
         rem += (down - up) * d;
     }
     return q;
+}
+OSMT_HD int32_t osmt_udiv24(int32_t n, int32_t d) { return osmt_udiv24r(n, d, osmt_rcp24(d)); }
+OSMT_HD int32_t osmt_ceil_div_pos24r(int32_t n, int32_t d, float r) {
+    if (n <= 0) return 0;
+    return osmt_udiv24r(n + d - 1, d, r);
 }
 OSMT_HD int32_t osmt_ceil_div_pos24(int32_t n, int32_t d) {
     if (n <= 0) return 0;
@@ -240,8 +248,9 @@ OSMT_HD void osmt_stroke_step(int32_t a32, int32_t b32, int32_t k32, int32_t* c_
 /* Main perpendicular of step k only: c = corrections so far, pe = p_error (see osmt_stroke_step). */
 OSMT_HD void osmt_stroke_main(int32_t a, int32_t b, int32_t k, int32_t* c_out, int32_t* pe) {
     if (b < OSMT_STEP24_MAX_B) {
-        const int32_t c = osmt_ceil_div_pos24(2 * a * k - b, 2 * b);
-        const int32_t d = osmt_ceil_div_pos24(2 * a * c - b, 2 * b);
+        const float r2b = osmt_rcp24(2 * b); /* both quotients divide by 2b */
+        const int32_t c = osmt_ceil_div_pos24r(2 * a * k - b, 2 * b, r2b);
+        const int32_t d = osmt_ceil_div_pos24r(2 * a * c - b, 2 * b, r2b);
         *c_out = c;
         *pe = 2 * a * c - 2 * b * d;
     } else {
@@ -272,9 +281,10 @@ OSMT_HD int32_t osmt_extra_count(int32_t a, int32_t b, int32_t K) {
 }
 OSMT_HD void osmt_extra_event(int32_t a, int32_t b, int32_t m, int32_t* c_out, int32_t* k_out, int32_t* pe_out) {
     if (b < OSMT_STEP24_MAX_B) {
-        const int32_t c = osmt_udiv24(2 * b * m - b, 2 * a) + 1;
+        const float r2a = osmt_rcp24(2 * a); /* both quotients divide by 2a */
+        const int32_t c = osmt_udiv24r(2 * b * m - b, 2 * a, r2a) + 1;
         *c_out = c;
-        *k_out = osmt_udiv24(2 * b * c - b, 2 * a);
+        *k_out = osmt_udiv24r(2 * b * c - b, 2 * a, r2a);
         *pe_out = 2 * a * c - 2 * b * m;
     } else {
         const int64_t A = a, B = b, M = m;

@@ -52,13 +52,21 @@ struct osmt_stroke_aux {
     osmt_dash_table caps;
 };
 
+/* Everything k_raster needs to start on an op, in ONE 64-byte record (one s_load_dwordx16):
+ * the op header fields, the pre-pass results and the first ring (the only ring of every way),
+ * so the dependent-load chain per op is oplist -> opinfo -> points. */
 struct osmt_opinfo {
     int32_t x0, y0, x1, y1; /* inclusive extent of pixels the op can touch (empty: x0 > x1) */
-    uint32_t aux;           /* STROKE: index into the stroke_aux table */
+    uint32_t aux;           /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
     uint32_t n_edges;       /* total edges over all rings */
     int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its Bresenham centre */
     int32_t reach_major;    /* STROKE: the same along the segment's major axis only (tighter) */
+    uint8_t kind, cap, color[3], _pad[3]; /* osmt_op.kind / cap / color */
+    uint32_t n_rings, ring_off;           /* osmt_op.n_rings / ring_off */
+    osmt_ring ring0;                      /* rings[ring_off] when n_rings >= 1 */
+    double opacity;                       /* osmt_op.opacity */
 };
+static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record");
 
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
