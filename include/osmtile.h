@@ -185,6 +185,15 @@ int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas_rgba
 int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canvas_rgba[4], uint32_t n, uint32_t L,
                           uint32_t W, uint32_t H, void* d_out_rgba, void* stream);
 
+/* ---- PNG encoding of a rendered tile (host side) ------- */
+/* rgb_triples_to_png (src/draw/png_writer.rs:4-21), the tail of Drawer::draw_tile
+ * (drawer.rs:40-58): RGB8 PNG of an RGBA8 framebuffer tile (A dropped).  The reference's
+ * tests compare DECODED pixels only, so filter / compression choices are free.
+ * level: zlib 0..9 (other values: zlib default).  out_capacity >= osmt_png_bound(). */
+size_t osmt_png_bound(uint32_t width, uint32_t height);
+int osmt_encode_png(const uint8_t* rgba, uint32_t width, uint32_t height, size_t row_stride_bytes, int level,
+                    uint8_t* out_png, size_t out_capacity, size_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

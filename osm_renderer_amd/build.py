@@ -6,9 +6,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libosmtile.so")
-SOURCES = ["osmt_kernels.hip", "osmt_api.cpp"]
+SOURCES = ["osmt_kernels.hip", "osmt_api.cpp", "osmt_png.cpp"]
 HEADERS = ["osmt_geom.h", "osmt_internal.h", os.path.join("..", "..", "include", "osmtile.h")]
 # -ffp-contract=off: the reference never fuses a*b+c; its u8 output truncates, so an FMA flips pixels.
+LIBS = ["-lz"]  # zlib: PNG encoding of rendered tiles (osmt_png.cpp)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 
 
@@ -30,7 +31,7 @@ def needs_build():
 def build_variant(name, defines):
     """Experimental kernel variant: libosmtile_<name>.so built with extra -D flags (see tools/)."""
     out = os.path.join(HERE, f"libosmtile_{name}.so")
-    cmd = [_hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + LIBS
     subprocess.check_call(cmd)
     return out
 
@@ -38,7 +39,7 @@ def build_variant(name, defines):
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

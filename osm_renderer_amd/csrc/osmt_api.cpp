@@ -44,6 +44,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+/* error reporting for the other translation units of the library */
+int osmt_fail_public(int code, const char* msg) { return fail(code, "%s", msg); }
+
 struct osmt_ctx {
     int device = 0;
     std::mutex mu; /* guards the image registry */

@@ -163,3 +163,17 @@ class Context:
             )
         )
         return out
+
+
+def encode_png(rgba, level=-1):
+    """osmt_encode_png: RGB8 PNG bytes of one RGBA8 tile [H, W, 4] (png_writer.rs:4-21)."""
+    img = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w, four = img.shape
+    assert four == 4
+    L = load()
+    cap = L.osmt_png_bound(w, h)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t()
+    check(L.osmt_encode_png(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, w * 4, level,
+                            out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+    return out[: n.value].tobytes()
