@@ -76,6 +76,7 @@ struct osmt_scene {
     double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     uint32_t* d_submask = nullptr;
+    uint8_t* d_opnv = nullptr;
 };
 
 namespace {
@@ -164,7 +165,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
+                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
@@ -181,6 +182,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.den = sc->d_den;
         a.aux = sc->d_aux;
         a.submask = sc->d_submask;
+        a.opnv = sc->d_opnv;
         a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
         a.images = ctx->d_images;
         a.image_pool = ctx->d_image_pool;
@@ -300,6 +302,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
+    const size_t o_opnv = carve(b->n_ops + 4);
     s->bytes = off + 256;
     hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
@@ -320,6 +323,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
+    s->d_opnv = (uint8_t*)(s->d_base + o_opnv);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;

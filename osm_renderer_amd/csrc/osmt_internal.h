@@ -84,6 +84,8 @@ struct osmt_raster_args {
     const double* trav;
     const double* den; /* per edge (indexed by its first point): center_dist_denom = |p2 - p1| */
     const osmt_stroke_aux* aux;
+    const uint8_t* opnv;     /* per op: 0 = not a stroke; 1..64 = stroke with that many virtual segments
+                              * (edges + cap stubs, single ring); 255 = stroke that needs its own passes */
     const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
     uint32_t _pad0;
@@ -101,7 +103,8 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
                                       double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st);
+                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, uint32_t* submask, uint32_t sub_rows,
+                              hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);

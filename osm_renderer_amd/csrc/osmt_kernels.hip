@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                                                const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
                                                osmt_opinfo* __restrict__ info, double* __restrict__ trav,
                                                double* __restrict__ den, osmt_stroke_aux* __restrict__ aux,
-                                               uint32_t* __restrict__ submask,
+                                               uint8_t* __restrict__ opnv, uint32_t* __restrict__ submask,
                                                uint32_t sub_rows) {
     const uint32_t o = blockIdx.x * 64u + threadIdx.x;
     if (o >= n_ops) return;
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
     oi.aux = op_aux[o];
     oi.n_edges = 0;
     oi.reach_major = 0;
+    opnv[o] = 0;
     if (op.kind == OSMT_OP_NONE) {
         info[o] = oi;
         return;
@@ -250,6 +251,10 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                     mark_segment(sm, n_sub_x, n_sub_y, a.x, a.y, b.x, b.y, g);
                 }
             }
+        }
+        {
+            const uint32_t nv = n_edges + (caps ? 2u : 0u);
+            opnv[o] = (op.n_rings == 1u && nv <= 64u) ? (uint8_t)nv : (uint8_t)255;
         }
         osmt_stroke_aux* sa = &aux[oi.aux];
         sa->half_width = hw;
@@ -412,6 +417,7 @@ constexpr int ROWSTEP = NTHREADS / SUB;     /* rows between a thread's consecuti
 #define OSMT_V_ROWCAP 16
 #endif
 constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path */
+
 constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
 
 struct RowRec {
@@ -434,7 +440,8 @@ constexpr int SEGCAP = 64;
 
 struct RasterShared {
     SegRec seg[SEGCAP];
-    uint32_t seg_prefix[SEGCAP + 1];
+    uint8_t opnv[OPCHUNK];          /* g_opnv of the compacted list entries */
+    uint32_t grp_base[OPCHUNK + 1]; /* first virtual-segment lane of every list entry of a group */
     unsigned long long plane[NBUF][SUB * SUBH]; /* generation alpha planes (f64 bit patterns) */
     uint32_t mask[NBUF][SUBH];                  /* fill coverage per row */
     RowRec rec[SUBH][ROWCAP];
@@ -635,6 +642,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_op* OSMT_R g_ops,
     const osmt_opinfo* OSMT_R g_info, const osmt_ring* OSMT_R g_rings, const int2* OSMT_R g_pts,
     const double* OSMT_R g_trav, const double* OSMT_R g_den, const osmt_stroke_aux* OSMT_R g_aux,
+    const uint8_t* OSMT_R g_opnv,
     const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
     const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
     size_t g_out_tile_stride) {
@@ -695,8 +703,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         /* ---- ordered compaction of the ops whose extent touches this sub-tile ---- */
         const uint32_t oi_idx = base + tid;
         bool hit = false;
-        if (oi_idx < job.n_ops)
+        uint32_t my_nv = 0;
+        if (oi_idx < job.n_ops) {
             hit = (g_submask[(size_t)(job.op_off + oi_idx) * g_sub_rows + sub_y] >> sub_x) & 1u;
+            if (hit) my_nv = g_opnv[job.op_off + oi_idx];
+        }
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) sh.wcount[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -707,11 +718,49 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             if (w < wave) off += cnt;
             total += cnt;
         }
-        if (hit) sh.oplist[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = oi_idx;
+        if (hit) {
+            const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            sh.oplist[pos] = oi_idx;
+            sh.opnv[pos] = (uint8_t)my_nv;
+        }
+        const bool any_stroke = __ballot(hit && my_nv != 0u) != 0ull;
         __syncthreads();
         total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
 
-        for (uint32_t li = 0; li < total; ++li) {
+        uint32_t g0 = 0;
+        while (g0 < total) {
+        /* ---- group = consecutive list entries whose stroke segments (edges + cap stubs) fit in the
+         * 64 lanes of ONE record pass; a stroke op with more segments (or several rings) forms a
+         * group of its own and takes the chunked per-op path below ------------------------------ */
+        uint32_t gend = g0, V = 0;
+        bool big = false;
+        if (!any_stroke) {
+            gend = total; /* fills only: one group, nothing to lay out */
+        } else {
+            for (; gend < total; ++gend) {
+                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.opnv[gend]);
+                if (nv > 64u) {
+                    if (gend == g0) {
+                        big = true;
+                        ++gend;
+                    }
+                    break;
+                }
+                if (V + nv > 64u) break;
+                if (lane == 0) sh.grp_base[gend - g0] = V;
+                V += nv;
+            }
+            if (lane == 0) sh.grp_base[gend - g0] = V;
+            __syncthreads();
+        }
+        /* A normal group's records are produced by ONE pass (at its first stroke op) in which lane
+         * -> (list entry, virtual segment) through grp_base; a big op runs one pass per 64 of its
+         * own virtual segments.  Same code, one call site. */
+        unsigned long long gbal = 0ull;
+        uint32_t gincl = 0;
+        bool records_ready = false;
+
+        for (uint32_t li = g0; li < gend; ++li) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
             const osmt_op* __restrict__ op = &g_ops[o];
             const uint32_t kind = op->kind;
@@ -722,69 +771,100 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const bool plain_main = sa->main.n_segs == 0;
                 const double initial_opacity = op->opacity;
                 const int32_t reach = oi->reach;
-                const int32_t reach_major = oi->reach_major;
-                const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
                 unsigned long long* plane = sh.plane[buf];
-                const uint32_t n_edges = oi->n_edges;
-                uint32_t e_base = 0;
-                for (uint32_t r = 0; r < op->n_rings; ++r) {
-                    const osmt_ring ring = g_rings[op->ring_off + r];
-                    if (ring.n_pts < 2) continue;
-                    const uint32_t ne = ring.n_pts - 1;
-                    /* virtual segments of this ring: its edges, and after the last edge of the op
-                     * the two cap stubs precomputed by k_opinfo (line.rs:33-57) */
-                    const uint32_t nv = ne + ((has_caps && e_base + ne == n_edges) ? 2u : 0u);
-                    for (uint32_t cb = 0; cb < nv; cb += 64u) {
-                        /* ---- one lane per virtual segment: cull, item ranges, record ------------- */
-                        const uint32_t v = cb + lane;
+                const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
+                const uint32_t nv_op = oi->n_edges + (has_caps ? 2u : 0u);
+                const uint32_t n_rounds = big ? (nv_op + 63u) / 64u : 1u;
+                for (uint32_t round = 0; round < n_rounds; ++round) {
+                    if (big || !records_ready) {
+                        /* ---- record pass: one lane per virtual segment (an edge, or one of the two cap
+                         * stubs precomputed by k_opinfo, line.rs:33-57): cull, item ranges, record ---- */
+                        if (big) __syncthreads(); /* previous round's records are consumed */
                         SegRec rec;
                         rec.count = 0;
                         rec.p1x = rec.p1y = rec.p2x = rec.p2y = 0;
                         rec.traveled = 0.0;
                         rec.denom = 1.0;
                         rec.caps_table = 0u;
-                        bool live = false;
-                        if (v < ne) {
-                            const int2 p1 = g_pts[ring.first_pt + v];
-                            const int2 p2 = g_pts[ring.first_pt + v + 1];
-                            rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
-                            rec.traveled = g_trav[ring.first_pt + v];
-                            rec.denom = g_den[ring.first_pt + v];
-                            live = true;
-                        } else if (v < nv) {
-                            const osmt_cap_seg cs = sa->cap_seg[v - ne];
-                            rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
-                            rec.denom = cs.denom;
-                            rec.caps_table = 1u;
-                            live = cs.valid != 0;
+                        uint32_t lo = o, v = round * 64u + lane; /* big: this op, its round-th 64 segments */
+                        bool valid = v < nv_op;
+                        if (!big) {
+                            valid = lane < V;
+                            uint32_t j = 0;
+                            const uint32_t gn = gend - g0;
+                            while (j + 1u < gn && sh.grp_base[j + 1u] <= lane) ++j; /* last entry with base <= lane */
+                            lo = job.op_off + sh.oplist[g0 + j];
+                            v = lane - sh.grp_base[j];
                         }
-                        if (live) rec.count = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, reach, reach_major, rc, &rec);
-                        const unsigned long long bal = __ballot(rec.count > 0u);
-                        const uint32_t m = (uint32_t)__popcll(bal);
-                        if (m == 0u) continue; /* wave-uniform */
-                        const uint32_t slot = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                        if (rec.count > 0u) sh.seg[slot] = rec;
-                        /* exclusive prefix of the item counts of the compacted records */
-                        uint32_t incl = rec.count;
+                        if (valid) {
+                            const osmt_opinfo loi = g_info[lo];
+                            const osmt_op* lop = &g_ops[lo];
+                            const uint32_t ne_all = loi.n_edges;
+                            bool live = false;
+                            if (v < ne_all) {
+                                /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
+                                uint32_t r = 0, e = v;
+                                osmt_ring ring = g_rings[lop->ring_off];
+                                while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < lop->n_rings) {
+                                    if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
+                                    ring = g_rings[lop->ring_off + ++r];
+                                }
+                                const int2 p1 = g_pts[ring.first_pt + e];
+                                const int2 p2 = g_pts[ring.first_pt + e + 1];
+                                rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
+                                rec.traveled = g_trav[ring.first_pt + e];
+                                rec.denom = g_den[ring.first_pt + e];
+                                live = true;
+                            } else {
+                                const osmt_cap_seg cs = g_aux[loi.aux].cap_seg[v - ne_all];
+                                rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
+                                rec.denom = cs.denom;
+                                rec.caps_table = 1u;
+                                live = cs.valid != 0;
+                            }
+                            if (live)
+                                rec.count = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, loi.reach, loi.reach_major, rc, &rec);
+                        }
+                        gbal = __ballot(rec.count > 0u);
+                        if (rec.count > 0u) sh.seg[__popcll(gbal & ((1ull << lane) - 1ull))] = rec;
+                        gincl = rec.count; /* inclusive prefix of the item counts over the lanes */
 #pragma unroll
                         for (uint32_t d = 1; d < 64u; d <<= 1) {
-                            const uint32_t y = __shfl_up(incl, d);
-                            if (lane >= d) incl += y;
+                            const uint32_t y = __shfl_up(gincl, d);
+                            if (lane >= d) gincl += y;
                         }
-                        if (rec.count > 0u) sh.seg_prefix[slot + 1] = incl;
-                        if (lane == 0) sh.seg_prefix[0] = 0u;
-                        const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63));
+                        records_ready = true;
                         __syncthreads();
-                        /* ---- all (record, item) pairs of this chunk, lanes packed --------------------- */
-                        for (uint32_t it = lane; it < total_items; it += 64u) {
-                            uint32_t j = 0;
-                            while (it >= sh.seg_prefix[j + 1]) ++j;
-                            const SegRec q = sh.seg[j];
-                            walk_item(q, it - sh.seg_prefix[j], plain_main, sa, initial_opacity, reach, rc, plane);
-                        }
-                        __syncthreads(); /* records are rewritten by the next chunk */
                     }
-                    e_base += ne;
+                    /* the op's records are lanes [va, vb) of the record pass */
+                    uint32_t va = 0, vb = min(64u, nv_op - round * 64u);
+                    if (!big) {
+                        va = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0]);
+                        vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0 + 1u]);
+                    }
+                    if (vb > va) {
+                        const unsigned long long lanes_ab =
+                            ((vb >= 64u) ? ~0ull : ((1ull << vb) - 1ull)) & ~((1ull << va) - 1ull);
+                        const unsigned long long mask = gbal & lanes_ab;
+                        const uint32_t item_lo = va ? (uint32_t)__builtin_amdgcn_readlane((int)gincl, (int)va - 1) : 0u;
+                        const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readlane((int)gincl, (int)vb - 1);
+                        const uint32_t slot0 = (uint32_t)__popcll(gbal & ((1ull << va) - 1ull));
+                        /* all (record, item) pairs of this op, lanes packed */
+                        for (uint32_t it = item_lo + lane; it < item_hi; it += 64u) {
+                            /* record of item `it`: walk the (wave-uniform) record lanes of this op and
+                             * compare with each one's inclusive item prefix, read with v_readlane */
+                            uint32_t j = slot0, base_items = item_lo;
+                            for (unsigned long long rem = mask; rem != 0ull; rem &= rem - 1ull) {
+                                const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)gincl, __builtin_ctzll(rem));
+                                if (it >= pv) {
+                                    ++j;
+                                    base_items = pv;
+                                }
+                            }
+                            const SegRec q = sh.seg[j];
+                            walk_item(q, it - base_items, plain_main, sa, initial_opacity, reach, rc, plane);
+                        }
+                    }
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
@@ -945,6 +1025,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 buf = (buf + 1u) % NBUF;
             }
         }
+        __syncthreads(); /* the group's records / bases are rewritten by the next group */
+        g0 = gend;
+        }
         __syncthreads(); /* oplist is rewritten by the next chunk */
     }
 
@@ -1064,10 +1147,11 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
 
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
+                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, uint32_t* submask, uint32_t sub_rows,
+                              hipStream_t st) {
     if (n_ops == 0) return hipSuccess;
     hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
-                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, submask, sub_rows);
+                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, opnv, submask, sub_rows);
     return hipGetLastError();
 }
 
@@ -1079,11 +1163,11 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const dim3 grid(groups * 8u * nsub);
     if (out_f64)
         hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.den, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.pts, a.trav, a.den, a.aux, a.opnv, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
                            a.out_tile_stride);
     else
         hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.den, a.aux, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
+                           a.pts, a.trav, a.den, a.aux, a.opnv, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
                            a.out_tile_stride);
     return hipGetLastError();
 }
