@@ -31,13 +31,9 @@ __device__ __forceinline__ int32_t f64_as_i32(double v) {
     if (v <= -2147483648.0) return INT32_MIN;
     return (int32_t)v;
 }
-/* Rust `f64 as u8` */
-__device__ __forceinline__ uint32_t f64_as_u8(double v) {
-    if (v != v) return 0u;
-    if (v >= 255.0) return 255u;
-    if (v <= 0.0) return 0u;
-    return (uint32_t)(int32_t)v;
-}
+/* Rust `f64 as u8`: truncation, saturating, NaN -> 0.  fmax(NaN, 0) == 0 (maxNum), so the clamp
+ * covers every case in two instructions before the conversion. */
+__device__ __forceinline__ uint32_t f64_as_u8(double v) { return (uint32_t)(int32_t)fmin(fmax(v, 0.0), 255.0); }
 
 /* ------------------------------------------------------------------------- */
 /* tile.rs:88-106 + point.rs:11-19 */
@@ -694,7 +690,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             acc[j][2] = bl;
         }
     }
-    for (uint32_t i = tid; i < NBUF * SUB * SUBH; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
+    bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
     if (tid < SUBH) sh.rowcnt[tid] = 0u;
     __syncthreads();
 
@@ -724,6 +720,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             sh.opnv[pos] = (uint8_t)my_nv;
         }
         const bool any_stroke = __ballot(hit && my_nv != 0u) != 0ull;
+        if (any_stroke && !plane_clean) {
+            for (uint32_t i = tid; i < NBUF * SUB * SUBH; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
+            plane_clean = true;
+        }
         __syncthreads();
         total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
 
