@@ -116,7 +116,7 @@ int validate_batch(const osmt_batch* b) {
     }
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
-        if (job.zoom > 22) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u too large", j, job.zoom);
+        if (job.zoom > OSMT_MAX_ZOOM) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u > MAX_ZOOM (src/tile.rs:5)", j, job.zoom);
         if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
         if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
         for (uint32_t k = 0; k < job.n_ops; ++k) {
