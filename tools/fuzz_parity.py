@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Randomised GPU-vs-oracle differential fuzzing beyond the pytest suite (run on a GPU box).
+
+    python tools/fuzz_parity.py [seconds] [seed]
+
+Random tiles with adversarial parameters: widths 0..40, all directions, tiny / huge dashes, every
+cap, use_caps_for_dashes, scales 1..3, far-away and huge coordinates, self-intersecting and
+multi-ring fills, many ops.  Any differing pixel is printed with the op that was drawn last."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from osm_renderer_amd import abi, display_list
+from osm_renderer_amd.display_list import TileBuilder
+from osm_renderer_amd.renderer import Context
+from oracle import oracle_py as O
+
+CAPS = [abi.CAP_NONE, abi.CAP_BUTT, abi.CAP_ROUND, abi.CAP_SQUARE]
+rnd = None
+
+
+def rand_pts(n, W, spread):
+    mode = rnd.integers(0, 5)
+    p0 = rnd.integers(-40, W + 40, size=2)
+    if mode == 0:  # far away / huge
+        p0 = rnd.integers(-200000, 200000, size=2)
+        spread = int(rnd.choice([50, 3000, 400000]))
+    steps = rnd.integers(-spread, spread + 1, size=(n, 2))
+    if mode == 1:  # axis aligned
+        steps[:, rnd.integers(0, 2)] = 0
+    if mode == 2:  # exact diagonals / repeats
+        steps[:, 1] = steps[:, 0] * rnd.choice([-1, 1])
+        steps[rnd.integers(0, n)] = 0
+    return (p0 + np.cumsum(steps, axis=0)).tolist()
+
+
+def make_tile(scale):
+    W = 256 * scale
+    tb = TileBuilder(scale=scale, canvas=None if rnd.random() < 0.2 else tuple(rnd.integers(0, 256, size=3)))
+    for _ in range(int(rnd.integers(1, 40))):
+        kind = rnd.random()
+        col = tuple(rnd.integers(0, 256, size=3))
+        op = float(rnd.choice([1.0, 1.0, 0.5, 0.25, 0.9, 0.0, 1.0 / 3.0]))
+        if kind < 0.4:
+            rings = [rand_pts(int(rnd.integers(2, 14)), W, int(rnd.choice([8, 40, 120]))) for _ in range(int(rnd.integers(1, 4)))]
+            for r in rings:
+                if rnd.random() < 0.8:
+                    r.append(r[0])
+            tb.fill(rings, col, op)
+        elif kind < 0.45:
+            tb.nop()
+        else:
+            d = None
+            if rnd.random() < 0.5:
+                nd = int(rnd.integers(1, 7))
+                d = [float(rnd.choice([0.3, 1.0, 2.0, 3.0, 5.5, 8.0, 13.0, 40.0])) * scale for _ in range(nd)]
+            w = float(rnd.choice([0.0, 0.05, 0.2, 0.5, 0.99, 1.0, 1.01, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 12.5, 25.0, 40.0])) * scale
+            tb.stroke(rand_pts(int(rnd.integers(2, 9)), W, int(rnd.choice([3, 30, 90, 300]))), w, col, op, dashes=d,
+                      cap=CAPS[int(rnd.integers(0, 4))], use_caps_for_dashes=bool(rnd.integers(0, 2)))
+    return tb.build()
+
+
+def run(budget=60.0, seed=1, ctx=None, dump=True):
+    """Fuzz for `budget` seconds; returns (tiles rendered, mismatching tiles)."""
+    global rnd
+    rnd = np.random.default_rng(seed)
+    ctx = ctx or Context(0)
+    t0 = time.time()
+    n_tiles = n_bad = 0
+    while time.time() - t0 < budget:
+        scale = int(rnd.choice([1, 1, 2, 3]))
+        tiles = [make_tile(scale) for _ in range(12)]
+        dl = display_list.concat(tiles)
+        got = ctx.render_batch_host(dl)
+        want = O.render_batch(dl, threads=12)
+        n_tiles += len(tiles)
+        if not np.array_equal(got, want):
+            for i in range(len(tiles)):
+                if not np.array_equal(got[i], want[i]):
+                    n_bad += 1
+                    ys, xs = np.nonzero((got[i] != want[i]).any(-1))
+                    print(f"MISMATCH seed={seed} tile#{n_tiles - len(tiles) + i} scale={scale}: {len(ys)} px, first at x={xs[0]} y={ys[0]} "
+                          f"gpu={got[i][ys[0], xs[0]].tolist()} oracle={want[i][ys[0], xs[0]].tolist()}")
+                    if not dump:
+                    continue
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_ops.npy", tiles[i].ops)
+                    np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_coords.npy", tiles[i].coords)
+                    np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_dashes.npy", tiles[i].dashes)
+                    np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_rings.npy", tiles[i].rings)
+    print(f"fuzz: {n_tiles} tiles in {time.time() - t0:.0f} s, {n_bad} mismatching tiles (seed {seed})")
+    return n_tiles, n_bad
+
+
+if __name__ == "__main__":
+    _, bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sys.exit(1 if bad else 0)
