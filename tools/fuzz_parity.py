@@ -81,9 +81,9 @@ def run(budget=60.0, seed=1, ctx=None, dump=True):
                     print(f"MISMATCH seed={seed} tile#{n_tiles - len(tiles) + i} scale={scale}: {len(ys)} px, first at x={xs[0]} y={ys[0]} "
                           f"gpu={got[i][ys[0], xs[0]].tolist()} oracle={want[i][ys[0], xs[0]].tolist()}")
                     if not dump:
-                    continue
-                os.makedirs("gpurun_out", exist_ok=True)
-                np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_ops.npy", tiles[i].ops)
+                        continue
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_ops.npy", tiles[i].ops)
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_coords.npy", tiles[i].coords)
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_dashes.npy", tiles[i].dashes)
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_rings.npy", tiles[i].rings)
