@@ -1,0 +1,13 @@
+"""A short run of the randomised differential fuzzer (tools/fuzz_parity.py): adversarial widths, dashes,
+caps, directions, huge coordinates, multi-ring fills, scales 1..3 — GPU vs oracle, bit-exact.
+(Round 1: 1560 tiles over two longer runs, 0 mismatches.)"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fuzz_short(gpu_ctx, oracle):
+    from tools import fuzz_parity
+
+    tiles, bad = fuzz_parity.run(budget=8.0, seed=2026, ctx=gpu_ctx, dump=False)
+    assert tiles >= 12 and bad == 0
