@@ -60,7 +60,7 @@ struct osmt_ctx {
 struct osmt_scene {
     osmt_ctx* ctx = nullptr;
     uint32_t n_jobs = 0, n_ops = 0, n_rings = 0, n_pts = 0, n_dashes = 0, n_strokes = 0;
-    uint32_t scale = 1, coord_kind = 0;
+    uint32_t scale = 1, coord_kind = 0, n_blk = 0;
     char* d_base = nullptr; /* one allocation, carved below */
     size_t bytes = 0;
     osmt_tile_job* d_jobs = nullptr;
@@ -77,6 +77,8 @@ struct osmt_scene {
     osmt_stroke_aux* d_aux = nullptr;
     uint32_t* d_submask = nullptr;
     uint8_t* d_opnv = nullptr;
+    uint32_t* d_op_blk = nullptr;
+    osmt_blk_bbox* d_blk = nullptr;
 };
 
 namespace {
@@ -165,7 +167,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
+                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_op_blk, sc->d_blk, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
@@ -183,6 +185,9 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.aux = sc->d_aux;
         a.submask = sc->d_submask;
         a.opnv = sc->d_opnv;
+        a.op_blk = sc->d_op_blk;
+        a.blk = sc->d_blk;
+        a.has_blocks = sc->n_blk > 0 ? 1u : 0u;
         a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
         a.images = ctx->d_images;
         a.image_pool = ctx->d_image_pool;
@@ -260,13 +265,27 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     HIP_TRY(hipSetDevice(ctx->device));
 
     /* host-side index tables: point -> job (for projection), op -> stroke slot */
-    std::vector<uint32_t> pt_job(b->n_pts, 0xFFFFFFFFu), op_aux(b->n_ops, 0u);
+    std::vector<uint32_t> pt_job(b->n_pts, 0xFFFFFFFFu), op_aux(b->n_ops, 0u), op_blk(b->n_ops, 0xFFFFFFFFu);
     uint32_t n_strokes = 0;
+    size_t n_blk = 0; /* 64-edge blocks of the ops with more than 64 edges */
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
         for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
-        for (uint32_t k = 0; k < job.n_ops; ++k)
-            if (b->ops[job.op_off + k].kind == OSMT_OP_STROKE) op_aux[job.op_off + k] = n_strokes++;
+        for (uint32_t k = 0; k < job.n_ops; ++k) {
+            const osmt_op& op = b->ops[job.op_off + k];
+            if (op.kind == OSMT_OP_STROKE) op_aux[job.op_off + k] = n_strokes++;
+            if (op.kind != OSMT_OP_NONE) {
+                size_t ne = 0;
+                for (uint32_t r = 0; r < op.n_rings; ++r) {
+                    const uint32_t np = b->rings[op.ring_off + r].n_pts;
+                    if (np >= 2) ne += np - 1;
+                }
+                if (ne > 64 && n_blk + (ne + 63) / 64 < 0xFFFFFFFFull) {
+                    op_blk[job.op_off + k] = (uint32_t)n_blk;
+                    n_blk += (ne + 63) / 64;
+                }
+            }
+        }
     }
 
     osmt_scene* s = new (std::nothrow) osmt_scene();
@@ -278,6 +297,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->n_pts = (uint32_t)b->n_pts;
     s->n_dashes = (uint32_t)b->n_dashes;
     s->n_strokes = n_strokes;
+    s->n_blk = (uint32_t)n_blk;
     s->scale = b->scale;
     s->coord_kind = b->coord_kind;
 
@@ -303,6 +323,8 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_opnv = carve(b->n_ops + 4);
+    const size_t o_opblk = carve(b->n_ops * 4);
+    const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     s->bytes = off + 256;
     hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
@@ -324,6 +346,8 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
     s->d_opnv = (uint8_t*)(s->d_base + o_opnv);
+    s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
+    s->d_blk = (osmt_blk_bbox*)(s->d_base + o_blk);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
@@ -338,6 +362,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
     if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
+    if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err != hipSuccess) {
         (void)hipFree(s->d_base);
         delete s;

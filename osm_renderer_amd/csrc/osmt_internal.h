@@ -68,6 +68,13 @@ struct osmt_opinfo {
 };
 static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record");
 
+/* Ops with more than 64 edges get one bounding box per block of 64 consecutive edges (running
+ * edge index over all rings): k_raster skips whole blocks that cannot touch its sub-tile, so a
+ * 2000-vertex way costs a sub-tile a few blocks, not 2000 edge tests. */
+struct osmt_blk_bbox {
+    int32_t x0, y0, x1, y1; /* over the end points of the block's edges (empty block: x0 > x1) */
+};
+
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
     uint32_t width, height;
@@ -84,11 +91,13 @@ struct osmt_raster_args {
     const double* trav;
     const double* den; /* per edge (indexed by its first point): center_dist_denom = |p2 - p1| */
     const osmt_stroke_aux* aux;
+    const uint32_t* op_blk;  /* per op: first entry in `blk` (0xFFFFFFFF: op has <= 64 edges, no blocks) */
+    const osmt_blk_bbox* blk;
     const uint8_t* opnv;     /* per op: 0 = not a stroke; 1..64 = stroke with that many virtual segments
                               * (edges + cap stubs, single ring); 255 = stroke that needs its own passes */
     const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
-    uint32_t _pad0;
+    uint32_t has_blocks;     /* some op has more than 64 edges: use the block-culling instantiation */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -103,8 +112,8 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
                                       double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, uint32_t* submask, uint32_t sub_rows,
-                              hipStream_t st);
+                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
+                              uint32_t* submask, uint32_t sub_rows, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);

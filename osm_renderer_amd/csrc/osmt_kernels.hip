@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                                                const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
                                                osmt_opinfo* __restrict__ info, double* __restrict__ trav,
                                                double* __restrict__ den, osmt_stroke_aux* __restrict__ aux,
-                                               uint8_t* __restrict__ opnv, uint32_t* __restrict__ submask,
+                                               uint8_t* __restrict__ opnv, const uint32_t* __restrict__ op_blk,
+                                               osmt_blk_bbox* __restrict__ blk, uint32_t* __restrict__ submask,
                                                uint32_t sub_rows) {
     const uint32_t o = blockIdx.x * 64u + threadIdx.x;
     if (o >= n_ops) return;
@@ -185,11 +186,27 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
     }
     double traveled = 0.0;
     uint32_t n_edges = 0;
+    /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
+    const uint32_t blk_off = op_blk[o];
+    uint32_t cur_blk = 0xFFFFFFFFu;
+    osmt_blk_bbox bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
     for (uint32_t r = 0; r < op.n_rings; ++r) {
         const osmt_ring ring = rings[op.ring_off + r];
         int2 prev = make_int2(0, 0);
         for (uint32_t i = 0; i < ring.n_pts; ++i) {
             const int2 p = pts[ring.first_pt + i];
+            if (blk_off != 0xFFFFFFFFu && i > 0) {
+                const uint32_t b_ = (n_edges + i - 1u) >> 6; /* running edge index / 64 */
+                if (b_ != cur_blk) {
+                    if (cur_blk != 0xFFFFFFFFu) blk[blk_off + cur_blk] = bb;
+                    cur_blk = b_;
+                    bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
+                }
+                bb.x0 = min(bb.x0, min(prev.x, p.x));
+                bb.y0 = min(bb.y0, min(prev.y, p.y));
+                bb.x1 = max(bb.x1, max(prev.x, p.x));
+                bb.y1 = max(bb.y1, max(prev.y, p.y));
+            }
             oi.x0 = min(oi.x0, p.x);
             oi.x1 = max(oi.x1, p.x);
             oi.y0 = min(oi.y0, p.y);
@@ -208,6 +225,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         }
         if (ring.n_pts >= 2) n_edges += ring.n_pts - 1;
     }
+    if (cur_blk != 0xFFFFFFFFu) blk[blk_off + cur_blk] = bb;
     oi.n_edges = n_edges;
     if (op.kind == OSMT_OP_STROKE) {
         const double hw = op.width / 2.0;
@@ -631,14 +649,16 @@ __device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const
 #define OSMT_R __restrict__
 #endif
 
-template <bool OUT_F64>
+/* BLOCKS: the scene has ops with more than 64 edges (osmt_blk_bbox culling compiled in); scenes
+ * made of short ways only (all named configs) run the leaner instantiation. */
+template <bool OUT_F64, bool BLOCKS>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* separate __restrict__ const pointers (not a struct): lets the compiler prove the display
      * list is read-only and fetch wave-uniform records with scalar loads */
     const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_op* OSMT_R g_ops,
     const osmt_opinfo* OSMT_R g_info, const osmt_ring* OSMT_R g_rings, const int2* OSMT_R g_pts,
     const double* OSMT_R g_trav, const double* OSMT_R g_den, const osmt_stroke_aux* OSMT_R g_aux,
-    const uint8_t* OSMT_R g_opnv,
+    const uint8_t* OSMT_R g_opnv, const uint32_t* OSMT_R g_op_blk, const osmt_blk_bbox* OSMT_R g_blk,
     const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
     const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
     size_t g_out_tile_stride) {
@@ -775,7 +795,15 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
                 const uint32_t nv_op = oi->n_edges + (has_caps ? 2u : 0u);
                 const uint32_t n_rounds = big ? (nv_op + 63u) / 64u : 1u;
+                const uint32_t blk_off = (BLOCKS && big) ? g_op_blk[o] : 0xFFFFFFFFu;
                 for (uint32_t round = 0; round < n_rounds; ++round) {
+                    if (blk_off != 0xFFFFFFFFu && (round + 1u) * 64u <= oi->n_edges) {
+                        /* a round made of edges only (the cap stubs live in the last round): skip it when
+                         * the block's box, grown by the reach of a run, misses the sub-tile */
+                        const osmt_blk_bbox bb = g_blk[blk_off + round];
+                        if (bb.x1 + reach < rc.x0 || bb.x0 - reach > rc.x1 || bb.y1 + reach < rc.y0 || bb.y0 - reach > rc.y1)
+                            continue;
+                    }
                     if (big || !records_ready) {
                         /* ---- record pass: one lane per virtual segment (an edge, or one of the two cap
                          * stubs precomputed by k_opinfo, line.rs:33-57): cull, item ranges, record ---- */
@@ -885,24 +913,47 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 buf = (buf + 1u) % NBUF;
             } else {
                 /* ---------------- fill_contour (fill.rs:16-47) ---------------- */
-                /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row */
+                /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row.  Ops
+                 * with more than 64 edges are walked block by block (64 running edge indices), skipping
+                 * the blocks whose rows cannot meet the sub-tile's rows (x does not matter: crossings
+                 * left or right of the sub-tile still decide the parity). */
+                /* only ops with more than 64 edges have blocks: do not even load the offset for a
+                 * single short ring (every polygon of the named configs) */
+                const bool maybe_long = BLOCKS && (op->n_rings > 1u || g_rings[op->ring_off].n_pts > 65u);
+                const uint32_t fblk_off = maybe_long ? g_op_blk[o] : 0xFFFFFFFFu;
                 uint32_t e_base = 0;
                 for (uint32_t r = 0; r < op->n_rings; ++r) {
                     const osmt_ring ring = g_rings[op->ring_off + r];
                     if (ring.n_pts < 2) continue;
                     const uint32_t ne = ring.n_pts - 1;
-                    const uint32_t n_items = ne * SUBH;
-                    for (uint32_t it = tid; it < n_items; it += NTHREADS) {
-                        const uint32_t e = it / SUBH, row = it % SUBH;
-                        const int2 p1 = g_pts[ring.first_pt + e];
-                        const int2 p2 = g_pts[ring.first_pt + e + 1];
-                        int32_t xmn, xmx;
-                        if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx)) {
-                            const uint32_t slot = atomicAdd(&sh.rowcnt[row], 1u);
-                            if (slot < ROWCAP) {
-                                sh.rec[row][slot].x_min = xmn;
-                                sh.rec[row][slot].x_max = xmx;
-                                sh.rec[row][slot].edge = e_base + e;
+                    /* pieces of this ring: the whole ring (short ops), or its intersections with the
+                     * 64-edge blocks that can meet this sub-tile's rows (long ops) */
+                    uint32_t b_first = 0, b_last = 0;
+                    if (BLOCKS && fblk_off != 0xFFFFFFFFu) {
+                        b_first = e_base >> 6;
+                        b_last = (e_base + ne - 1u) >> 6;
+                    }
+                    for (uint32_t bk = b_first; bk <= b_last; ++bk) {
+                        uint32_t e_lo = 0, n_items = ne * SUBH; /* ring-local first edge, (edge,row) items */
+                        if (BLOCKS && fblk_off != 0xFFFFFFFFu) {
+                            const osmt_blk_bbox bb = g_blk[fblk_off + bk];
+                            /* rows carrying records of an edge: ytop < y <= ybot */
+                            if (bb.y1 < rc.y0 || bb.y0 >= rc.y1) continue;
+                            e_lo = max(bk << 6, e_base) - e_base;
+                            n_items = (min((bk + 1u) << 6, e_base + ne) - e_base - e_lo) * SUBH;
+                        }
+                        for (uint32_t it = tid; it < n_items; it += NTHREADS) {
+                            const uint32_t e = e_lo + it / SUBH, row = it % SUBH;
+                            const int2 p1 = g_pts[ring.first_pt + e];
+                            const int2 p2 = g_pts[ring.first_pt + e + 1];
+                            int32_t xmn, xmx;
+                            if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx)) {
+                                const uint32_t slot = atomicAdd(&sh.rowcnt[row], 1u);
+                                if (slot < ROWCAP) {
+                                    sh.rec[row][slot].x_min = xmn;
+                                    sh.rec[row][slot].x_max = xmx;
+                                    sh.rec[row][slot].edge = e_base + e;
+                                }
                             }
                         }
                     }
@@ -1147,11 +1198,11 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
 
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
                               const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, uint32_t* submask, uint32_t sub_rows,
-                              hipStream_t st) {
+                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
+                              uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
     if (n_ops == 0) return hipSuccess;
     hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
-                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, opnv, submask, sub_rows);
+                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, opnv, op_blk, blk, submask, sub_rows);
     return hipGetLastError();
 }
 
@@ -1161,14 +1212,16 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
-    if (out_f64)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.den, a.aux, a.opnv, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
-                           a.out_tile_stride);
-    else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, a.rings,
-                           a.pts, a.trav, a.den, a.aux, a.opnv, a.submask, a.sub_rows, a.images, a.image_pool, a.n_images, a.out,
-                           a.out_tile_stride);
+#define OSMT_LAUNCH_RASTER(F64, BLK)                                                                                  \
+    hipLaunchKernelGGL((k_raster<F64, BLK>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info,      \
+                       a.rings, a.pts, a.trav, a.den, a.aux, a.opnv, a.op_blk, a.blk, a.submask, a.sub_rows, a.images,    \
+                       a.image_pool, a.n_images, a.out, a.out_tile_stride)
+    if (out_f64) {
+        if (a.has_blocks) OSMT_LAUNCH_RASTER(true, true); else OSMT_LAUNCH_RASTER(true, false);
+    } else {
+        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true); else OSMT_LAUNCH_RASTER(false, false);
+    }
+#undef OSMT_LAUNCH_RASTER
     return hipGetLastError();
 }
 

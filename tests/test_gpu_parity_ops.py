@@ -261,3 +261,29 @@ def test_dense_config5_tile(gpu_ctx, oracle):
     dl = synth.make_tiles(synth.config_tiles(1, x0=79000, y0=40000), zoom=17, n_poly=1500, n_line=1200,
                           radius=(2.0, 12.0), step=12.0)
     assert_parity(gpu_ctx, oracle, dl, msg="dense")
+
+
+def test_long_ways_and_multipolygons_use_the_block_path(gpu_ctx, oracle):
+    """Ops with more than 64 edges: several record rounds per stroke, 64-edge block culling for
+    strokes and fills, cap stubs in the last round, rings crossing block boundaries."""
+    t = np.linspace(0, 9 * np.pi, 400)
+    spiral = np.stack([128 + (6 + 4.1 * t) * np.cos(t), 128 + (6 + 4.1 * t) * np.sin(t)], 1).round().astype(int).tolist()
+    wave = [(int(x), int(130 + 60 * np.sin(x / 17.0))) for x in range(-300, 600, 3)]
+    tb = TileBuilder()
+    tb.stroke(spiral, 3.0, (200, 30, 30), 0.8, dashes=[7, 4], cap=abi.CAP_ROUND, use_caps_for_dashes=True)
+    tb.stroke(wave, 6.0, (30, 30, 200), 0.6, cap=abi.CAP_SQUARE)
+    ring_a = [(int(128 + 110 * np.cos(a)), int(128 + 100 * np.sin(a))) for a in np.linspace(0, 2 * np.pi, 150)]
+    ring_b = [(int(128 + 60 * np.cos(a)), int(120 + 55 * np.sin(-a))) for a in np.linspace(0, 2 * np.pi, 90)]
+    ring_c = [(int(300 + 90 * np.cos(a)), int(40 + 80 * np.sin(a))) for a in np.linspace(0, 2 * np.pi, 70)]
+    for r in (ring_a, ring_b, ring_c):
+        r[-1] = r[0]
+    tb.fill([ring_a, ring_b, ring_c], (20, 160, 60), 0.7)
+    tb.stroke(ring_a, 1.0, (0, 0, 0), 1.0)
+    dl1 = tb.build()
+    # the same at @2x with everything shifted far to the left: most blocks are culled
+    tb2 = TileBuilder(scale=2)
+    far = [(x * 2 - 700, y * 2) for x, y in wave]
+    tb2.stroke(far, 9.0, (10, 10, 10), 0.9, dashes=[20, 6])
+    tb2.fill([[(x * 2 - 300, y * 2 + 40) for x, y in ring_a]], (250, 200, 10), 0.5)
+    assert_parity(gpu_ctx, oracle, dl1, msg="long ops")
+    assert_parity(gpu_ctx, oracle, tb2.build(), msg="long ops @2x")
