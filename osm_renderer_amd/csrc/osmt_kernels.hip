@@ -634,6 +634,63 @@ __device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const
                            initial_opacity, mn, mx, pe, mul, rc, plane);
 }
 
+/* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
+ * repeated minimum search and OR the paired spans that fall into [x0, x1].  Used only for rows
+ * with more than ROWCAP crossings (cold; deliberately not inlined). */
+__device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
+                                                    uint32_t ring_off, uint32_t n_rings, int32_t y, int32_t x0,
+                                                    int32_t x1) {
+    uint32_t m = 0u;
+    int32_t last_x = INT32_MIN;
+    int64_t last_e = -1;
+    bool have_last = false;
+    uint32_t k = 0;
+    int32_t from_x = 0;
+    for (;;) {
+        bool found = false;
+        int32_t bx = 0, bxm = 0;
+        int64_t be = 0;
+        uint32_t eb = 0;
+        for (uint32_t r = 0; r < n_rings; ++r) {
+            const osmt_ring ring = rings[ring_off + r];
+            if (ring.n_pts < 2) continue;
+            for (uint32_t e = 0; e + 1 < ring.n_pts; ++e) {
+                const int2 p1 = pts[ring.first_pt + e];
+                const int2 p2 = pts[ring.first_pt + e + 1];
+                int32_t xmn, xmx;
+                if (!osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, y, &xmn, &xmx)) continue;
+                const int64_t ge = (int64_t)eb + e;
+                const bool after = !have_last || xmn > last_x || (xmn == last_x && ge > last_e);
+                if (!after) continue;
+                if (!found || xmn < bx || (xmn == bx && ge < be)) {
+                    found = true;
+                    bx = xmn;
+                    bxm = xmx;
+                    be = ge;
+                }
+            }
+            eb += ring.n_pts - 1;
+        }
+        if (!found) break;
+        if ((k & 1u) == 0u) {
+            from_x = bx;
+        } else {
+            const int32_t from = max(from_x, x0);
+            const int32_t to = min(bxm, x1);
+            if (from <= to) {
+                const uint32_t len = (uint32_t)(to - from + 1);
+                const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                m |= bits << (uint32_t)(from - x0);
+            }
+        }
+        have_last = true;
+        last_x = bx;
+        last_e = be;
+        ++k;
+    }
+    return m;
+}
+
 #ifndef OSMT_V_WAVES
 #define OSMT_V_WAVES 3
 #endif
@@ -988,57 +1045,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             }
                         }
                     } else {
-                        /* slow path (more than ROWCAP crossings on a row): stream the records in
-                         * (x_min, edge) order by repeated minimum search — no storage needed */
-                        int32_t last_x = INT32_MIN;
-                        int64_t last_e = -1;
-                        bool have_last = false;
-                        uint32_t k = 0;
-                        int32_t from_x = 0;
-                        for (;;) {
-                            bool found = false;
-                            int32_t bx = 0, bxm = 0;
-                            int64_t be = 0;
-                            uint32_t eb = 0;
-                            for (uint32_t r = 0; r < op->n_rings; ++r) {
-                                const osmt_ring ring = g_rings[op->ring_off + r];
-                                if (ring.n_pts < 2) continue;
-                                for (uint32_t e = 0; e + 1 < ring.n_pts; ++e) {
-                                    const int2 p1 = g_pts[ring.first_pt + e];
-                                    const int2 p2 = g_pts[ring.first_pt + e + 1];
-                                    int32_t xmn, xmx;
-                                    if (!osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx))
-                                        continue;
-                                    const int64_t ge = (int64_t)eb + e;
-                                    const bool after =
-                                        !have_last || xmn > last_x || (xmn == last_x && ge > last_e);
-                                    if (!after) continue;
-                                    if (!found || xmn < bx || (xmn == bx && ge < be)) {
-                                        found = true;
-                                        bx = xmn;
-                                        bxm = xmx;
-                                        be = ge;
-                                    }
-                                }
-                                eb += ring.n_pts - 1;
-                            }
-                            if (!found) break;
-                            if ((k & 1u) == 0u) {
-                                from_x = bx;
-                            } else {
-                                const int32_t from = max(from_x, rc.x0);
-                                const int32_t to = min(bxm, rc.x1);
-                                if (from <= to) {
-                                    const uint32_t len = (uint32_t)(to - from + 1);
-                                    const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                                    m |= bits << (uint32_t)(from - rc.x0);
-                                }
-                            }
-                            have_last = true;
-                            last_x = bx;
-                            last_e = be;
-                            ++k;
-                        }
+                        /* slow path (more than ROWCAP crossings on a row): kept out of line — it is cold,
+                         * and inlined it would only add code and register pressure to the hot path */
+                        m = fill_row_streaming(g_rings, g_pts, op->ring_off, op->n_rings, rc.y0 + (int32_t)row, rc.x0, rc.x1);
                     }
                     sh.mask[buf][row] = m;
                     sh.rowcnt[row] = 0u;
