@@ -247,7 +247,7 @@ def test_many_ops_per_tile_more_than_one_chunk(gpu_ctx, oracle):
 
 
 def test_no_canvas_and_scales(gpu_ctx, oracle):
-    for scale in (1, 2, 3):
+    for scale in (1, 2, 3, 4):
         tb = TileBuilder(scale=scale, canvas=None)
         s = scale
         tb.fill([(10 * s, 10 * s), (200 * s, 30 * s), (120 * s, 240 * s), (10 * s, 10 * s)], (250, 120, 20), 0.75)
