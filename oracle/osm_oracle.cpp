@@ -12,7 +12,7 @@
  * PARITY PIN STATUS
  *   - projection (tile.rs:88-106): PINNED by the reference's own doctest known-answer
  *     values (src/tile.rs:26-28, 83-86) — tests/test_oracle_kat.py.
- *   - fill / stroke / blend / RGB: PINNED by four crops of the reference's REAL golden images
+ *   - fill / stroke / blend / RGB: PINNED by five crops of the reference's REAL golden images
  *     (tests/rendered/17_expected.png, 18_expected.png) that the oracle reproduces with ZERO
  *     differing pixels from stylesheet parameters + fitted integer vertices
  *     (tests/golden/ref_golden_patches.json, tests/test_reference_golden_patches.py):
@@ -21,11 +21,14 @@
  *                         traveled phase, 0.5-opacity third generation (161 colours)
  *       building 990 px   fill-opacity 0.9 polygon + 0.2-px outline of a closed 8-vertex ring
  *       wood    3411 px   opaque 16-vertex polygon: fat Bresenham extents, top-row exclusion, pairing
+ *       courtyard 3193 px multipolygon building with a hole: ONE edge table over both rings,
+ *                         even-odd pairing in x_min order (outer ring = stand-in rectangle outside
+ *                         the crop, inner ring fitted; the hole drawn as a separate op differs)
  *     Inputs were FITTED (the .osm is missing); +-1 px / reversed inputs do not match — see
  *     tests/golden/make_ref_patches.py for what that does and does not prove.
  *   - NOT pinned by any reference output (the reference cannot be built here — no rustc/cargo,
  *     crates not vendored — and tests/osm/nano_moscow.osm is absent): Square/Butt caps,
- *     use_caps_for_dashes = false, image fills, multipolygon (multi-ring) fills.  For these the
+ *     use_caps_for_dashes = false, image fills.  For these the
  *     oracle is checked only against the hand-derived vectors K1..K8 (tests/golden/kat.json,
  *     derived from the reference SOURCE).  Status of those parts: PARITY UNPINNED.
  *

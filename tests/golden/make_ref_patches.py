@@ -27,6 +27,16 @@ the reversed segment differs in 1), so they pin the oracle to the reference's re
                  outline color #330066 width 0.2 (mapnik.mapcss:2355-2359; no linecap) in the Stroke pass, over
                  the canvas #f1eee8.  8 fitted vertices; the whole 30x33 window matches (66 colours); the other
                  ring direction differs in 8 px, every +-1 vertex move in >= 29.
+  patch "courtyard": z17 golden, mosaic tile (col 4, row 0): the courtyard of a type=multipolygon building
+                 (fill #bca9a9 fill-opacity 0.9, Fill pass only: drawer.rs:82-105 draws multipolygons in no
+                 other pass, hence no outline) over the canvas #f1eee8.  ONE fill op with TWO rings: the fitted
+                 9-vertex inner ring, and a stand-in rectangle for the outer ring, whose real outline lies
+                 outside the crop (its only effect inside the window is one crossing left and one right of the
+                 hole on every row, which the rectangle supplies).  Pins the multi-ring rule of fill.rs:16-60:
+                 all rings share one edge table, crossings pair up in x_min order across rings, so the hole's
+                 left edge ends a span with its x_max and its right edge starts one with its x_min, and the
+                 hole's apex row is poisoned.  57x57 window minus 56 px of an icon/label drawn later; 3193
+                 compared pixels, 0 differ; every +-1 move of a hole vertex differs.
   patch "wood":  natural=wood / landuse=wood polygon, fill #aed1a0 opaque (mapnik.mapcss:243-246)
                  over the same #dddddd.
 
@@ -52,6 +62,13 @@ WOOD = dict(
     ring=[(201, 158), (190, 181), (171, 171), (155, 163), (148, 156), (141, 151), (129, 142), (124, 138), (120, 131),
           (120, 117), (126, 111), (130, 108), (134, 104), (138, 101), (153, 105), (159, 109), (201, 158)],
     window=(115, 204, 95, 189),
+)
+
+
+COURTYARD = dict(
+    outer_stand_in=[(-50, 100), (400, 100), (400, 400), (-50, 400), (-50, 100)],
+    hole=[(79, 193), (95, 208), (97, 210), (72, 235), (68, 240), (68, 242), (61, 236), (65, 232), (53, 220), (79, 193)],
+    window=(50, 106, 190, 246),
 )
 
 
@@ -124,6 +141,21 @@ def main():
         "expected_rgb": tile17[y0 : y1 + 1, x0 : x1 + 1].tolist(),
     }
 
+    tile17c = im17[0:256, 4 * 256 : 5 * 256]
+    x0, x1, y0, y1 = COURTYARD["window"]
+    win = tile17c[y0 : y1 + 1, x0 : x1 + 1]
+    known = (win == np.array([193, 175, 175])).all(-1) | (win == np.array([0xF1, 0xEE, 0xE8])).all(-1)
+    known[:2, -3:] = False  # the real outer ring's own corner enters the window here
+    courtyard = {
+        "source": "tests/rendered/17_expected.png, mosaic tile (col 4, row 0), tile-relative pixel coordinates",
+        "window_x0_x1_y0_y1": list(COURTYARD["window"]),
+        "canvas": [0xF1, 0xEE, 0xE8],
+        "ops": [{"kind": "fill", "rings": [[list(p) for p in COURTYARD["outer_stand_in"]], [list(p) for p in COURTYARD["hole"]]],
+                 "color": [0xBC, 0xA9, 0xA9], "opacity": 0.9}],
+        "mask_rows": ["".join("1" if v else "0" for v in row) for row in known],
+        "expected_rgb": win.tolist(),
+    }
+
     x0, x1, y0, y1 = WOOD["window"]
     green = (tile[y0 : y1 + 1, x0 : x1 + 1] == np.array([174, 209, 160])).all(-1)
     wood = {
@@ -134,10 +166,11 @@ def main():
         "fill_rgb": [174, 209, 160],
         "expected_fill_mask_rows": ["".join("1" if v else "0" for v in row) for row in green],
     }
-    out = {"_provenance": __doc__, "stub": stub, "dashed": dashed, "building": building, "wood": wood}
+    out = {"_provenance": __doc__, "stub": stub, "dashed": dashed, "building": building, "courtyard": courtyard, "wood": wood}
     with open(os.path.join(HERE, "ref_golden_patches.json"), "w") as f:
         json.dump(out, f)
-    print("stub mask px", int(mask.sum()), "dashed mask px", int(dmask.sum()), "wood px", int(green.sum()))
+    print("stub mask px", int(mask.sum()), "dashed mask px", int(dmask.sum()), "wood px", int(green.sum()),
+          "courtyard px", int(known.sum()))
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ def _display_list(patch):
             tb.stroke(op["points"], op["width"], tuple(op["color"]), op["opacity"], dashes=op.get("dashes"),
                       cap=CAP[op["cap"]], use_caps_for_dashes=op.get("use_caps_for_dashes", False))
         else:
-            tb.fill(op["ring"], tuple(op["color"]), op["opacity"])
+            tb.fill(op["rings"] if "rings" in op else op["ring"], tuple(op["color"]), op["opacity"])
     return tb.build()
 
 
@@ -87,6 +87,31 @@ def test_oracle_reproduces_reference_building_patch(oracle):
         _check_building(oracle.render_job(_display_list(q), 0)[..., :3])
 
 
+def _check_courtyard(rgb):
+    _check_masked("courtyard", rgb, 3193, 2000, 2)
+
+
+def test_oracle_reproduces_reference_multipolygon_patch(oracle):
+    """multi-ring fill (building with a courtyard): one edge table over all rings, even-odd pairing in x_min order,
+    fat extents on the hole side, poisoned apex row (fill.rs:16-60 with point_pairs.rs multipolygon rings)."""
+    _check_courtyard(oracle.render_job(_display_list(FIX["courtyard"]), 0)[..., :3])
+    hole = FIX["courtyard"]["ops"][0]["rings"][1]
+    for i in range(len(hole) - 1):
+        for d in ((1, 0), (0, 1), (-1, 0), (0, -1)):
+            q = json.loads(json.dumps(FIX["courtyard"]))
+            r = q["ops"][0]["rings"][1]
+            r[i] = [r[i][0] + d[0], r[i][1] + d[1]]
+            if i == 0:
+                r[-1] = list(r[0])
+            with pytest.raises(AssertionError):
+                _check_courtyard(oracle.render_job(_display_list(q), 0)[..., :3])
+    # the same hole drawn as a second fill op (its own edge table) is NOT what the reference does
+    q = json.loads(json.dumps(FIX["courtyard"]))
+    q["ops"] = [dict(q["ops"][0], rings=[q["ops"][0]["rings"][0]]), dict(q["ops"][0], rings=[hole])]
+    with pytest.raises(AssertionError):
+        _check_courtyard(oracle.render_job(_display_list(q), 0)[..., :3])
+
+
 def test_oracle_reproduces_reference_fill_patch(oracle):
     _check_wood(oracle.render_job(_display_list(FIX["wood"]), 0)[..., :3])
 
@@ -109,6 +134,7 @@ def test_stroke_patch_is_selective(oracle):
 
 @pytest.mark.gpu
 def test_gpu_reproduces_reference_patches(gpu_ctx):
-    for name, check in (("stub", _check_stub), ("dashed", _check_dashed), ("building", _check_building), ("wood", _check_wood)):
+    for name, check in (("stub", _check_stub), ("dashed", _check_dashed), ("building", _check_building),
+                        ("courtyard", _check_courtyard), ("wood", _check_wood)):
         out = gpu_ctx.render_batch_host(_display_list(FIX[name]))
         check(out[0, :, :, :3])
