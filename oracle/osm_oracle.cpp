@@ -12,7 +12,7 @@
  * PARITY PIN STATUS
  *   - projection (tile.rs:88-106): PINNED by the reference's own doctest known-answer
  *     values (src/tile.rs:26-28, 83-86) — tests/test_oracle_kat.py.
- *   - fill / stroke / blend / RGB: PINNED by five crops of the reference's REAL golden images
+ *   - fill / stroke / blend / RGB: PINNED by six crops of the reference's REAL golden images
  *     (tests/rendered/17_expected.png, 18_expected.png) that the oracle reproduces with ZERO
  *     differing pixels from stylesheet parameters + fitted integer vertices
  *     (tests/golden/ref_golden_patches.json, tests/test_reference_golden_patches.py):
@@ -21,6 +21,7 @@
  *                         traveled phase, 0.5-opacity third generation (161 colours)
  *       building 990 px   fill-opacity 0.9 polygon + 0.2-px outline of a closed 8-vertex ring
  *       wood    3411 px   opaque 16-vertex polygon: fat Bresenham extents, top-row exclusion, pairing
+ *       subway  2416 px   dashes 5,3 with NO caps on a width-2 line, phase carried across a vertex
  *       courtyard 3193 px multipolygon building with a hole: ONE edge table over both rings,
  *                         even-odd pairing in x_min order (outer ring = stand-in rectangle outside
  *                         the crop, inner ring fitted; the hole drawn as a separate op differs)

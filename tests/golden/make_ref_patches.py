@@ -37,6 +37,15 @@ the reversed segment differs in 1), so they pin the oracle to the reference's re
                  left edge ends a span with its x_max and its right edge starts one with its x_min, and the
                  hole's apex row is poisoned.  57x57 window minus 56 px of an icon/label drawn later; 3193
                  compared pixels, 0 differ; every +-1 move of a hole vertex differs.
+  patch "subway": z17 golden, mosaic tile (col 0, row 2): a railway=subway tunnel, color #999999 width 2
+                 dashes 5,3 and NO linecap (mapnik.mapcss:3377-3381), over the canvas.  The visible piece is one
+                 straight segment on the line through (-256,243),(256,221) (slope and offset regressed from the
+                 anti-aliased values, then the integer family with slope -11/256 picked); the way's earlier
+                 part lies in other tiles, so ONE lead-in segment (-887,-504)->(-256,243) outside the tile
+                 stands in for it: its only visible effect is the dash phase at the tile edge (traveled mod 8 =
+                 1.83946 at (-256,243); 0.0005 off already differs).  Pins dashes WITHOUT caps (cap None with
+                 use_caps_for_dashes), the feathered dash ends, traveled accumulation across a join and the
+                 thin-line (half-width 1) across feather: whole 151x16 window, 0 of 2416 px differ.
   patch "wood":  natural=wood / landuse=wood polygon, fill #aed1a0 opaque (mapnik.mapcss:243-246)
                  over the same #dddddd.
 
@@ -65,6 +74,7 @@ WOOD = dict(
 )
 
 
+SUBWAY = dict(points=[(-887, -504), (-256, 243), (256, 221)], window=(0, 150, 222, 237))
 COURTYARD = dict(
     outer_stand_in=[(-50, 100), (400, 100), (400, 400), (-50, 400), (-50, 100)],
     hole=[(79, 193), (95, 208), (97, 210), (72, 235), (68, 240), (68, 242), (61, 236), (65, 232), (53, 220), (79, 193)],
@@ -156,6 +166,18 @@ def main():
         "expected_rgb": win.tolist(),
     }
 
+    tile17s = im17[2 * 256 : 3 * 256, 0:256]
+    x0, x1, y0, y1 = SUBWAY["window"]
+    subway = {
+        "source": "tests/rendered/17_expected.png, mosaic tile (col 0, row 2), tile-relative pixel coordinates",
+        "window_x0_x1_y0_y1": list(SUBWAY["window"]),
+        "canvas": [0xF1, 0xEE, 0xE8],
+        "ops": [{"kind": "stroke", "points": [list(p) for p in SUBWAY["points"]], "width": 2.0, "color": [0x99, 0x99, 0x99],
+                 "opacity": 1.0, "cap": "none", "dashes": [5.0, 3.0], "use_caps_for_dashes": True}],
+        "mask_rows": ["1" * (x1 - x0 + 1) for _ in range(y0, y1 + 1)],
+        "expected_rgb": tile17s[y0 : y1 + 1, x0 : x1 + 1].tolist(),
+    }
+
     x0, x1, y0, y1 = WOOD["window"]
     green = (tile[y0 : y1 + 1, x0 : x1 + 1] == np.array([174, 209, 160])).all(-1)
     wood = {
@@ -166,7 +188,7 @@ def main():
         "fill_rgb": [174, 209, 160],
         "expected_fill_mask_rows": ["".join("1" if v else "0" for v in row) for row in green],
     }
-    out = {"_provenance": __doc__, "stub": stub, "dashed": dashed, "building": building, "courtyard": courtyard, "wood": wood}
+    out = {"_provenance": __doc__, "stub": stub, "dashed": dashed, "building": building, "courtyard": courtyard, "subway": subway, "wood": wood}
     with open(os.path.join(HERE, "ref_golden_patches.json"), "w") as f:
         json.dump(out, f)
     print("stub mask px", int(mask.sum()), "dashed mask px", int(dmask.sum()), "wood px", int(green.sum()),

@@ -112,6 +112,28 @@ def test_oracle_reproduces_reference_multipolygon_patch(oracle):
         _check_courtyard(oracle.render_job(_display_list(q), 0)[..., :3])
 
 
+def _check_subway(rgb):
+    _check_masked("subway", rgb, 2416, 300, 60)
+
+
+def test_oracle_reproduces_reference_capless_dashes_patch(oracle):
+    """dashes 5,3 with NO linecap on a width-2 line (railway=subway tunnel): feathered dash ends without caps,
+    traveled phase carried across a vertex; the phase is pinned to < 0.0005 px by the dash-end grey levels."""
+    _check_subway(oracle.render_job(_display_list(FIX["subway"]), 0)[..., :3])
+    for mod in ("lead", "cap", "nocapsfordashes_is_same"):
+        q = json.loads(json.dumps(FIX["subway"]))
+        if mod == "lead":
+            q["ops"][0]["points"][0][0] += 1  # phase moves by ~0.64 px
+        elif mod == "cap":
+            q["ops"][0]["cap"] = "round"
+        else:
+            q["ops"][0]["use_caps_for_dashes"] = False  # cap None: the flag must not matter
+            _check_subway(oracle.render_job(_display_list(q), 0)[..., :3])
+            continue
+        with pytest.raises(AssertionError):
+            _check_subway(oracle.render_job(_display_list(q), 0)[..., :3])
+
+
 def test_oracle_reproduces_reference_fill_patch(oracle):
     _check_wood(oracle.render_job(_display_list(FIX["wood"]), 0)[..., :3])
 
@@ -135,6 +157,6 @@ def test_stroke_patch_is_selective(oracle):
 @pytest.mark.gpu
 def test_gpu_reproduces_reference_patches(gpu_ctx):
     for name, check in (("stub", _check_stub), ("dashed", _check_dashed), ("building", _check_building),
-                        ("courtyard", _check_courtyard), ("wood", _check_wood)):
+                        ("courtyard", _check_courtyard), ("subway", _check_subway), ("wood", _check_wood)):
         out = gpu_ctx.render_batch_host(_display_list(FIX[name]))
         check(out[0, :, :, :3])
