@@ -122,6 +122,38 @@ typedef struct osmt_batch {
     size_t n_dashes;
 } osmt_batch;
 
+/* ---- label pass ---------------------------------------- */
+/* One Labeler::label_entity call (labeler.rs:16-38): an optional icon blit
+ * (labeler.rs:91-106) followed by an optional text (TextPlacer::place,
+ * font/text_placer.rs:24-160).  The text arrives as the Rasterizer::draw_line
+ * calls the reference's glyph walk makes (font/rasterizer.rs:27-88; draw_quad,
+ * :90-113, flattens curves into draw_line calls on the host, so libm's hypot
+ * stays where the reference calls it), in call order: the GPU replays them
+ * into the exact-area accumulators and runs save_to_figure (:115-147),
+ * set_label_pixel / bump_label_generation (tile_pixels.rs:131-162) and the
+ * final blend_unfinished_pixels(true) (:154-158, 205-223).  40 bytes. */
+typedef struct osmt_label {
+    uint8_t has_icon;      /* style.icon_image found in the IconCache AND get_label_position is Some (labeler.rs:48-66) */
+    uint8_t has_text;      /* place() reached save_to_figure (text_placer.rs:159); 0 = place() returned true early / no text_style */
+    uint8_t text_color[3]; /* Rasterizer::color (text_placer.rs:50-54) */
+    uint8_t _pad[3];
+    uint32_t image_id;     /* has_icon: id from osmt_register_image */
+    uint32_t seg_off;      /* first draw_line call in osmt_label_batch.segs */
+    uint32_t n_segs;
+    uint32_t _reserved;
+    double icon_center_x, icon_center_y; /* get_label_position (labeler.rs:57-60), already scaled */
+} osmt_label;
+
+/* Labels of a whole batch; tile i owns labels [job_label_off[i], job_label_off[i+1]) in
+ * draw order (drawer.rs:221-262: areas first, then nodes). */
+typedef struct osmt_label_batch {
+    const osmt_label* labels;
+    size_t n_labels;
+    const uint32_t* job_label_off; /* [n_jobs + 1] */
+    const double* segs;            /* [n_segs][4] = (x0, y0, x1, y1) exactly as passed to Rasterizer::draw_line */
+    size_t n_segs;
+} osmt_label_batch;
+
 typedef struct osmt_config {
     int32_t device; /* HIP device ordinal */
     uint32_t flags; /* reserved, 0 */
@@ -150,6 +182,10 @@ int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uin
  * (TileRenderedPixels, drawer.rs:27-30; to_rgb_triples, tile_pixels.rs:164-181). */
 int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba, size_t out_tile_stride_bytes);
 
+/* The same followed by the label pass (drawer.rs:107-125) when `labels` is not NULL. */
+int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
+                             size_t out_tile_stride_bytes);
+
 /* ---- whole path, HBM-resident (the fast path) --------------------------- */
 int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* batch, osmt_scene** out_scene);
 void osmt_scene_free(osmt_scene* scene);
@@ -165,6 +201,15 @@ int osmt_render_scene_f64(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, voi
  * (Point::from_node), 2 = per-op extents + traveled distances, 4 = raster. */
 int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba,
                              size_t out_tile_stride_bytes, void* stream);
+/* Attaches the label pass of every tile of the scene (Drawer::draw_labels,
+ * drawer.rs:107-125,221-262); osmt_render_scene then returns the pixels after
+ * blend_unfinished_pixels(true).  NULL / n_labels == 0 detaches.  Coordinates must
+ * be finite and |v| <= 2^20.  osmt_render_scene_f64 keeps returning the canvas
+ * BEFORE labels. */
+int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* scene, const osmt_label_batch* labels);
+/* Label statuses of the last osmt_render_scene (label_generation_statuses,
+ * tile_pixels.rs:160-162): ok[i] = 1 if label i succeeded.  Synchronises the stream. */
+int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* scene, uint8_t* ok);
 /* Copies the projected integer points of the scene back: xy = [n_pts][2]. */
 int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* scene, int32_t* xy);
 

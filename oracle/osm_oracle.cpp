@@ -45,6 +45,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -163,6 +164,7 @@ struct orc_pixels {
     std::vector<RgbaColor> pixels;
     std::vector<NextPixel> next_pixels;
     size_t generation;
+    std::vector<bool> label_generation_statuses;
 
     /* tile_pixels.rs:57-87 new */
     explicit orc_pixels(size_t scale) {
@@ -182,6 +184,7 @@ struct orc_pixels {
         for (auto& p : pixels) p = init;
         for (auto& n : next_pixels) n.some = false;
         generation = 0;
+        label_generation_statuses.clear();
     }
     size_t local_coords_to_idx(size_t x, size_t y) const { return y * scaled_extended_tile_size + x; }
     /* tile_pixels.rs:191-199 global_coords_to_idx (for_labels = false) */
@@ -225,6 +228,37 @@ struct orc_pixels {
     /* tile_pixels.rs:154-158 */
     void blend_unfinished_pixels() {
         for (size_t idx = 0; idx < next_pixels.size(); ++idx) blend_pixel(idx);
+    }
+    /* tile_pixels.rs:131-148 set_label_pixel (global_coords_to_idx with for_labels = true) */
+    bool set_label_pixel(int32_t x, int32_t y, const RgbaColor& color) {
+        if (x < labels_bb.min_x || x > labels_bb.max_x || y < labels_bb.min_y || y > labels_bb.max_y) return true;
+        const size_t idx = local_coords_to_idx((size_t)(x - labels_bb.min_x), (size_t)(y - labels_bb.min_y));
+        const size_t label_generation = label_generation_statuses.size();
+        NextPixel& np = next_pixels[idx];
+        if (np.some) {
+            if (np.generation < label_generation && label_generation_statuses[np.generation]) return false;
+        }
+        np = NextPixel{true, color, label_generation};
+        return true;
+    }
+    /* tile_pixels.rs:160-162 */
+    void bump_label_generation(bool succeeded) { label_generation_statuses.push_back(succeeded); }
+    /* tile_pixels.rs:154-158 with for_labels = true; blend_pixel :205-223 */
+    void blend_unfinished_label_pixels() {
+        for (size_t idx = 0; idx < next_pixels.size(); ++idx) {
+            NextPixel& np = next_pixels[idx];
+            if (np.some && label_generation_statuses[np.generation]) {
+                RgbaColor& old = pixels[idx];
+                const double a = np.color.a;
+                RgbaColor nw;
+                nw.r = np.color.r + (1.0 - a) * old.r;
+                nw.g = np.color.g + (1.0 - a) * old.g;
+                nw.b = np.color.b + (1.0 - a) * old.b;
+                nw.a = np.color.a + (1.0 - a) * old.a;
+                old = nw;
+            }
+            np.some = false;
+        }
     }
     /* tile_pixels.rs:164-181 to_rgb_triples */
     void to_rgb(uint8_t* out, bool rgba) const {
@@ -606,6 +640,166 @@ void op_point_pairs(const osmt_batch* b, const osmt_tile_job& job, const osmt_op
     }
 }
 
+/* ---- font/rasterizer.rs ------------------------------------------------------ */
+struct Stripe { /* :6-10 */
+    std::map<int32_t, double> a, s;
+};
+struct Rasterizer { /* :14-17 */
+    std::map<int32_t, Stripe> stripes;
+    uint8_t color[3];
+
+    /* :27-88 draw_line */
+    void draw_line(double x0, double y0, double x1, double y1) {
+        const double delta = y1 - y0;
+        if (delta == 0.0) return;
+        const double sign = (y0 <= y1) ? 1.0 : -1.0;
+        const double slope = (x1 - x0) / delta;
+        const double slope_recip = 1.0 / slope; /* f64::recip */
+        auto eval_x_at_y = [&](double y) { return x0 + (y - y0) * slope; };
+        auto eval_y_at_x = [&](double x) { return y0 + (x - x0) * slope_recip; };
+        const double y_min = std::fmin(y0, y1);
+        const double y_max = std::fmax(y0, y1);
+        const int32_t yf = f64_as_i32(std::floor(y_min)), yl = f64_as_i32(std::floor(y_max));
+        for (int64_t yy = yf; yy <= yl; ++yy) {
+            const int32_t y = (int32_t)yy;
+            Stripe& cur = stripes[y]; /* entry(y).or_default() */
+            const double y_bottom = std::fmax((double)y, y_min);
+            const double y_top = std::fmin((double)wadd(y, 1), y_max);
+            const double y_delta = y_top - y_bottom;
+            const double x_at_bottom = eval_x_at_y(y_bottom);
+            const double x_at_top = eval_x_at_y(y_top);
+            bool flip_edge;
+            double x_smallest, x_largest;
+            if (x_at_bottom <= x_at_top) {
+                flip_edge = false, x_smallest = x_at_bottom, x_largest = x_at_top;
+            } else {
+                flip_edge = true, x_smallest = x_at_top, x_largest = x_at_bottom;
+            }
+            const int32_t x_to = f64_as_i32(std::floor(x_largest));
+            for (int64_t xx = f64_as_i32(std::floor(x_smallest)); xx <= x_to; ++xx) {
+                const int32_t x = (int32_t)xx;
+                const double x_left = std::fmax((double)x, x_smallest);
+                const double x_next = (double)wadd(x, 1);
+                const double x_right = std::fmin(x_next, x_largest);
+                double pixel_area = (x_next - x_right) * y_delta;
+                const double trapezoid_width = x_right - x_left;
+                if (trapezoid_width > 0.0) {
+                    const double y_at_left = eval_y_at_x(x_left);
+                    const double y_at_right = eval_y_at_x(x_right);
+                    const double trapezoid_height =
+                        flip_edge ? (y_top - y_at_left) + (y_top - y_at_right) : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+                    pixel_area += trapezoid_width * trapezoid_height / 2.0;
+                }
+                auto it = cur.a.emplace(x, 0.0).first; /* entry(x).or_insert(0.0) */
+                it->second += sign * pixel_area;
+            }
+            auto it = cur.s.emplace(wadd(x_to, 1), 0.0).first;
+            it->second += sign * y_delta;
+        }
+    }
+
+    /* :90-113 draw_quad */
+    template <class F>
+    static void flatten_quad(double x0, double y0, double x1, double y1, double x2, double y2, F&& line) {
+        auto dist_between = [](double xa, double ya, double xb, double yb) { return std::hypot(std::fabs(xa - xb), std::fabs(ya - yb)); };
+        const double d01 = dist_between(x0, y0, x1, y1);
+        const double d12 = dist_between(x1, y1, x2, y2);
+        const double d02 = dist_between(x0, y0, x2, y2);
+        if ((d01 + d12) <= 1.0001 * d02) {
+            line(x0, y0, x2, y2);
+            return;
+        }
+        auto midpoint = [](double c1, double c2) { return (c1 + c2) / 2.0; };
+        const double m01_x = midpoint(x0, x1), m01_y = midpoint(y0, y1);
+        const double m12_x = midpoint(x1, x2), m12_y = midpoint(y1, y2);
+        const double m012_x = midpoint(m01_x, m12_x), m012_y = midpoint(m01_y, m12_y);
+        flatten_quad(x0, y0, m01_x, m01_y, m012_x, m012_y, line);
+        flatten_quad(m012_x, m012_y, m12_x, m12_y, x2, y2, line);
+    }
+
+    /* :115-147 save_to_figure; `visit(x, y, total)` returns false to abort like set_label_pixel */
+    template <class F>
+    bool for_each_pixel(F&& visit) const {
+        for (const auto& ys : stripes) {
+            const Stripe& stripe = ys.second;
+            auto a_it = stripe.a.begin();
+            auto s_it = stripe.s.begin();
+            double s_acc = 0.0;
+            int32_t x_min = INT32_MAX, x_max = INT32_MIN;
+            if (!stripe.a.empty()) {
+                x_min = std::min(x_min, stripe.a.begin()->first);
+                x_max = std::max(x_max, stripe.a.rbegin()->first);
+            }
+            if (!stripe.s.empty()) {
+                x_min = std::min(x_min, stripe.s.begin()->first);
+                x_max = std::max(x_max, stripe.s.rbegin()->first);
+            }
+            for (int64_t xx = x_min; xx <= x_max; ++xx) {
+                const int32_t x = (int32_t)xx;
+                double sv = 0.0, av = 0.0;
+                if (s_it != stripe.s.end() && s_it->first == x) sv = (s_it++)->second;
+                s_acc += sv;
+                if (a_it != stripe.a.end() && a_it->first == x) av = (a_it++)->second;
+                const double total = std::fmin(av + s_acc, 1.0);
+                if (total > 0.0 && !visit(x, ys.first, total)) return false;
+            }
+        }
+        return true;
+    }
+    bool save_to_figure(orc_pixels& pixels) const {
+        return for_each_pixel([&](int32_t x, int32_t y, double total) { return pixels.set_label_pixel(x, y, from_color(color, total)); });
+    }
+};
+
+/* labeler.rs:91-106 draw_icon */
+bool draw_icon(const orc_icon& icon, double center_x, double center_y, orc_pixels& pixels) {
+    auto get_start_coord = [](double coord, uint32_t dimension) { return f64_as_i32(coord - ((double)dimension / 2.0)); };
+    const int32_t start_x = get_start_coord(center_x, icon.width);
+    const int32_t start_y = get_start_coord(center_y, icon.height);
+    for (uint32_t x = 0; x < icon.width; ++x)
+        for (uint32_t y = 0; y < icon.height; ++y) {
+            const double* px = icon.rgba + 4 * ((size_t)y * icon.width + x);
+            if (!pixels.set_label_pixel(wadd(start_x, (int32_t)x), wadd(start_y, (int32_t)y), RgbaColor{px[0], px[1], px[2], px[3]}))
+                return false;
+        }
+    return true;
+}
+
+/* labeler.rs:16-38 label_entity over the display-list form of one label */
+bool label_entity(const osmt_label& lb, const double* segs, const orc_icon* icons, size_t n_icons, orc_pixels& px) {
+    bool succeeded;
+    bool icon_ok = true; /* label_with_icon: Some(..) unless draw_icon failed (:40-67) */
+    if (lb.has_icon && lb.image_id < n_icons) icon_ok = draw_icon(icons[lb.image_id], lb.icon_center_x, lb.icon_center_y, px);
+    if (icon_ok) {
+        if (lb.has_text) { /* label_with_text -> TextPlacer::place -> save_to_figure (:69-89) */
+            Rasterizer r;
+            std::memcpy(r.color, lb.text_color, 3);
+            for (uint32_t i = 0; i < lb.n_segs; ++i) {
+                const double* q = segs + 4 * ((size_t)lb.seg_off + i);
+                r.draw_line(q[0], q[1], q[2], q[3]);
+            }
+            succeeded = r.save_to_figure(px);
+        } else {
+            succeeded = true;
+        }
+    } else {
+        succeeded = false;
+    }
+    px.bump_label_generation(succeeded);
+    return succeeded;
+}
+
+/* drawer.rs:107-125: draw_labels + blend_unfinished_pixels(true) for one tile */
+void label_job_into(const osmt_label_batch* lb, size_t job_idx, const orc_icon* icons, size_t n_icons, orc_pixels& px,
+                    uint8_t* out_status) {
+    if (!lb || lb->n_labels == 0) return;
+    for (uint32_t i = lb->job_label_off[job_idx]; i < lb->job_label_off[job_idx + 1]; ++i) {
+        const bool ok = label_entity(lb->labels[i], lb->segs, icons, n_icons, px);
+        if (out_status) out_status[i] = ok ? 1 : 0;
+    }
+    px.blend_unfinished_label_pixels();
+}
+
 /* drawer.rs:60-131 draw_to_pixels (display-list form; labels excluded) */
 void render_job_into(const osmt_batch* b, size_t job_idx, const orc_icon* icons, size_t n_icons, orc_pixels& px) {
     const osmt_tile_job& job = b->jobs[job_idx];
@@ -745,24 +939,67 @@ size_t orc_fill_edge_walk(const int32_t a[2], const int32_t b[2], int32_t* out_x
     return n;
 }
 
-int orc_render_job(const osmt_batch* batch, size_t job_idx, const orc_icon* icons, size_t n_icons, uint8_t* out_rgba,
-                   double* out_f64) {
+int orc_render_job_labels(const osmt_batch* batch, const osmt_label_batch* labels, size_t job_idx, const orc_icon* icons,
+                          size_t n_icons, uint8_t* out_rgba, double* out_f64, uint8_t* out_status) {
     if (!batch || job_idx >= batch->n_jobs) return -1;
     orc_pixels px(batch->scale);
     render_job_into(batch, job_idx, icons, n_icons, px);
+    label_job_into(labels, job_idx, icons, n_icons, px, out_status);
     if (out_rgba) px.to_rgb(out_rgba, true);
     if (out_f64) orc_read_pixels_f64(&px, out_f64);
     return 0;
 }
+int orc_render_job(const osmt_batch* batch, size_t job_idx, const orc_icon* icons, size_t n_icons, uint8_t* out_rgba,
+                   double* out_f64) {
+    return orc_render_job_labels(batch, nullptr, job_idx, icons, n_icons, out_rgba, out_f64, nullptr);
+}
+
+size_t orc_rasterizer_pixels(const double* segs, size_t n_segs, int32_t* out_xy, double* out_total, size_t cap) {
+    Rasterizer r;
+    r.color[0] = r.color[1] = r.color[2] = 0;
+    for (size_t i = 0; i < n_segs; ++i) r.draw_line(segs[4 * i], segs[4 * i + 1], segs[4 * i + 2], segs[4 * i + 3]);
+    size_t n = 0;
+    r.for_each_pixel([&](int32_t x, int32_t y, double total) {
+        if (n < cap) {
+            out_xy[2 * n] = x;
+            out_xy[2 * n + 1] = y;
+            out_total[n] = total;
+        }
+        ++n;
+        return true;
+    });
+    return n;
+}
+
+size_t orc_flatten_quad(const double q[6], double* out_segs, size_t cap) {
+    size_t n = 0;
+    Rasterizer::flatten_quad(q[0], q[1], q[2], q[3], q[4], q[5], [&](double x0, double y0, double x1, double y1) {
+        if (n < cap) {
+            out_segs[4 * n] = x0;
+            out_segs[4 * n + 1] = y0;
+            out_segs[4 * n + 2] = x1;
+            out_segs[4 * n + 3] = y1;
+        }
+        ++n;
+    });
+    return n;
+}
 
 int orc_render_batch(const osmt_batch* batch, size_t first, size_t count, const orc_icon* icons, size_t n_icons,
                      uint8_t* out_rgba, size_t out_tile_stride, int threads) {
+    return orc_render_batch_labels(batch, nullptr, first, count, icons, n_icons, out_rgba, out_tile_stride, threads, nullptr);
+}
+
+int orc_render_batch_labels(const osmt_batch* batch, const osmt_label_batch* labels, size_t first, size_t count,
+                            const orc_icon* icons, size_t n_icons, uint8_t* out_rgba, size_t out_tile_stride, int threads,
+                            uint8_t* out_status) {
     if (!batch || first + count > batch->n_jobs) return -1;
     if (threads < 1) threads = 1;
     auto worker = [&](int tid) {
         orc_pixels px(batch->scale); /* one TilePixels per worker (http_server.rs:69-72) */
         for (size_t i = (size_t)tid; i < count; i += (size_t)threads) {
             render_job_into(batch, first + i, icons, n_icons, px);
+            label_job_into(labels, first + i, icons, n_icons, px, out_status);
             px.to_rgb(out_rgba + i * out_tile_stride, true);
         }
     };

@@ -70,6 +70,18 @@ int orc_render_job(const osmt_batch* batch, size_t job_idx, const orc_icon* icon
  * per thread, tiles dealt round-robin (http_server.rs:50-83,105-108). */
 int orc_render_batch(const osmt_batch* batch, size_t first, size_t count, const orc_icon* icons, size_t n_icons,
                      uint8_t* out_rgba, size_t out_tile_stride, int threads);
+/* The same followed by the label pass (drawer.rs:107-125): Labeler::label_entity per osmt_label in order,
+ * then blend_unfinished_pixels(true).  out_status (optional): [labels->n_labels], written for the tile's labels. */
+int orc_render_job_labels(const osmt_batch* batch, const osmt_label_batch* labels, size_t job_idx, const orc_icon* icons,
+                          size_t n_icons, uint8_t* out_rgba, double* out_f64, uint8_t* out_status);
+int orc_render_batch_labels(const osmt_batch* batch, const osmt_label_batch* labels, size_t first, size_t count,
+                            const orc_icon* icons, size_t n_icons, uint8_t* out_rgba, size_t out_tile_stride, int threads,
+                            uint8_t* out_status);
+/* font/rasterizer.rs:27-88 + :115-147 on a fresh Rasterizer: the (x, y, total) triples save_to_figure would pass
+ * to set_label_pixel, in its order.  Returns the count (may exceed cap; only cap are written). */
+size_t orc_rasterizer_pixels(const double* segs, size_t n_segs, int32_t* out_xy, double* out_total, size_t cap);
+/* font/rasterizer.rs:90-113 draw_quad: the draw_line calls it makes, [n][4]. */
+size_t orc_flatten_quad(const double q[6], double* out_segs, size_t cap);
 /* Converts the batch's points of job `job_idx` like Point::from_node: xy = [n_pts][2] */
 void orc_job_points(const osmt_batch* batch, size_t job_idx, int32_t* xy);
 

@@ -74,6 +74,31 @@ class Batch(C.Structure):
     ]
 
 
+class Label(C.Structure):
+    _fields_ = [
+        ("has_icon", C.c_uint8),
+        ("has_text", C.c_uint8),
+        ("text_color", C.c_uint8 * 3),
+        ("_pad", C.c_uint8 * 3),
+        ("image_id", C.c_uint32),
+        ("seg_off", C.c_uint32),
+        ("n_segs", C.c_uint32),
+        ("_reserved", C.c_uint32),
+        ("icon_center_x", C.c_double),
+        ("icon_center_y", C.c_double),
+    ]
+
+
+class LabelBatch(C.Structure):
+    _fields_ = [
+        ("labels", C.POINTER(Label)),
+        ("n_labels", C.c_size_t),
+        ("job_label_off", C.POINTER(C.c_uint32)),
+        ("segs", C.POINTER(C.c_double)),
+        ("n_segs", C.c_size_t),
+    ]
+
+
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32)]
 
@@ -81,3 +106,4 @@ class Config(C.Structure):
 assert C.sizeof(Op) == 64
 assert C.sizeof(Ring) == 8
 assert C.sizeof(TileJob) == 32
+assert C.sizeof(Label) == 40

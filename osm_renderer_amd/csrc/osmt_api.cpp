@@ -79,6 +79,18 @@ struct osmt_scene {
     uint8_t* d_opnv = nullptr;
     uint32_t* d_op_blk = nullptr;
     osmt_blk_bbox* d_blk = nullptr;
+    /* label pass (osmt_scene_set_labels): its own allocation */
+    uint32_t n_labels = 0, n_label_segs = 0;
+    char* d_lab_base = nullptr;
+    osmt_labelinfo* d_lab = nullptr;
+    uint32_t* d_job_label_off = nullptr;
+    double* d_lab_segs = nullptr;
+    osmt_label_seg* d_lab_prep = nullptr;
+    double* d_lab_a = nullptr;
+    double* d_lab_s = nullptr;
+    uint32_t* d_lab_bitmap = nullptr;
+    uint8_t* d_lab_ok = nullptr;
+    uint32_t* d_lab_err = nullptr;
 };
 
 namespace {
@@ -194,6 +206,18 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.n_images = (uint32_t)ctx->images.size();
         a.out = d_out;
         a.out_tile_stride = stride;
+        if (sc->n_labels && !f64) {
+            /* the label pass does not read the area canvas: coverage + collisions first, then
+             * k_raster blends the survivors right before to_rgb_triples */
+            HIP_TRY(osmt_launch_labels(sc->d_lab, sc->n_labels, sc->d_job_label_off, sc->n_jobs, sc->scale, sc->d_lab_segs,
+                                       sc->n_label_segs, sc->d_lab_prep, sc->d_lab_a, sc->d_lab_s, sc->d_lab_bitmap,
+                                       sc->d_lab_ok, sc->d_lab_err, st));
+            a.labels.info = sc->d_lab;
+            a.labels.n_labels = sc->n_labels;
+            a.labels.job_label_off = sc->d_job_label_off;
+            a.labels.ok = sc->d_lab_ok;
+            a.labels.plane = sc->d_lab_a;
+        }
         HIP_TRY(osmt_launch_raster(a, f64, st));
     }
     return OSMT_OK;
@@ -376,7 +400,150 @@ void osmt_scene_free(osmt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->d_base) (void)hipFree(s->d_base);
+    if (s->d_lab_base) (void)hipFree(s->d_lab_base);
     delete s;
+}
+
+/* Drawer::draw_labels (drawer.rs:221-262) as data: validates, sizes each label's coverage window and
+ * uploads.  Window of a label = stripes its draw_line calls can create inside labels_bb's rows
+ * (tile_pixels.rs:67-72) x every column those stripes can hold a key in (+-2 cells of slack for the
+ * rounding of eval_x_at_y, font/rasterizer.rs:37). */
+int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch* lb) {
+    if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (sc->d_lab_base) (void)hipFree(sc->d_lab_base);
+    sc->d_lab_base = nullptr;
+    sc->n_labels = sc->n_label_segs = 0;
+    if (!lb || lb->n_labels == 0) return OSMT_OK;
+    if (!lb->labels || !lb->job_label_off || (lb->n_segs && !lb->segs)) return fail(OSMT_INVALID_ARG, "NULL label pool");
+    if (lb->n_labels >= 0xFFFFFFFFull || lb->n_segs >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "label batch too large");
+    if (lb->job_label_off[0] != 0 || lb->job_label_off[sc->n_jobs] != lb->n_labels)
+        return fail(OSMT_INVALID_ARG, "job_label_off must run from 0 to n_labels over n_jobs + 1 entries");
+    for (uint32_t j = 0; j < sc->n_jobs; ++j)
+        if (lb->job_label_off[j] > lb->job_label_off[j + 1]) return fail(OSMT_INVALID_ARG, "job_label_off is not monotonic");
+    const double LIM = 1048576.0; /* 2^20 */
+    for (size_t i = 0; i < 4 * lb->n_segs; ++i)
+        if (!(std::fabs(lb->segs[i]) <= LIM)) return fail(OSMT_UNSUPPORTED, "label segment %zu: coordinate not finite or |v| > 2^20", i / 4);
+
+    std::vector<osmt_image_desc> images;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        images = ctx->images;
+    }
+    const int32_t W = (int32_t)(OSMT_TILE_SIZE * sc->scale);
+    std::vector<osmt_labelinfo> info(lb->n_labels);
+    size_t cells = 0;
+    for (uint32_t j = 0; j < sc->n_jobs; ++j) {
+        for (uint32_t l = lb->job_label_off[j]; l < lb->job_label_off[j + 1]; ++l) {
+            const osmt_label& in = lb->labels[l];
+            osmt_labelinfo& o = info[l];
+            memset(&o, 0, sizeof o);
+            o.job = j;
+            o.ry0 = 1;
+            o.ry1 = 0;
+            if (in.has_icon && in.image_id < images.size()) { /* icon missing from the cache: Some(0), no blit (labeler.rs:64-66) */
+                if (!(std::fabs(in.icon_center_x) <= LIM) || !(std::fabs(in.icon_center_y) <= LIM))
+                    return fail(OSMT_UNSUPPORTED, "label %u: icon centre not finite or |v| > 2^20", l);
+                const osmt_image_desc& im = images[in.image_id];
+                o.icon_w = im.width;
+                o.icon_h = im.height;
+                o.icon_off = im.offset;
+                o.icon_x = (int32_t)(in.icon_center_x - ((double)im.width / 2.0)); /* get_start_coord (labeler.rs:92-95) */
+                o.icon_y = (int32_t)(in.icon_center_y - ((double)im.height / 2.0));
+            }
+            o.has_text = in.has_text ? 1 : 0;
+            memcpy(o.color, in.text_color, 3);
+            if (!in.has_text || in.n_segs == 0) continue;
+            if ((size_t)in.seg_off + in.n_segs > lb->n_segs) return fail(OSMT_INVALID_ARG, "label %u: segment range out of bounds", l);
+            o.seg_off = in.seg_off;
+            o.n_segs = in.n_segs;
+            int32_t ry0 = INT32_MAX, ry1 = INT32_MIN, cx0 = INT32_MAX, cx1 = INT32_MIN;
+            for (uint32_t k = 0; k < in.n_segs; ++k) {
+                const double* q = lb->segs + 4 * ((size_t)in.seg_off + k);
+                if (q[3] - q[1] == 0.0) continue; /* draw_line returns (font/rasterizer.rs:30-32) */
+                int32_t a = (int32_t)std::floor(std::fmin(q[1], q[3])), b = (int32_t)std::floor(std::fmax(q[1], q[3]));
+                a = std::max(a, -W);
+                b = std::min(b, 2 * W - 1);
+                if (a > b) continue; /* no stripe inside labels_bb */
+                ry0 = std::min(ry0, a);
+                ry1 = std::max(ry1, b);
+                cx0 = std::min(cx0, (int32_t)std::floor(std::fmin(q[0], q[2])) - 2);
+                cx1 = std::max(cx1, (int32_t)std::floor(std::fmax(q[0], q[2])) + 3);
+            }
+            if (ry0 > ry1) continue;
+            const size_t rows = (size_t)(ry1 - ry0 + 1), cols = (size_t)(cx1 - cx0 + 1);
+            if (rows * cols > ((size_t)1 << 24))
+                return fail(OSMT_UNSUPPORTED, "label %u: coverage window of %zu x %zu cells is too large", l, cols, rows);
+            o.ry0 = ry0;
+            o.ry1 = ry1;
+            o.cx0 = cx0;
+            o.cols = (uint32_t)cols;
+            o.plane_off = cells;
+            cells += rows * cols;
+        }
+    }
+    if (cells > ((size_t)1 << 31)) return fail(OSMT_UNSUPPORTED, "label coverage windows need %zu cells (> 2^31)", cells);
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t EW = 3 * (size_t)W;
+    const size_t words = (EW * EW + 31) / 32;
+    const size_t o_info = carve(lb->n_labels * sizeof(osmt_labelinfo));
+    const size_t o_off = carve(((size_t)sc->n_jobs + 1) * 4);
+    const size_t o_segs = carve(lb->n_segs * 32);
+    const size_t o_prep = carve(lb->n_segs * sizeof(osmt_label_seg));
+    const size_t o_a = carve((cells + 1) * 8);
+    const size_t o_s = carve((cells + 1) * 8);
+    const size_t o_bm = carve((size_t)sc->n_jobs * words * 4);
+    const size_t o_ok = carve(lb->n_labels);
+    const size_t o_err = carve(4);
+    hipError_t e = hipMalloc((void**)&sc->d_lab_base, off + 256);
+    if (e != hipSuccess) {
+        sc->d_lab_base = nullptr;
+        return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) for labels failed: %s", off,
+                    hipGetErrorString(e));
+    }
+    char* base = sc->d_lab_base;
+    sc->d_lab = (osmt_labelinfo*)(base + o_info);
+    sc->d_job_label_off = (uint32_t*)(base + o_off);
+    sc->d_lab_segs = (double*)(base + o_segs);
+    sc->d_lab_prep = (osmt_label_seg*)(base + o_prep);
+    sc->d_lab_a = (double*)(base + o_a);
+    sc->d_lab_s = (double*)(base + o_s);
+    sc->d_lab_bitmap = (uint32_t*)(base + o_bm);
+    sc->d_lab_ok = (uint8_t*)(base + o_ok);
+    sc->d_lab_err = (uint32_t*)(base + o_err);
+    e = hipMemcpy(sc->d_lab, info.data(), info.size() * sizeof(osmt_labelinfo), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && lb->n_segs) e = hipMemcpy(sc->d_lab_segs, lb->segs, lb->n_segs * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(sc->d_lab_ok, 0, lb->n_labels);
+    if (e == hipSuccess) e = hipMemset(sc->d_lab_err, 0, 4);
+    if (e != hipSuccess) {
+        (void)hipFree(sc->d_lab_base);
+        sc->d_lab_base = nullptr;
+        return fail(OSMT_HIP_ERROR, "label upload failed: %s", hipGetErrorString(e));
+    }
+    sc->n_labels = (uint32_t)lb->n_labels;
+    sc->n_label_segs = (uint32_t)lb->n_segs;
+    return OSMT_OK;
+}
+
+int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* sc, uint8_t* ok) {
+    if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
+    if (sc->n_labels == 0) return OSMT_OK;
+    if (!ok) return fail(OSMT_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, sc->d_lab_err, 4, hipMemcpyDeviceToHost));
+    if (err) return fail(OSMT_HIP_ERROR, "label coverage window overflow (internal error %u)", err);
+    HIP_TRY(hipMemcpy(ok, sc->d_lab_ok, sc->n_labels, hipMemcpyDeviceToHost));
+    return OSMT_OK;
 }
 
 int osmt_render_scene(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t stride, void* stream) {
@@ -401,10 +568,22 @@ int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
 }
 
 int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba, size_t stride) {
+    return osmt_render_batch_labels(ctx, batch, nullptr, out_rgba, stride);
+}
+
+int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
+                             size_t stride) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
     osmt_scene* sc = nullptr;
     int rc = osmt_scene_upload(ctx, batch, &sc);
     if (rc != OSMT_OK) return rc;
+    if (labels) {
+        rc = osmt_scene_set_labels(ctx, sc, labels);
+        if (rc != OSMT_OK) {
+            osmt_scene_free(sc);
+            return rc;
+        }
+    }
     const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
     const size_t tile_bytes = W * W * 4;
     if (stride < tile_bytes) {

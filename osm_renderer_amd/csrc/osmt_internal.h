@@ -80,6 +80,43 @@ struct osmt_image_desc {
     uint32_t width, height;
 };
 
+/* ---- label pass ------------------------------------------------------ */
+/* One Rasterizer::draw_line call, pre-digested by k_label_segprep (font/rasterizer.rs:27-41):
+ * everything that does not depend on the stripe y. */
+struct osmt_label_seg {
+    double x0, y0;
+    double slope, slope_recip; /* (x1 - x0) / delta and its f64::recip */
+    double y_min, y_max;
+    double sign;               /* +1.0 / -1.0 */
+    int32_t yf, yl;            /* floor(y_min) as i32 ..= floor(y_max) as i32; yf > yl: delta == 0.0, no-op */
+};
+static_assert(sizeof(osmt_label_seg) == 64, "osmt_label_seg must be one 64-byte record");
+
+/* One Labeler::label_entity call with its coverage plane: the dense window
+ * [cx0, cx0 + cols) x [ry0, ry1] of the Rasterizer's stripes (rows clipped to labels_bb,
+ * tile_pixels.rs:67-72; columns cover every key the clipped rows can receive). */
+struct osmt_labelinfo {
+    uint32_t seg_off, n_segs;
+    int32_t ry0, ry1; /* empty (ry0 > ry1): no text pixels can land inside labels_bb */
+    int32_t cx0;
+    uint32_t cols;
+    uint64_t plane_off; /* first cell of the window in the A / S pools */
+    int32_t icon_x, icon_y; /* get_start_coord (labeler.rs:92-95) */
+    uint32_t icon_w, icon_h; /* 0 x 0: no icon */
+    uint64_t icon_off;       /* first pixel in the image pool (double4 units) */
+    uint8_t has_text, color[3];
+    uint32_t job;
+};
+static_assert(sizeof(osmt_labelinfo) == 64, "osmt_labelinfo must be one 64-byte record");
+
+struct osmt_label_args {
+    const osmt_labelinfo* info; /* [n_labels] */
+    uint32_t n_labels;
+    const uint32_t* job_label_off; /* [n_jobs + 1] */
+    const uint8_t* ok;             /* [n_labels] label_generation_statuses (written by k_label_resolve) */
+    const double* plane;           /* A pool after k_label_cover: min(a + s_acc, 1.0) per cell, 0 where no key */
+};
+
 struct osmt_raster_args {
     const osmt_tile_job* jobs;
     uint32_t n_jobs;
@@ -104,6 +141,7 @@ struct osmt_raster_args {
     uint32_t _pad;
     void* out;
     size_t out_tile_stride; /* bytes (RGBA8 output) */
+    osmt_label_args labels;  /* info == NULL: no label pass */
 };
 
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
@@ -115,6 +153,10 @@ hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_rin
                               double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
                               uint32_t* submask, uint32_t sub_rows, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
+/* label pass: segprep -> cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
+hipError_t osmt_launch_labels(const osmt_labelinfo* info, uint32_t n_labels, const uint32_t* job_label_off, uint32_t n_jobs,
+                              uint32_t scale, const double* segs, uint32_t n_segs, osmt_label_seg* prep, double* plane_a,
+                              double* plane_s, uint32_t* bitmap, uint8_t* ok, uint32_t* err, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);
 

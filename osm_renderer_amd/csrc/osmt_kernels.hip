@@ -708,7 +708,7 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 
 /* BLOCKS: the scene has ops with more than 64 edges (osmt_blk_bbox culling compiled in); scenes
  * made of short ways only (all named configs) run the leaner instantiation. */
-template <bool OUT_F64, bool BLOCKS>
+template <bool OUT_F64, bool BLOCKS, bool LABELS>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* separate __restrict__ const pointers (not a struct): lets the compiler prove the display
      * list is read-only and fetch wave-uniform records with scalar loads */
@@ -718,7 +718,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint8_t* OSMT_R g_opnv, const uint32_t* OSMT_R g_op_blk, const osmt_blk_bbox* OSMT_R g_blk,
     const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
     const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
-    size_t g_out_tile_stride) {
+    size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab, const uint32_t* OSMT_R g_job_label_off,
+    const uint8_t* OSMT_R g_lab_ok, const double* OSMT_R g_lab_plane) {
     __shared__ RasterShared sh;
 
     const uint32_t tid = threadIdx.x;
@@ -1091,6 +1092,45 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         __syncthreads(); /* oplist is rewritten by the next chunk */
     }
 
+    /* ---- label pass, blend_unfinished_pixels(true) (tile_pixels.rs:154-158,205-223) ----------
+     * k_label_resolve has decided which labels succeeded; succeeded labels never share a pixel
+     * (set_label_pixel refuses the second one), so every pixel is blended at most once and the
+     * order of the loop does not matter.  Inside one label the text's pixels (total > 0) were
+     * written after the icon's and replace them (labeler.rs:29-31). */
+    if (LABELS) {
+        const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
+        for (uint32_t l = l0; l < l1; ++l) {
+            if (!g_lab_ok[l]) continue;
+            const osmt_labelinfo* OSMT_R li = g_lab + l;
+            const int32_t ry0 = li->ry0, ry1 = li->ry1, cx0 = li->cx0;
+            const int32_t cx1 = cx0 + (int32_t)li->cols - 1;
+            const bool text_hit = li->has_text && ry0 <= rc.y1 && ry1 >= rc.y0 && cx0 <= rc.x1 && cx1 >= rc.x0;
+            const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
+            const int32_t iw = (int32_t)li->icon_w, ih = (int32_t)li->icon_h;
+            const bool icon_hit = iw > 0 && ix0 <= rc.x1 && ix0 + iw - 1 >= rc.x0 && iy0 <= rc.y1 && iy0 + ih - 1 >= rc.y0;
+            if (!text_hit && !icon_hit) continue;
+            const double cr = (double)li->color[0] / 255.0, cg = (double)li->color[1] / 255.0,
+                         cb = (double)li->color[2] / 255.0;
+            const double* OSMT_R plane = g_lab_plane + li->plane_off;
+            const uint32_t cols = li->cols;
+            const double4* OSMT_R ipx = g_image_pool + li->icon_off;
+            const int32_t x = rc.x0 + (int32_t)lx;
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const int32_t y = rc.y0 + (int32_t)(ly0 + (uint32_t)j * ROWSTEP);
+                double t = 0.0;
+                if (text_hit && y >= ry0 && y <= ry1 && x >= cx0 && x <= cx1)
+                    t = plane[(size_t)(y - ry0) * cols + (uint32_t)(x - cx0)];
+                if (t > 0.0) { /* RgbaColor::from_color(&self.color, total) (rasterizer.rs:140) */
+                    blend_rgb(acc[j], t * cr, t * cg, t * cb, t);
+                } else if (icon_hit && x >= ix0 && x < ix0 + iw && y >= iy0 && y < iy0 + ih) {
+                    const double4 c = ipx[(size_t)(y - iy0) * (uint32_t)iw + (uint32_t)(x - ix0)];
+                    blend_rgb(acc[j], c.x, c.y, c.z, c.w);
+                }
+            }
+        }
+    }
+
     /* ---- to_rgb_triples (tile_pixels.rs:164-181) / raw canvas ---------------- */
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
@@ -1189,6 +1229,188 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
 }  // namespace
 
 /* ---- launchers (C++ internal interface, see osmt_internal.h) ---------------- */
+/* ------------------------------------------------------------------------- */
+/* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
+ *
+ * k_label_segprep  one thread per draw_line call: the y-independent part of draw_line.
+ * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; every lane walks
+ *                  ALL of the label's draw_line calls in call order and adds the calls that cross its
+ *                  stripe into its own row of the dense A / S planes — the per-key f64 sums therefore
+ *                  happen in exactly the reference's order (BTreeMap entry += ..., :77,:80).  Then the
+ *                  lane runs save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and
+ *                  leaves total = min(a + s_acc, 1.0) in the A plane (0 where the stripe has no key).
+ * k_label_resolve  one workgroup per tile, labels strictly in draw order: a label succeeds iff none of
+ *                  the pixels it would set (icon rectangle, then cells with total > 0) inside labels_bb
+ *                  belongs to an earlier SUCCEEDED label (set_label_pixel, tile_pixels.rs:131-148;
+ *                  pixels of failed labels are overwritten freely); succeeded labels mark their pixels
+ *                  in a (3W)^2-bit ownership map.  The early `return false` of draw_icon /
+ *                  save_to_figure only skips pixels of a label that is not blended anyway.
+ * k_raster<LABELS> blends the succeeded labels over the area canvas before to_rgb_triples. */
+__global__ void k_label_segprep(const double4* __restrict__ segs, uint32_t n, osmt_label_seg* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 q = segs[i];
+    const double x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
+    osmt_label_seg r;
+    const double delta = y1 - y0;
+    r.x0 = x0;
+    r.y0 = y0;
+    r.sign = (y0 <= y1) ? 1.0 : -1.0;
+    r.slope = (x1 - x0) / delta;
+    r.slope_recip = 1.0 / r.slope;
+    r.y_min = fmin(y0, y1);
+    r.y_max = fmax(y0, y1);
+    if (delta == 0.0) {
+        r.yf = 1;
+        r.yl = 0;
+    } else {
+        r.yf = (int32_t)floor(r.y_min);
+        r.yl = (int32_t)floor(r.y_max);
+    }
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab, uint32_t n_labels,
+                                                    const osmt_label_seg* __restrict__ g_seg, double* g_a, double* g_s,
+                                                    uint32_t* g_err) {
+    const uint32_t l = blockIdx.x;
+    if (l >= n_labels) return;
+    const osmt_labelinfo* __restrict__ li = g_lab + l;
+    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0) return;
+    const uint32_t lane = threadIdx.x;
+    const int32_t ry0 = li->ry0, cx0 = li->cx0;
+    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
+    const uint32_t n_segs = li->n_segs;
+    const osmt_label_seg* __restrict__ segs = g_seg + li->seg_off;
+    double* A = g_a + li->plane_off;
+    double* S = g_s + li->plane_off;
+    for (uint32_t rbase = 0; rbase < R; rbase += 64u) {
+        const uint32_t nrow = min(64u, R - rbase);
+        {
+            const size_t base = (size_t)rbase * cols, cnt = (size_t)nrow * cols;
+            for (size_t i = lane; i < cnt; i += 64u) {
+                A[base + i] = 0.0;
+                S[base + i] = 0.0;
+            }
+        }
+        __syncthreads(); /* one wave per block: orders the zeroing before the row owners' read-modify-writes */
+        const bool active = lane < nrow;
+        const int32_t y = ry0 + (int32_t)(rbase + lane);
+        double* a_row = A + (size_t)(rbase + lane) * cols;
+        double* s_row = S + (size_t)(rbase + lane) * cols;
+        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
+        bool oob = false;
+        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
+        for (uint32_t si = 0; si < n_segs; ++si) {
+            const osmt_label_seg* __restrict__ sg = segs + si;
+            const int32_t yf = sg->yf, yl = sg->yl;
+            if (yl < band0 || yf > band1) continue; /* wave-uniform: also drops delta == 0 */
+            if (!active || y < yf || y > yl) continue;
+            /* font/rasterizer.rs:46-80 for stripe y */
+            const double x0 = sg->x0, y0 = sg->y0, slope = sg->slope, recip = sg->slope_recip, sign = sg->sign;
+            const double y_bottom = fmax((double)y, sg->y_min);
+            const double y_top = fmin((double)(y + 1), sg->y_max);
+            const double y_delta = y_top - y_bottom;
+            const double x_at_bottom = x0 + (y_bottom - y0) * slope;
+            const double x_at_top = x0 + (y_top - y0) * slope;
+            const bool flip_edge = !(x_at_bottom <= x_at_top);
+            const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+            const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+            const int32_t x_to = (int32_t)floor(x_largest);
+            const int32_t x_from = (int32_t)floor(x_smallest);
+            if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
+                oob = true;
+                continue;
+            }
+            for (int32_t x = x_from; x <= x_to; ++x) {
+                const double x_left = fmax((double)x, x_smallest);
+                const double x_next = (double)(x + 1);
+                const double x_right = fmin(x_next, x_largest);
+                double pixel_area = (x_next - x_right) * y_delta;
+                const double trapezoid_width = x_right - x_left;
+                if (trapezoid_width > 0.0) {
+                    const double y_at_left = y0 + (x_left - x0) * recip;
+                    const double y_at_right = y0 + (x_right - x0) * recip;
+                    const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                              : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+                    pixel_area += trapezoid_width * trapezoid_height / 2.0;
+                }
+                a_row[x - cx0] += sign * pixel_area;
+            }
+            s_row[x_to + 1 - cx0] += sign * y_delta;
+            x_min = min(x_min, x_from);
+            x_max = max(x_max, x_to + 1);
+        }
+        /* save_to_figure (:115-147) for this stripe: keys span [x_min, x_max] */
+        if (active && x_min <= x_max) {
+            double s_acc = 0.0;
+            for (int32_t x = x_min; x <= x_max; ++x) {
+                s_acc += s_row[x - cx0];
+                a_row[x - cx0] = fmin(a_row[x - cx0] + s_acc, 1.0);
+            }
+        }
+        if (oob) atomicOr(g_err, 1u);
+        __syncthreads();
+    }
+}
+
+#define OSMT_LABEL_RESOLVE_THREADS 256
+__global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
+    const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_job_label_off, uint32_t n_jobs, uint32_t scale,
+    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok) {
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_jobs) return;
+    const uint32_t tid = threadIdx.x;
+    const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
+    const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
+    const size_t words = ((size_t)EW * EW + 31u) / 32u;
+    uint32_t* bm = g_bitmap + (size_t)tile * words;
+    for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
+    __threadfence();
+    __syncthreads();
+    const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
+    for (uint32_t l = l0; l < l1; ++l) {
+        const osmt_labelinfo* __restrict__ li = g_lab + l;
+        const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
+        const uint32_t iw = li->icon_w, ih = li->icon_h;
+        const bool has_cells = li->has_text && li->ry0 <= li->ry1 && li->cols > 0;
+        const int32_t ry0 = li->ry0, cx0 = li->cx0;
+        const uint32_t cols = li->cols;
+        const uint32_t n_cells = has_cells ? (uint32_t)(li->ry1 - ry0 + 1) * cols : 0u;
+        const double* __restrict__ A = g_a + li->plane_off;
+        for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
+            bool hit = false;
+            for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
+                const int32_t x = ix0 + (int32_t)(i % iw), y = iy0 + (int32_t)(i / iw);
+                if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
+                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
+                if (pass == 0)
+                    hit |= (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+                else
+                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            }
+            for (uint32_t i = tid; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) {
+                if (!(A[i] > 0.0)) continue;
+                const int32_t x = cx0 + (int32_t)(i % cols), y = ry0 + (int32_t)(i / cols);
+                if (x < -W || x >= 2 * W) continue; /* rows are clipped already */
+                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
+                if (pass == 0)
+                    hit |= (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+                else
+                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            }
+            if (pass == 0) {
+                const int failed = __syncthreads_or(hit ? 1 : 0);
+                if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
+                if (failed) break;
+            } else {
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    }
+}
+
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
                                double scale, int32_t* pts, hipStream_t st) {
     if (n_pts == 0) return hipSuccess;
@@ -1221,16 +1443,32 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
-#define OSMT_LAUNCH_RASTER(F64, BLK)                                                                                  \
-    hipLaunchKernelGGL((k_raster<F64, BLK>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info,      \
+#define OSMT_LAUNCH_RASTER(F64, BLK, LAB)                                                                             \
+    hipLaunchKernelGGL((k_raster<F64, BLK, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, \
                        a.rings, a.pts, a.trav, a.den, a.aux, a.opnv, a.op_blk, a.blk, a.submask, a.sub_rows, a.images,    \
-                       a.image_pool, a.n_images, a.out, a.out_tile_stride)
-    if (out_f64) {
-        if (a.has_blocks) OSMT_LAUNCH_RASTER(true, true); else OSMT_LAUNCH_RASTER(true, false);
+                       a.image_pool, a.n_images, a.out, a.out_tile_stride, a.labels.info, a.labels.job_label_off,         \
+                       a.labels.ok, a.labels.plane)
+    if (out_f64) { /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
+        if (a.has_blocks) OSMT_LAUNCH_RASTER(true, true, false); else OSMT_LAUNCH_RASTER(true, false, false);
+    } else if (a.labels.info) {
+        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true, true); else OSMT_LAUNCH_RASTER(false, false, true);
     } else {
-        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true); else OSMT_LAUNCH_RASTER(false, false);
+        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true, false); else OSMT_LAUNCH_RASTER(false, false, false);
     }
 #undef OSMT_LAUNCH_RASTER
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_labels(const osmt_labelinfo* info, uint32_t n_labels, const uint32_t* job_label_off, uint32_t n_jobs,
+                              uint32_t scale, const double* segs, uint32_t n_segs, osmt_label_seg* prep, double* plane_a,
+                              double* plane_s, uint32_t* bitmap, uint8_t* ok, uint32_t* err, hipStream_t st) {
+    if (n_labels == 0 || n_jobs == 0) return hipSuccess;
+    if (n_segs)
+        hipLaunchKernelGGL(k_label_segprep, dim3((n_segs + 255u) / 256u), dim3(256), 0, st,
+                           reinterpret_cast<const double4*>(segs), n_segs, prep);
+    hipLaunchKernelGGL(k_label_cover, dim3(n_labels), dim3(64), 0, st, info, n_labels, prep, plane_a, plane_s, err);
+    hipLaunchKernelGGL(k_label_resolve, dim3(n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, info, job_label_off, n_jobs,
+                       scale, plane_a, bitmap, ok);
     return hipGetLastError();
 }
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "osmt_create", "osmt_destroy", "osmt_last_error", "osmt_version", "osmt_register_image", "osmt_render_batch",
     "osmt_scene_upload", "osmt_scene_free", "osmt_render_scene", "osmt_render_scene_f64", "osmt_render_scene_stages",
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
-    "osmt_encode_png",
+    "osmt_encode_png", "osmt_render_batch_labels", "osmt_scene_set_labels", "osmt_scene_read_label_status",
 ]
 
 
@@ -60,6 +60,9 @@ def load():
     L.osmt_project.argtypes = [vp, dp, C.c_size_t, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double, ip]
     L.osmt_composite.argtypes = [vp, dp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
     L.osmt_composite_device.argtypes = [vp, vp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.osmt_render_batch_labels.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
+    L.osmt_scene_set_labels.argtypes = [vp, vp, C.POINTER(abi.LabelBatch)]
+    L.osmt_scene_read_label_status.argtypes = [vp, vp, u8p]
     L.osmt_png_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.osmt_png_bound.restype = C.c_size_t
     L.osmt_encode_png.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -27,7 +27,7 @@ def _stream_ptr(stream=None):
 class Scene:
     """A display-list batch resident in HBM (osmt_scene)."""
 
-    def __init__(self, ctx, dl: DisplayList):
+    def __init__(self, ctx, dl: DisplayList, labels=None):
         self.ctx = ctx
         self.dl = dl
         self.n_jobs = dl.n_jobs
@@ -36,6 +36,27 @@ class Scene:
         h = C.c_void_p()
         check(load().osmt_scene_upload(ctx._h, C.byref(b), C.byref(h)))
         self._h = h
+        self.labels = None
+        if labels is not None:
+            self.set_labels(labels)
+
+    def set_labels(self, labels):
+        """osmt_scene_set_labels: attach (or, with None, detach) the label pass of every tile."""
+        if labels is None:
+            check(load().osmt_scene_set_labels(self.ctx._h, self._h, None))
+        else:
+            assert labels.n_jobs == self.n_jobs
+            lb = labels.as_batch()
+            check(load().osmt_scene_set_labels(self.ctx._h, self._h, C.byref(lb)))
+        self.labels = labels
+
+    def label_status(self):
+        """label_generation_statuses of the last render (tile_pixels.rs:160-162)."""
+        n = len(self.labels.labels) if self.labels is not None else 0
+        out = np.zeros(n, dtype=np.uint8)
+        if n:
+            check(load().osmt_scene_read_label_status(self.ctx._h, self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
 
     def free(self):
         if getattr(self, "_h", None):
@@ -85,8 +106,8 @@ class Context:
         return out.value
 
     # -- whole path --------------------------------------------------------------
-    def upload(self, dl: DisplayList) -> Scene:
-        return Scene(self, dl)
+    def upload(self, dl: DisplayList, labels=None) -> Scene:
+        return Scene(self, dl, labels)
 
     def render(self, scene: Scene, out=None, stream=None):
         """osmt_render_scene: returns a uint8 cuda tensor [n, H, W, 4] (asynchronous)."""
@@ -115,11 +136,16 @@ class Context:
         check(load().osmt_scene_read_points(self._h, scene._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
-    def render_batch_host(self, dl: DisplayList):
-        """osmt_render_batch: host buffers in, host RGBA8 out."""
+    def render_batch_host(self, dl: DisplayList, labels=None):
+        """osmt_render_batch / osmt_render_batch_labels: host buffers in, host RGBA8 out."""
         b = dl.as_batch()
         out = np.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
-        check(load().osmt_render_batch(self._h, C.byref(b), out.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 4))
+        if labels is None:
+            check(load().osmt_render_batch(self._h, C.byref(b), out.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 4))
+        else:
+            lb = labels.as_batch()
+            check(load().osmt_render_batch_labels(self._h, C.byref(b), C.byref(lb), out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  dl.dim * dl.dim * 4))
         return out
 
     # -- stages --------------------------------------------------------------------

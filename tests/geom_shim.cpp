@@ -43,6 +43,8 @@ size_t shim_sizeof(int which) {
         case 2: return sizeof(osmt_tile_job);
         case 3: return sizeof(osmt_batch);
         case 4: return sizeof(osmt_config);
+        case 5: return sizeof(osmt_label);
+        case 6: return sizeof(osmt_label_batch);
         case 10: return offsetof(osmt_op, opacity);
         case 11: return offsetof(osmt_op, width);
         case 12: return offsetof(osmt_op, n_dashes);
@@ -52,6 +54,11 @@ size_t shim_sizeof(int which) {
         case 30: return offsetof(osmt_batch, coord_kind);
         case 31: return offsetof(osmt_batch, latlon);
         case 32: return offsetof(osmt_batch, dashes);
+        case 40: return offsetof(osmt_label, image_id);
+        case 41: return offsetof(osmt_label, n_segs);
+        case 42: return offsetof(osmt_label, icon_center_x);
+        case 43: return offsetof(osmt_label_batch, job_label_off);
+        case 44: return offsetof(osmt_label_batch, n_segs);
     }
     return 0;
 }

@@ -47,6 +47,15 @@ def test_struct_layouts_match_the_header():
     assert s(30) == abi.Batch.coord_kind.offset
     assert s(31) == abi.Batch.latlon.offset
     assert s(32) == abi.Batch.dashes.offset
+    from osm_renderer_amd import labels
+
+    assert s(5) == C.sizeof(abi.Label) == labels.LABEL_DTYPE.itemsize == 40
+    assert s(6) == C.sizeof(abi.LabelBatch)
+    assert s(40) == abi.Label.image_id.offset == labels.LABEL_DTYPE.fields["image_id"][1]
+    assert s(41) == abi.Label.n_segs.offset == labels.LABEL_DTYPE.fields["n_segs"][1]
+    assert s(42) == abi.Label.icon_center_x.offset == labels.LABEL_DTYPE.fields["icon_center_x"][1]
+    assert s(43) == abi.LabelBatch.job_label_off.offset
+    assert s(44) == abi.LabelBatch.n_segs.offset
 
 
 def test_no_device_is_a_loud_error_not_a_fallback():
