@@ -85,12 +85,15 @@ struct osmt_scene {
     osmt_labelinfo* d_lab = nullptr;
     uint32_t* d_job_label_off = nullptr;
     double* d_lab_segs = nullptr;
-    osmt_label_seg* d_lab_prep = nullptr;
     double* d_lab_a = nullptr;
-    double* d_lab_s = nullptr;
+    double* d_lab_s_wide = nullptr;
+    uint32_t* d_lab_wide = nullptr;
+    uint32_t n_lab_wide = 0;
     uint32_t* d_lab_bitmap = nullptr;
     uint8_t* d_lab_ok = nullptr;
     uint32_t* d_lab_err = nullptr;
+    osmt_tile_label* d_tile_labels = nullptr;
+    uint32_t* d_tile_label_cnt = nullptr;
 };
 
 namespace {
@@ -209,13 +212,29 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         if (sc->n_labels && !f64) {
             /* the label pass does not read the area canvas: coverage + collisions first, then
              * k_raster blends the survivors right before to_rgb_triples */
-            HIP_TRY(osmt_launch_labels(sc->d_lab, sc->n_labels, sc->d_job_label_off, sc->n_jobs, sc->scale, sc->d_lab_segs,
-                                       sc->n_label_segs, sc->d_lab_prep, sc->d_lab_a, sc->d_lab_s, sc->d_lab_bitmap,
-                                       sc->d_lab_ok, sc->d_lab_err, st));
+            osmt_label_launch ll;
+            memset(&ll, 0, sizeof ll);
+            ll.info = sc->d_lab;
+            ll.n_labels = sc->n_labels;
+            ll.n_jobs = sc->n_jobs;
+            ll.scale = sc->scale;
+            ll.n_wide = sc->n_lab_wide;
+            ll.job_label_off = sc->d_job_label_off;
+            ll.segs = sc->d_lab_segs;
+            ll.wide = sc->d_lab_wide;
+            ll.plane_a = sc->d_lab_a;
+            ll.plane_s_wide = sc->d_lab_s_wide;
+            ll.bitmap = sc->d_lab_bitmap;
+            ll.ok = sc->d_lab_ok;
+            ll.err = sc->d_lab_err;
+            ll.tile_labels = sc->d_tile_labels;
+            ll.tile_label_cnt = sc->d_tile_label_cnt;
+            HIP_TRY(osmt_launch_labels(ll, st));
             a.labels.info = sc->d_lab;
             a.labels.n_labels = sc->n_labels;
             a.labels.job_label_off = sc->d_job_label_off;
-            a.labels.ok = sc->d_lab_ok;
+            a.labels.tile_labels = sc->d_tile_labels;
+            a.labels.tile_label_cnt = sc->d_tile_label_cnt;
             a.labels.plane = sc->d_lab_a;
         }
         HIP_TRY(osmt_launch_raster(a, f64, st));
@@ -433,13 +452,13 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     }
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * sc->scale);
     std::vector<osmt_labelinfo> info(lb->n_labels);
-    size_t cells = 0;
+    std::vector<uint32_t> wide;
+    size_t cells = 0, wide_cells = 0;
     for (uint32_t j = 0; j < sc->n_jobs; ++j) {
         for (uint32_t l = lb->job_label_off[j]; l < lb->job_label_off[j + 1]; ++l) {
             const osmt_label& in = lb->labels[l];
             osmt_labelinfo& o = info[l];
             memset(&o, 0, sizeof o);
-            o.job = j;
             o.ry0 = 1;
             o.ry1 = 0;
             if (in.has_icon && in.image_id < images.size()) { /* icon missing from the cache: Some(0), no blit (labeler.rs:64-66) */
@@ -481,6 +500,12 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
             o.cols = (uint32_t)cols;
             o.plane_off = cells;
             cells += rows * cols;
+            if (cols > OSMT_LABEL_LDS_CELLS) {
+                if (wide_cells + 64 * cols >= 0xFFFFFFFFull) return fail(OSMT_UNSUPPORTED, "too many wide label windows");
+                o.wide_off = (uint32_t)wide_cells;
+                wide_cells += 64 * cols;
+                wide.push_back(l);
+            }
         }
     }
     if (cells > ((size_t)1 << 31)) return fail(OSMT_UNSUPPORTED, "label coverage windows need %zu cells (> 2^31)", cells);
@@ -496,10 +521,12 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     const size_t o_info = carve(lb->n_labels * sizeof(osmt_labelinfo));
     const size_t o_off = carve(((size_t)sc->n_jobs + 1) * 4);
     const size_t o_segs = carve(lb->n_segs * 32);
-    const size_t o_prep = carve(lb->n_segs * sizeof(osmt_label_seg));
     const size_t o_a = carve((cells + 1) * 8);
-    const size_t o_s = carve((cells + 1) * 8);
-    const size_t o_bm = carve((size_t)sc->n_jobs * words * 4);
+    const size_t o_s = carve((wide_cells + 1) * 8);
+    const size_t o_wide = carve((wide.size() + 1) * 4);
+    const size_t o_bm = carve(words * 4 <= 96 * 1024 ? 4 : (size_t)sc->n_jobs * words * 4); /* scale 1: the map lives in LDS */
+    const size_t o_tl = carve(lb->n_labels * sizeof(osmt_tile_label));
+    const size_t o_tlc = carve((size_t)sc->n_jobs * 4);
     const size_t o_ok = carve(lb->n_labels);
     const size_t o_err = carve(4);
     hipError_t e = hipMalloc((void**)&sc->d_lab_base, off + 256);
@@ -512,15 +539,19 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     sc->d_lab = (osmt_labelinfo*)(base + o_info);
     sc->d_job_label_off = (uint32_t*)(base + o_off);
     sc->d_lab_segs = (double*)(base + o_segs);
-    sc->d_lab_prep = (osmt_label_seg*)(base + o_prep);
     sc->d_lab_a = (double*)(base + o_a);
-    sc->d_lab_s = (double*)(base + o_s);
+    sc->d_lab_s_wide = (double*)(base + o_s);
+    sc->d_lab_wide = (uint32_t*)(base + o_wide);
+    sc->n_lab_wide = (uint32_t)wide.size();
+    sc->d_tile_labels = (osmt_tile_label*)(base + o_tl);
+    sc->d_tile_label_cnt = (uint32_t*)(base + o_tlc);
     sc->d_lab_bitmap = (uint32_t*)(base + o_bm);
     sc->d_lab_ok = (uint8_t*)(base + o_ok);
     sc->d_lab_err = (uint32_t*)(base + o_err);
     e = hipMemcpy(sc->d_lab, info.data(), info.size() * sizeof(osmt_labelinfo), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && lb->n_segs) e = hipMemcpy(sc->d_lab_segs, lb->segs, lb->n_segs * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !wide.empty()) e = hipMemcpy(sc->d_lab_wide, wide.data(), wide.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(sc->d_lab_ok, 0, lb->n_labels);
     if (e == hipSuccess) e = hipMemset(sc->d_lab_err, 0, 4);
     if (e != hipSuccess) {

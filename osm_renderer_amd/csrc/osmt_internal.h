@@ -81,7 +81,7 @@ struct osmt_image_desc {
 };
 
 /* ---- label pass ------------------------------------------------------ */
-/* One Rasterizer::draw_line call, pre-digested by k_label_segprep (font/rasterizer.rs:27-41):
+/* One Rasterizer::draw_line call, pre-digested (label_seg_prep, font/rasterizer.rs:27-41):
  * everything that does not depend on the stripe y. */
 struct osmt_label_seg {
     double x0, y0;
@@ -100,20 +100,49 @@ struct osmt_labelinfo {
     int32_t ry0, ry1; /* empty (ry0 > ry1): no text pixels can land inside labels_bb */
     int32_t cx0;
     uint32_t cols;
-    uint64_t plane_off; /* first cell of the window in the A / S pools */
+    uint64_t plane_off; /* first cell of the window in the A pool */
     int32_t icon_x, icon_y; /* get_start_coord (labeler.rs:92-95) */
     uint32_t icon_w, icon_h; /* 0 x 0: no icon */
     uint64_t icon_off;       /* first pixel in the image pool (double4 units) */
     uint8_t has_text, color[3];
-    uint32_t job;
+    uint32_t wide_off; /* windows wider than the LDS band: first cell of a 64-stripe S scratch (k_label_cover_wide) */
 };
 static_assert(sizeof(osmt_labelinfo) == 64, "osmt_labelinfo must be one 64-byte record");
+
+/* Accumulator cells (A and S each) one k_label_cover wave keeps in LDS: a label's window is processed in
+ * bands of OSMT_LABEL_LDS_CELLS / cols stripes; windows with more columns take k_label_cover_wide. */
+#ifndef OSMT_LABEL_LDS_CELLS
+#define OSMT_LABEL_LDS_CELLS 640
+#endif
+
+/* k_label_resolve -> k_raster: a succeeded label that reaches into the tile, with the box to test sub-tiles against */
+struct osmt_tile_label {
+    int16_t x0, y0, x1, y1;
+    uint32_t label;
+    uint32_t _pad;
+};
+
+struct osmt_label_launch {
+    const osmt_labelinfo* info;
+    uint32_t n_labels, n_jobs, scale, n_wide;
+    const uint32_t* job_label_off;
+    const double* segs;
+    const uint32_t* wide; /* labels that need k_label_cover_wide */
+    double* plane_a;
+    double* plane_s_wide;
+    uint32_t* bitmap; /* scale > 1 only */
+    uint8_t* ok;
+    uint32_t* err;
+    osmt_tile_label* tile_labels;
+    uint32_t* tile_label_cnt;
+};
 
 struct osmt_label_args {
     const osmt_labelinfo* info; /* [n_labels] */
     uint32_t n_labels;
     const uint32_t* job_label_off; /* [n_jobs + 1] */
-    const uint8_t* ok;             /* [n_labels] label_generation_statuses (written by k_label_resolve) */
+    const osmt_tile_label* tile_labels; /* [n_labels], tile i's entries start at job_label_off[i] (k_label_resolve) */
+    const uint32_t* tile_label_cnt;     /* [n_jobs] */
     const double* plane;           /* A pool after k_label_cover: min(a + s_acc, 1.0) per cell, 0 where no key */
 };
 
@@ -153,10 +182,8 @@ hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_rin
                               double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
                               uint32_t* submask, uint32_t sub_rows, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
-/* label pass: segprep -> cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
-hipError_t osmt_launch_labels(const osmt_labelinfo* info, uint32_t n_labels, const uint32_t* job_label_off, uint32_t n_jobs,
-                              uint32_t scale, const double* segs, uint32_t n_segs, osmt_label_seg* prep, double* plane_a,
-                              double* plane_s, uint32_t* bitmap, uint8_t* ok, uint32_t* err, hipStream_t st);
+/* label pass: cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
+hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);
 

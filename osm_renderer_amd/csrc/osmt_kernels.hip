@@ -719,7 +719,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
     const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
     size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab, const uint32_t* OSMT_R g_job_label_off,
-    const uint8_t* OSMT_R g_lab_ok, const double* OSMT_R g_lab_plane) {
+    const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt, const double* OSMT_R g_lab_plane) {
     __shared__ RasterShared sh;
 
     const uint32_t tid = threadIdx.x;
@@ -1098,10 +1098,12 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * order of the loop does not matter.  Inside one label the text's pixels (total > 0) were
      * written after the icon's and replace them (labeler.rs:29-31). */
     if (LABELS) {
-        const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
-        for (uint32_t l = l0; l < l1; ++l) {
-            if (!g_lab_ok[l]) continue;
-            const osmt_labelinfo* OSMT_R li = g_lab + l;
+        const osmt_tile_label* OSMT_R tl = g_tl + g_job_label_off[tile];
+        const uint32_t n_tl = g_tl_cnt[tile];
+        for (uint32_t k = 0; k < n_tl; ++k) {
+            const osmt_tile_label e = tl[k];
+            if (e.x0 > rc.x1 || e.x1 < rc.x0 || e.y0 > rc.y1 || e.y1 < rc.y0) continue;
+            const osmt_labelinfo* OSMT_R li = g_lab + e.label;
             const int32_t ry0 = li->ry0, ry1 = li->ry1, cx0 = li->cx0;
             const int32_t cx1 = cx0 + (int32_t)li->cols - 1;
             const bool text_hit = li->has_text && ry0 <= rc.y1 && ry1 >= rc.y0 && cx0 <= rc.x1 && cx1 >= rc.x0;
@@ -1232,13 +1234,14 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
 /* ------------------------------------------------------------------------- */
 /* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
  *
- * k_label_segprep  one thread per draw_line call: the y-independent part of draw_line.
- * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; every lane walks
- *                  ALL of the label's draw_line calls in call order and adds the calls that cross its
- *                  stripe into its own row of the dense A / S planes — the per-key f64 sums therefore
- *                  happen in exactly the reference's order (BTreeMap entry += ..., :77,:80).  Then the
- *                  lane runs save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and
- *                  leaves total = min(a + s_acc, 1.0) in the A plane (0 where the stripe has no key).
+ * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; the wave digests the
+ *                  draw_line calls 64 at a time (one call per lane: the y-independent part of draw_line,
+ *                  two f64 divisions) into LDS, then every lane walks the calls that cross the band IN
+ *                  CALL ORDER and adds those that cross its stripe into its own row of the LDS-resident
+ *                  A / S accumulators — the per-key f64 sums therefore happen in exactly the reference's
+ *                  order (BTreeMap entry += ..., :77,:80) with no atomics.  Then the lane runs
+ *                  save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and the band is
+ *                  copied out coalesced: total = min(a + s_acc, 1.0) per cell, 0 where the stripe has no key.
  * k_label_resolve  one workgroup per tile, labels strictly in draw order: a label succeeds iff none of
  *                  the pixels it would set (icon rectangle, then cells with total > 0) inside labels_bb
  *                  belongs to an earlier SUCCEEDED label (set_label_pixel, tile_pixels.rs:131-148;
@@ -1246,10 +1249,44 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
  *                  in a (3W)^2-bit ownership map.  The early `return false` of draw_icon /
  *                  save_to_figure only skips pixels of a label that is not blended anyway.
  * k_raster<LABELS> blends the succeeded labels over the area canvas before to_rgb_triples. */
-__global__ void k_label_segprep(const double4* __restrict__ segs, uint32_t n, osmt_label_seg* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double4 q = segs[i];
+/* draw_line for stripe y (font/rasterizer.rs:46-80) into the stripe's own accumulator rows */
+__device__ __forceinline__ bool label_stripe(const osmt_label_seg& sg, int32_t y, int32_t cx0, uint32_t cols, double* a_row,
+                                             double* s_row, int32_t& x_min, int32_t& x_max) {
+    const double x0 = sg.x0, y0 = sg.y0, slope = sg.slope, recip = sg.slope_recip, sign = sg.sign;
+    const double y_bottom = fmax((double)y, sg.y_min);
+    const double y_top = fmin((double)(y + 1), sg.y_max);
+    const double y_delta = y_top - y_bottom;
+    const double x_at_bottom = x0 + (y_bottom - y0) * slope;
+    const double x_at_top = x0 + (y_top - y0) * slope;
+    const bool flip_edge = !(x_at_bottom <= x_at_top);
+    const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+    const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+    const int32_t x_to = (int32_t)floor(x_largest);
+    const int32_t x_from = (int32_t)floor(x_smallest);
+    if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) return false; /* cannot happen: the window is conservative */
+    for (int32_t x = x_from; x <= x_to; ++x) {
+        const double x_left = fmax((double)x, x_smallest);
+        const double x_next = (double)(x + 1);
+        const double x_right = fmin(x_next, x_largest);
+        double pixel_area = (x_next - x_right) * y_delta;
+        const double trapezoid_width = x_right - x_left;
+        if (trapezoid_width > 0.0) {
+            const double y_at_left = y0 + (x_left - x0) * recip;
+            const double y_at_right = y0 + (x_right - x0) * recip;
+            const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                      : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+            pixel_area += trapezoid_width * trapezoid_height / 2.0;
+        }
+        a_row[x - cx0] += sign * pixel_area;
+    }
+    s_row[x_to + 1 - cx0] += sign * y_delta;
+    x_min = min(x_min, x_from);
+    x_max = max(x_max, x_to + 1);
+    return true;
+}
+
+/* the y-independent part of draw_line (font/rasterizer.rs:27-41) */
+__device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
     const double x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
     osmt_label_seg r;
     const double delta = y1 - y0;
@@ -1267,81 +1304,257 @@ __global__ void k_label_segprep(const double4* __restrict__ segs, uint32_t n, os
         r.yf = (int32_t)floor(r.y_min);
         r.yl = (int32_t)floor(r.y_max);
     }
-    out[i] = r;
+    return r;
+}
+
+#define LC_CELLS OSMT_LABEL_LDS_CELLS
+
+/* sums one draw_line call may park in its lane's registers per batch; calls that need more (long stems
+ * crossing many stripes) are replayed stripe-by-stripe by the row owners instead */
+#define LC_MAXE 8
+#define LC_SLOW 0xFFu
+#define LC_NOCOL 0xFFFFFFFFu
+
+__device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)j);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab, uint32_t n_labels,
-                                                    const osmt_label_seg* __restrict__ g_seg, double* g_a, double* g_s,
+                                                    const double4* __restrict__ g_seg, double* __restrict__ g_a,
                                                     uint32_t* g_err) {
+    __shared__ double sh_a[LC_CELLS];
+    __shared__ double sh_s[LC_CELLS];
     const uint32_t l = blockIdx.x;
     if (l >= n_labels) return;
     const osmt_labelinfo* __restrict__ li = g_lab + l;
-    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0) return;
+    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0 || li->cols > LC_CELLS) return;
     const uint32_t lane = threadIdx.x;
     const int32_t ry0 = li->ry0, cx0 = li->cx0;
     const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
     const uint32_t n_segs = li->n_segs;
-    const osmt_label_seg* __restrict__ segs = g_seg + li->seg_off;
+    const double4* __restrict__ segs = g_seg + li->seg_off;
+    double* __restrict__ A = g_a + li->plane_off;
+    const uint32_t band_rows = min(64u, LC_CELLS / cols);
+    bool oob = false;
+    for (uint32_t rbase = 0; rbase < R; rbase += band_rows) {
+        const uint32_t nrow = min(band_rows, R - rbase);
+        const uint32_t cnt = nrow * cols;
+        for (uint32_t i = lane; i < cnt; i += 64u) {
+            sh_a[i] = 0.0;
+            sh_s[i] = 0.0;
+        }
+        __syncthreads();
+        const bool active = lane < nrow;
+        const int32_t y = ry0 + (int32_t)(rbase + lane);
+        double* a_row = sh_a + (active ? lane * cols : 0u);
+        double* s_row = sh_s + (active ? lane * cols : 0u);
+        /* the stripe owner keeps the cell it is adding to in a register (consecutive calls of a curve land in
+         * the same cell): LDS is touched only when the cell changes */
+        uint32_t a_col = LC_NOCOL, s_col = LC_NOCOL;
+        double a_val = 0.0, s_val = 0.0;
+        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys (x - cx0) */
+        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
+        for (uint32_t base = 0; base < n_segs; base += 64u) {
+            /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
+            const uint32_t i = base + lane;
+            bool overlaps = false;
+            osmt_label_seg sg;
+            uint32_t n = 0;
+            uint32_t ekey[LC_MAXE]; /* kind << 31 | local stripe << 20 | column */
+            double eval[LC_MAXE];
+#pragma unroll
+            for (int k = 0; k < LC_MAXE; ++k) {
+                ekey[k] = 0u;
+                eval[k] = 0.0;
+            }
+            if (i < n_segs) {
+                sg = label_seg_prep(segs[i]);
+                overlaps = sg.yl >= band0 && sg.yf <= band1; /* also drops delta == 0 (yf > yl) */
+                if (overlaps) {
+                    int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
+                    auto emit = [&](uint32_t key, double val) {
+#pragma unroll
+                        for (int k = 0; k < LC_MAXE; ++k)
+                            if ((uint32_t)k == n) {
+                                ekey[k] = key;
+                                eval[k] = val;
+                            }
+                        ++n;
+                    };
+                    for (int32_t yy = ya; yy <= yb; ++yy) {
+                        /* font/rasterizer.rs:46-80 for stripe yy */
+                        const double y_bottom = fmax((double)yy, sg.y_min);
+                        const double y_top = fmin((double)(yy + 1), sg.y_max);
+                        const double y_delta = y_top - y_bottom;
+                        const double x_at_bottom = sg.x0 + (y_bottom - sg.y0) * sg.slope;
+                        const double x_at_top = sg.x0 + (y_top - sg.y0) * sg.slope;
+                        const bool flip_edge = !(x_at_bottom <= x_at_top);
+                        const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+                        const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+                        const int32_t x_to = (int32_t)floor(x_largest);
+                        const int32_t x_from = (int32_t)floor(x_smallest);
+                        if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
+                            oob = true;
+                            continue;
+                        }
+                        if (n + (uint32_t)(x_to - x_from) + 2u > LC_MAXE) {
+                            n = LC_SLOW;
+                            break;
+                        }
+                        const uint32_t rowbits = (uint32_t)(yy - band0) << 20;
+                        for (int32_t x = x_from; x <= x_to; ++x) {
+                            const double x_left = fmax((double)x, x_smallest);
+                            const double x_next = (double)(x + 1);
+                            const double x_right = fmin(x_next, x_largest);
+                            double pixel_area = (x_next - x_right) * y_delta;
+                            const double trapezoid_width = x_right - x_left;
+                            if (trapezoid_width > 0.0) {
+                                const double y_at_left = sg.y0 + (x_left - sg.x0) * sg.slope_recip;
+                                const double y_at_right = sg.y0 + (x_right - sg.x0) * sg.slope_recip;
+                                const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                                          : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+                                pixel_area += trapezoid_width * trapezoid_height / 2.0;
+                            }
+                            emit(rowbits | (uint32_t)(x - cx0), sg.sign * pixel_area);
+                        }
+                        emit(0x80000000u | rowbits | (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(overlaps);
+            /* Consecutive calls of a flattened curve mostly land in the same cells: a lane whose key set equals
+             * its predecessor's continues that lane's RUN.  Runs are applied key by key — sums to different
+             * cells are independent, sums to one cell stay in call order. */
+            bool same_prev = overlaps && n != LC_SLOW && n != 0u;
+            {
+                const uint32_t pn = (uint32_t)__shfl_up((int)n, 1);
+                same_prev = same_prev && lane != 0u && pn == n;
+#pragma unroll
+                for (int k = 0; k < LC_MAXE; ++k) same_prev = same_prev && (uint32_t)__shfl_up((int)ekey[k], 1) == ekey[k];
+            }
+            const unsigned long long sp = __ballot(same_prev) & (m << 1); /* the predecessor must be in the band too */
+            unsigned long long heads = m & ~sp;
+            /* ---- phase 2, lane = stripe: the parked sums are applied strictly in call order ---- */
+            while (heads) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(heads);
+                heads &= heads - 1ull;
+                const uint32_t run = 1u + (j < 63u ? (uint32_t)__builtin_ctzll(~(sp >> (j + 1u))) : 0u);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j);
+                if (nj == LC_SLOW) {
+                    osmt_label_seg q;
+                    q.x0 = readlane_f64(sg.x0, j);
+                    q.y0 = readlane_f64(sg.y0, j);
+                    q.slope = readlane_f64(sg.slope, j);
+                    q.slope_recip = readlane_f64(sg.slope_recip, j);
+                    q.y_min = readlane_f64(sg.y_min, j);
+                    q.y_max = readlane_f64(sg.y_max, j);
+                    q.sign = readlane_f64(sg.sign, j);
+                    q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
+                    q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
+                    /* the replay works on LDS directly: write the cached cells back first */
+                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+                    a_col = s_col = LC_NOCOL;
+                    if (active && y >= q.yf && y <= q.yl) {
+                        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
+                        oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
+                        if (x_min <= x_max) {
+                            c_min = min(c_min, (uint32_t)(x_min - cx0));
+                            c_max = max(c_max, (uint32_t)(x_max - cx0));
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int e = 0; e < LC_MAXE; ++e) {
+                    if ((uint32_t)e < nj) {
+                        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)ekey[e], (int)j);
+                        const bool mine = ((key >> 20) & 0x7FFu) == lane;
+                        const uint32_t col = key & 0xFFFFFu;
+                        /* register selects only (no pointers to the cached values: those would be demoted to scratch) */
+                        const bool is_s = (key >> 31) != 0u;
+                        uint32_t cur_col = is_s ? s_col : a_col;
+                        double cur_val = is_s ? s_val : a_val;
+                        if (mine) {
+                            double* row = is_s ? s_row : a_row;
+                            if (col != cur_col) {
+                                if (cur_col != LC_NOCOL) row[cur_col] = cur_val;
+                                cur_val = row[col];
+                                cur_col = col;
+                            }
+                            c_min = min(c_min, col);
+                            c_max = max(c_max, col);
+                        }
+                        for (uint32_t t = 0; t < run; ++t) {
+                            const double v = readlane_f64(eval[e], j + t);
+                            if (mine) cur_val += v;
+                        }
+                        if (mine) {
+                            s_col = is_s ? cur_col : s_col;
+                            s_val = is_s ? cur_val : s_val;
+                            a_col = is_s ? a_col : cur_col;
+                            a_val = is_s ? a_val : cur_val;
+                        }
+                    }
+                }
+            }
+        }
+        if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+        if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+        /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
+        if (active && c_min <= c_max) {
+            double s_acc = 0.0;
+            for (uint32_t c = c_min; c <= c_max; ++c) {
+                s_acc += s_row[c];
+                a_row[c] = fmin(a_row[c] + s_acc, 1.0);
+            }
+        }
+        __syncthreads();
+        double* __restrict__ dst = A + (size_t)rbase * cols;
+        for (uint32_t i = lane; i < cnt; i += 64u) dst[i] = sh_a[i];
+        __syncthreads();
+    }
+    if (oob) atomicOr(g_err, 1u);
+}
+
+/* Windows wider than LC_CELLS columns (a glyph far to the side of labels_bb in a stripe that crosses it):
+ * the same walk with the accumulator rows in global memory. */
+__global__ __launch_bounds__(64) void k_label_cover_wide(const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_wide,
+                                                         uint32_t n_wide, const double4* __restrict__ g_seg, double* g_a, double* g_s,
+                                                         uint32_t* g_err) {
+    if (blockIdx.x >= n_wide) return;
+    const osmt_labelinfo* __restrict__ li = g_lab + g_wide[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const int32_t ry0 = li->ry0, cx0 = li->cx0;
+    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
+    const uint32_t n_segs = li->n_segs;
+    const double4* __restrict__ segs = g_seg + li->seg_off;
     double* A = g_a + li->plane_off;
-    double* S = g_s + li->plane_off;
+    double* S = g_s + li->wide_off;
+    bool oob = false;
     for (uint32_t rbase = 0; rbase < R; rbase += 64u) {
         const uint32_t nrow = min(64u, R - rbase);
         {
-            const size_t base = (size_t)rbase * cols, cnt = (size_t)nrow * cols;
+            const size_t cnt = (size_t)nrow * cols;
             for (size_t i = lane; i < cnt; i += 64u) {
-                A[base + i] = 0.0;
-                S[base + i] = 0.0;
+                A[(size_t)rbase * cols + i] = 0.0;
+                S[i] = 0.0;
             }
         }
         __syncthreads(); /* one wave per block: orders the zeroing before the row owners' read-modify-writes */
         const bool active = lane < nrow;
         const int32_t y = ry0 + (int32_t)(rbase + lane);
-        double* a_row = A + (size_t)(rbase + lane) * cols;
-        double* s_row = S + (size_t)(rbase + lane) * cols;
+        double* a_row = A + (size_t)(rbase + (active ? lane : 0u)) * cols;
+        double* s_row = S + (size_t)(active ? lane : 0u) * cols;
         int32_t x_min = INT32_MAX, x_max = INT32_MIN;
-        bool oob = false;
-        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
         for (uint32_t si = 0; si < n_segs; ++si) {
-            const osmt_label_seg* __restrict__ sg = segs + si;
-            const int32_t yf = sg->yf, yl = sg->yl;
-            if (yl < band0 || yf > band1) continue; /* wave-uniform: also drops delta == 0 */
-            if (!active || y < yf || y > yl) continue;
-            /* font/rasterizer.rs:46-80 for stripe y */
-            const double x0 = sg->x0, y0 = sg->y0, slope = sg->slope, recip = sg->slope_recip, sign = sg->sign;
-            const double y_bottom = fmax((double)y, sg->y_min);
-            const double y_top = fmin((double)(y + 1), sg->y_max);
-            const double y_delta = y_top - y_bottom;
-            const double x_at_bottom = x0 + (y_bottom - y0) * slope;
-            const double x_at_top = x0 + (y_top - y0) * slope;
-            const bool flip_edge = !(x_at_bottom <= x_at_top);
-            const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
-            const double x_largest = flip_edge ? x_at_bottom : x_at_top;
-            const int32_t x_to = (int32_t)floor(x_largest);
-            const int32_t x_from = (int32_t)floor(x_smallest);
-            if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
-                oob = true;
-                continue;
-            }
-            for (int32_t x = x_from; x <= x_to; ++x) {
-                const double x_left = fmax((double)x, x_smallest);
-                const double x_next = (double)(x + 1);
-                const double x_right = fmin(x_next, x_largest);
-                double pixel_area = (x_next - x_right) * y_delta;
-                const double trapezoid_width = x_right - x_left;
-                if (trapezoid_width > 0.0) {
-                    const double y_at_left = y0 + (x_left - x0) * recip;
-                    const double y_at_right = y0 + (x_right - x0) * recip;
-                    const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
-                                                              : (y_at_left - y_bottom) + (y_at_right - y_bottom);
-                    pixel_area += trapezoid_width * trapezoid_height / 2.0;
-                }
-                a_row[x - cx0] += sign * pixel_area;
-            }
-            s_row[x_to + 1 - cx0] += sign * y_delta;
-            x_min = min(x_min, x_from);
-            x_max = max(x_max, x_to + 1);
+            const osmt_label_seg sg = label_seg_prep(segs[si]);
+            if (!active || y < sg.yf || y > sg.yl) continue;
+            oob |= !label_stripe(sg, y, cx0, cols, a_row, s_row, x_min, x_max);
         }
-        /* save_to_figure (:115-147) for this stripe: keys span [x_min, x_max] */
         if (active && x_min <= x_max) {
             double s_acc = 0.0;
             for (int32_t x = x_min; x <= x_max; ++x) {
@@ -1349,26 +1562,35 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                 a_row[x - cx0] = fmin(a_row[x - cx0] + s_acc, 1.0);
             }
         }
-        if (oob) atomicOr(g_err, 1u);
         __syncthreads();
     }
+    if (oob) atomicOr(g_err, 1u);
 }
 
 #define OSMT_LABEL_RESOLVE_THREADS 256
+/* LDS_BM: the (3W)^2-bit ownership map lives in LDS (scale 1: 72 KB); otherwise in global memory. */
+template <bool LDS_BM>
 __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
     const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_job_label_off, uint32_t n_jobs, uint32_t scale,
-    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok) {
+    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok, osmt_tile_label* __restrict__ g_tl,
+    uint32_t* __restrict__ g_tl_cnt) {
+    extern __shared__ uint32_t sh_bm[];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_jobs) return;
     const uint32_t tid = threadIdx.x;
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
     const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
     const size_t words = ((size_t)EW * EW + 31u) / 32u;
-    uint32_t* bm = g_bitmap + (size_t)tile * words;
+    uint32_t* bm = LDS_BM ? sh_bm : g_bitmap + (size_t)tile * words;
     for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
-    __threadfence();
+    if (!LDS_BM) __threadfence();
     __syncthreads();
+    auto test = [&](uint32_t bit) -> bool {
+        if (LDS_BM) return (bm[bit >> 5] >> (bit & 31u)) & 1u;
+        return (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+    };
     const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
+    uint32_t n_out = 0; /* thread 0: succeeded labels that reach into the tile itself */
     for (uint32_t l = l0; l < l1; ++l) {
         const osmt_labelinfo* __restrict__ li = g_lab + l;
         const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
@@ -1378,6 +1600,7 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
         const uint32_t cols = li->cols;
         const uint32_t n_cells = has_cells ? (uint32_t)(li->ry1 - ry0 + 1) * cols : 0u;
         const double* __restrict__ A = g_a + li->plane_off;
+        bool failed = false;
         for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
             bool hit = false;
             for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
@@ -1385,7 +1608,7 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
                 if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
                 const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
                 if (pass == 0)
-                    hit |= (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+                    hit |= test(bit);
                 else
                     atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
             }
@@ -1395,20 +1618,40 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
                 if (x < -W || x >= 2 * W) continue; /* rows are clipped already */
                 const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
                 if (pass == 0)
-                    hit |= (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+                    hit |= test(bit);
                 else
                     atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
             }
             if (pass == 0) {
-                const int failed = __syncthreads_or(hit ? 1 : 0);
+                failed = __syncthreads_or(hit ? 1 : 0) != 0;
                 if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
                 if (failed) break;
             } else {
-                __threadfence();
+                if (!LDS_BM) __threadfence();
                 __syncthreads();
             }
         }
+        if (!failed && tid == 0) {
+            /* what k_raster has to look at: the label's pixels clipped to the tile [0, W)^2 */
+            int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+            if (has_cells) {
+                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = li->ry1;
+            }
+            if (iw) {
+                bx0 = min(bx0, ix0), bx1 = max(bx1, ix0 + (int32_t)iw - 1);
+                by0 = min(by0, iy0), by1 = max(by1, iy0 + (int32_t)ih - 1);
+            }
+            bx0 = max(bx0, 0), by0 = max(by0, 0), bx1 = min(bx1, W - 1), by1 = min(by1, W - 1);
+            if (bx0 <= bx1 && by0 <= by1) {
+                osmt_tile_label e;
+                e.x0 = (int16_t)bx0, e.y0 = (int16_t)by0, e.x1 = (int16_t)bx1, e.y1 = (int16_t)by1;
+                e.label = l;
+                e._pad = 0;
+                g_tl[l0 + n_out++] = e;
+            }
+        }
     }
+    if (tid == 0) g_tl_cnt[tile] = n_out;
 }
 
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
@@ -1447,7 +1690,7 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     hipLaunchKernelGGL((k_raster<F64, BLK, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, \
                        a.rings, a.pts, a.trav, a.den, a.aux, a.opnv, a.op_blk, a.blk, a.submask, a.sub_rows, a.images,    \
                        a.image_pool, a.n_images, a.out, a.out_tile_stride, a.labels.info, a.labels.job_label_off,         \
-                       a.labels.ok, a.labels.plane)
+                       a.labels.tile_labels, a.labels.tile_label_cnt, a.labels.plane)
     if (out_f64) { /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
         if (a.has_blocks) OSMT_LAUNCH_RASTER(true, true, false); else OSMT_LAUNCH_RASTER(true, false, false);
     } else if (a.labels.info) {
@@ -1459,16 +1702,28 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     return hipGetLastError();
 }
 
-hipError_t osmt_launch_labels(const osmt_labelinfo* info, uint32_t n_labels, const uint32_t* job_label_off, uint32_t n_jobs,
-                              uint32_t scale, const double* segs, uint32_t n_segs, osmt_label_seg* prep, double* plane_a,
-                              double* plane_s, uint32_t* bitmap, uint8_t* ok, uint32_t* err, hipStream_t st) {
-    if (n_labels == 0 || n_jobs == 0) return hipSuccess;
-    if (n_segs)
-        hipLaunchKernelGGL(k_label_segprep, dim3((n_segs + 255u) / 256u), dim3(256), 0, st,
-                           reinterpret_cast<const double4*>(segs), n_segs, prep);
-    hipLaunchKernelGGL(k_label_cover, dim3(n_labels), dim3(64), 0, st, info, n_labels, prep, plane_a, plane_s, err);
-    hipLaunchKernelGGL(k_label_resolve, dim3(n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, info, job_label_off, n_jobs,
-                       scale, plane_a, bitmap, ok);
+hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
+    if (a.n_labels == 0 || a.n_jobs == 0) return hipSuccess;
+    const double4* segs = reinterpret_cast<const double4*>(a.segs);
+    hipLaunchKernelGGL(k_label_cover, dim3(a.n_labels), dim3(64), 0, st, a.info, a.n_labels, segs, a.plane_a, a.err);
+    if (a.n_wide)
+        hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
+                           a.plane_s_wide, a.err);
+    const size_t EW = 3u * (size_t)OSMT_TILE_SIZE * a.scale;
+    const size_t bm_bytes = ((EW * EW + 31u) / 32u) * 4u;
+    if (bm_bytes <= 96u * 1024u) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), bm_bytes, st, a.info,
+                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+    } else {
+        hipLaunchKernelGGL(k_label_resolve<false>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, a.info,
+                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+    }
     return hipGetLastError();
 }
 
