@@ -27,6 +27,14 @@
  *                         the crop, inner ring fitted; the hole drawn as a separate op differs)
  *     Inputs were FITTED (the .osm is missing); +-1 px / reversed inputs do not match — see
  *     tests/golden/make_ref_patches.py for what that does and does not prove.
+ *   - label pass (font/rasterizer.rs, tile_pixels.rs:131-162 + the for_labels blend, labeler.rs:91-106):
+ *     PINNED by the metro-station label "Арбатская" of tests/rendered/17_expected.png — icon + 9 glyphs,
+ *     1135 compared pixels, 0 differ — with NOTHING fitted but the node's integer position (read off the
+ *     icon): outlines and metrics come from the reference's own font through a restatement of the
+ *     stb_truetype calls text_placer.rs makes (tests/golden/make_ref_label_patches.py,
+ *     tests/test_reference_golden_labels.py).  A 0.1-px text offset no longer matches.  Not covered by a
+ *     reference output: labels that COLLIDE (hand-derived cases in tests/test_labels_oracle.py, from the
+ *     reference source) and TextPosition::Line placement (host side, outside the oracle).
  *   - NOT pinned by any reference output (the reference cannot be built here — no rustc/cargo,
  *     crates not vendored — and tests/osm/nano_moscow.osm is absent): Square/Butt caps,
  *     use_caps_for_dashes = false, image fills.  For these the
