@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--n-line", type=int, default=40, help="diagnostic: polylines per tile (default = the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
+    ap.add_argument("--no-labels", action="store_true")
+    ap.add_argument("--label-tiles", type=int, default=256)
     args = ap.parse_args()
 
     import numpy as np
@@ -185,6 +187,82 @@ def main():
             "tiles_per_launch": n,
         }
         del planes, cout
+
+    # ---- label pass on top of the same area workload — rank 0, N = 1 only ----
+    if rank == 0 and world == 1 and not args.no_labels:
+        from osm_renderer_amd import labels as labels_mod
+
+        n = args.label_tiles
+        pool = min(32, n)
+        sizes = [(16, 16), (12, 20), (20, 20)]
+        rng = np.random.default_rng(1)
+        first_img = None
+        for h, w in sizes:
+            iid = ctx.register_image(rng.integers(0, 256, size=(h, w, 4)).astype(np.uint8))
+            first_img = iid if first_img is None else first_img
+        base = labels_mod.make_labels(pool, labels_per_tile=24, scale=args.scale, n_images=3, image_sizes=sizes, seed=2)
+        base.labels["image_id"] += first_img
+        ll = labels_mod.concat_labels([base.subset([i % pool]) for i in range(n)])
+        ldl = synth.make_tiles(synth.config_tiles(n), zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
+        lscene = ctx.upload(ldl)
+        lout = torch.empty((n, ldl.dim, ldl.dim, 4), dtype=torch.uint8, device=dev)
+
+        def timed(reps=10):
+            for _ in range(2):
+                ctx.render(lscene, lout)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ctx.render(lscene, lout)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        ms_plain = timed()
+        lscene.set_labels(ll)
+        ms_lab = timed()
+        ok = lscene.label_status()
+        d_ms = max(ms_lab - ms_plain, 1e-6)
+        result["label_pass"] = {
+            "workload": f"{n} config-2 tiles + 24 synthetic labels per tile (TrueType-like outlines flattened like draw_quad; "
+                        "40 % with an icon, 30 % rotated), pool of 32 tiles repeated",
+            "labels": int(len(ll.labels)),
+            "draw_line_calls": int(len(ll.segs)),
+            "labels_succeeded": int(ok.sum()),
+            "ms_areas_only": ms_plain,
+            "ms_with_labels": ms_lab,
+            "label_pass_ms": d_ms,
+            "labels_per_s": len(ll.labels) / d_ms * 1e3,
+            "draw_line_calls_per_s": len(ll.segs) / d_ms * 1e3,
+            "tiles_per_s_with_labels": n / ms_lab * 1e3,
+            "algorithmic_bytes": ll.algorithmic_bytes(),
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle_py
+
+            oracle_py.build()
+            nt = min(16, os.cpu_count() or 1)
+            sub_dl, sub_ll = ldl.subset(range(pool)), ll.subset(range(pool))
+
+            def best(fn, reps=3):
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts)
+
+            t_plain = best(lambda: oracle_py.render_batch(sub_dl, threads=nt))
+            t_lab = best(lambda: oracle_py.render_batch(sub_dl, threads=nt, labels=sub_ll))
+            cpu_s = max(t_lab - t_plain, 1e-9)
+            result["label_pass"]["cpu_baseline"] = {
+                "value": len(sub_ll.labels) / cpu_s, "unit": "labels/s", "cores": nt, "kind": "port",
+                "sample": f"{pool} tiles, {len(sub_ll.labels)} labels: oracle render with labels ({t_lab:.3f} s) minus "
+                          f"without ({t_plain:.3f} s), best of 3 each",
+            }
+        lscene.free()
+        del lout
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N = 1 only) ---------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -35,6 +35,7 @@
 #define OSMT_DRAW_HPP
 
 #include <cstdint>
+#include <cmath>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -120,6 +121,9 @@ class TilePixels {
         dashes_.clear();
         canvas_ = canvas_color;
         pending_op_ = false;
+        labels_.clear();
+        label_segs_.clear();
+        pending_label_ = osmt_label{};
     }
     /* drawer.rs:218: closes the current area; an area that drew nothing still counts */
     void bump_generation() {
@@ -132,6 +136,13 @@ class TilePixels {
     }
     /* tile_pixels.rs:154-158: a no-op for a recorder (blending happens on the GPU, in order) */
     void blend_unfinished_pixels(bool /*for_labels*/) {}
+    /* tile_pixels.rs:160-162: closes the current label (one Labeler::label_entity call, labeler.rs:16-38).
+     * The verdict itself is computed on the GPU (set_label_pixel's collision rule needs every earlier label);
+     * the argument is accepted for source compatibility and ignored. */
+    void bump_label_generation(bool /*succeeded*/) {
+        labels_.push_back(pending_label_);
+        pending_label_ = osmt_label{};
+    }
     size_t dimension() const { return TILE_SIZE * scale_; } /* tile_pixels.rs:183-185 */
     size_t scale() const { return scale_; }
 
@@ -141,7 +152,9 @@ class TilePixels {
         osmt_batch b = make_batch(&job, 1, ops_, rings_, points_, dashes_);
         const size_t dim = dimension();
         std::vector<uint8_t> rgba(dim * dim * 4);
-        check(osmt_render_batch(ctx_->raw(), &b, rgba.data(), rgba.size()));
+        const uint32_t off[2] = {0u, (uint32_t)labels_.size()};
+        osmt_label_batch lb{labels_.data(), labels_.size(), off, label_segs_.data(), label_segs_.size() / 4};
+        check(osmt_render_batch_labels(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgba.data(), rgba.size()));
         RgbTriples out(dim * dim);
         for (size_t i = 0; i < dim * dim; ++i) out[i] = {rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]};
         return out;
@@ -149,6 +162,8 @@ class TilePixels {
 
   private:
     friend class TileBatch;
+    friend class Rasterizer;
+    friend bool draw_icon(uint32_t, double, double, TilePixels&);
     friend void fill_contour(const PointPairs&, const Filler&, double, TilePixels&);
     friend void draw_lines(const PointPairs&, double, const Color&, double, const std::optional<std::vector<double>>&,
                            const std::optional<LineCap>&, bool, TilePixels&);
@@ -226,6 +241,67 @@ class TilePixels {
     std::vector<int32_t> points_;
     std::vector<double> dashes_;
     bool pending_op_ = false;
+    std::vector<osmt_label> labels_;
+    std::vector<double> label_segs_; /* x0, y0, x1, y1 per Rasterizer::draw_line call */
+    osmt_label pending_label_{};
+};
+
+/* Labeler::draw_icon (labeler.rs:91-106): the icon of the label being built, centred at
+ * get_label_position.  Always true here: collisions are resolved on the GPU, in label order. */
+inline bool draw_icon(uint32_t image_id, double center_x, double center_y, TilePixels& pixels) {
+    pixels.pending_label_.has_icon = 1;
+    pixels.pending_label_.image_id = image_id;
+    pixels.pending_label_.icon_center_x = center_x;
+    pixels.pending_label_.icon_center_y = center_y;
+    return true;
+}
+
+/* font/rasterizer.rs: the glyph walk of TextPlacer::place calls draw_line / draw_quad exactly as in the
+ * reference; the calls are recorded (curves flattened here, with the same libm hypot) and replayed on
+ * the GPU, which owns the exact-area accumulation and save_to_figure's pixel loop. */
+class Rasterizer {
+  public:
+    explicit Rasterizer(const Color& color) : color_(color) {}
+    /* :27-88 */
+    void draw_line(double x0, double y0, double x1, double y1) {
+        segs_.push_back(x0);
+        segs_.push_back(y0);
+        segs_.push_back(x1);
+        segs_.push_back(y1);
+    }
+    /* :90-113 */
+    void draw_quad(double x0, double y0, double x1, double y1, double x2, double y2) {
+        auto dist_between = [](double xa, double ya, double xb, double yb) { return std::hypot(std::fabs(xa - xb), std::fabs(ya - yb)); };
+        const double d01 = dist_between(x0, y0, x1, y1);
+        const double d12 = dist_between(x1, y1, x2, y2);
+        const double d02 = dist_between(x0, y0, x2, y2);
+        if ((d01 + d12) <= 1.0001 * d02) {
+            draw_line(x0, y0, x2, y2);
+            return;
+        }
+        auto midpoint = [](double c1, double c2) { return (c1 + c2) / 2.0; };
+        const double m01_x = midpoint(x0, x1), m01_y = midpoint(y0, y1);
+        const double m12_x = midpoint(x1, x2), m12_y = midpoint(y1, y2);
+        const double m012_x = midpoint(m01_x, m12_x), m012_y = midpoint(m01_y, m12_y);
+        draw_quad(x0, y0, m01_x, m01_y, m012_x, m012_y);
+        draw_quad(m012_x, m012_y, m12_x, m12_y, x2, y2);
+    }
+    /* :115-147: hands the text of the label being built to the canvas.  Always true (see draw_icon). */
+    bool save_to_figure(TilePixels& pixels) const {
+        osmt_label& l = pixels.pending_label_;
+        l.has_text = 1;
+        l.text_color[0] = color_.r;
+        l.text_color[1] = color_.g;
+        l.text_color[2] = color_.b;
+        l.seg_off = (uint32_t)(pixels.label_segs_.size() / 4);
+        l.n_segs = (uint32_t)(segs_.size() / 4);
+        pixels.label_segs_.insert(pixels.label_segs_.end(), segs_.begin(), segs_.end());
+        return true;
+    }
+
+  private:
+    Color color_;
+    std::vector<double> segs_;
 };
 
 /* fill.rs:16 */
@@ -291,6 +367,13 @@ class TileBatch {
         }
         points_.insert(points_.end(), px.points_.begin(), px.points_.end());
         dashes_.insert(dashes_.end(), px.dashes_.begin(), px.dashes_.end());
+        const uint32_t seg_off = (uint32_t)(label_segs_.size() / 4);
+        for (osmt_label l : px.labels_) {
+            if (l.n_segs) l.seg_off += seg_off;
+            labels_.push_back(l);
+        }
+        label_segs_.insert(label_segs_.end(), px.label_segs_.begin(), px.label_segs_.end());
+        label_off_.push_back((uint32_t)labels_.size());
     }
     std::vector<TileRenderedPixels> render() {
         const size_t dim = TILE_SIZE * scale_;
@@ -308,7 +391,8 @@ class TileBatch {
         b.n_pts = points_.size() / 2;
         b.dashes = dashes_.data();
         b.n_dashes = dashes_.size();
-        check(osmt_render_batch(ctx_->raw(), &b, rgba.data(), dim * dim * 4));
+        osmt_label_batch lb{labels_.data(), labels_.size(), label_off_.data(), label_segs_.data(), label_segs_.size() / 4};
+        check(osmt_render_batch_labels(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgba.data(), dim * dim * 4));
         std::vector<TileRenderedPixels> out(jobs_.size());
         for (size_t t = 0; t < jobs_.size(); ++t) {
             out[t].dimension = dim;
@@ -327,6 +411,9 @@ class TileBatch {
     std::vector<osmt_ring> rings_;
     std::vector<int32_t> points_;
     std::vector<double> dashes_;
+    std::vector<osmt_label> labels_;
+    std::vector<double> label_segs_;
+    std::vector<uint32_t> label_off_{0u};
 };
 
 }  // namespace osmt

@@ -35,6 +35,33 @@ static void draw_tile_a(TilePixels& px) {
     draw_lines(pairs({{0, 0}, {255, 255}}), 1.5, Color{0, 0, 0}, 1.0, std::nullopt, std::nullopt, false, px);
     px.bump_generation();
     px.blend_unfinished_pixels(false);
+    // label pass (drawer.rs:107-125): text only; a second label that collides with it; a curve
+    auto square = [](Rasterizer& r, double x0, double y0, double x1, double y1) {
+        r.draw_line(x0, y0, x0, y1);
+        r.draw_line(x0, y1, x1, y1);
+        r.draw_line(x1, y1, x1, y0);
+        r.draw_line(x1, y0, x0, y0);
+    };
+    {
+        Rasterizer r(Color{102, 102, 255});
+        square(r, 40.25, 40.5, 70.75, 52.125);
+        r.save_to_figure(px);
+        px.bump_label_generation(true);
+    }
+    {
+        Rasterizer r(Color{255, 0, 0});
+        square(r, 60, 45, 90, 60);
+        r.save_to_figure(px);
+        px.bump_label_generation(true);
+    }
+    {
+        Rasterizer r(Color{0, 0, 0});
+        r.draw_line(150, 150, 150, 180);
+        r.draw_quad(150, 180, 190, 165, 150, 150);
+        r.save_to_figure(px);
+        px.bump_label_generation(true);
+    }
+    px.blend_unfinished_pixels(true);
 }
 
 static void draw_tile_b(TilePixels& px) {

@@ -13,28 +13,34 @@ BIN = os.path.join(ROOT, "tests", "_build", "host_mirror_demo")
 
 
 def _oracle_tiles(oracle):
-    a = oracle.Pixels(1)
-    a.reset((241, 238, 232))
-    a.fill_contour(oracle.ring_to_pairs([(10, 10), (200, 30), (150, 220), (20, 180), (10, 10)]), (200, 40, 40), 0.6)
-    a.bump_generation()
-    a.bump_generation()
-    mp = np.concatenate([oracle.ring_to_pairs([(60, 60), (120, 70), (100, 130), (60, 60)]),
-                         oracle.ring_to_pairs([(300, 300), (310, 300), (305, 320), (300, 300)])])
-    a.fill_contour(mp, (20, 40, 220), 1.0)
-    a.bump_generation()
-    a.draw_lines(oracle.ring_to_pairs([(5, 250), (90, 120), (180, 200), (250, 20)]), 6.0, (10, 120, 10), 0.8,
-                 dashes=[9.0, 4.0], cap=abi.CAP_ROUND)
-    a.bump_generation()
-    a.draw_lines(oracle.ring_to_pairs([(0, 0), (255, 255)]), 1.5, (0, 0, 0), 1.0)
-    a.bump_generation()
-    a.blend_unfinished_pixels()
+    from osm_renderer_amd import labels
+    from osm_renderer_amd.display_list import TileBuilder
+
+    tb = TileBuilder(canvas=(241, 238, 232))
+    tb.fill([[(10, 10), (200, 30), (150, 220), (20, 180), (10, 10)]], (200, 40, 40), 0.6)
+    tb.nop()
+    tb.fill([[(60, 60), (120, 70), (100, 130), (60, 60)], [(300, 300), (310, 300), (305, 320), (300, 300)]], (20, 40, 220), 1.0)
+    tb.stroke([(5, 250), (90, 120), (180, 200), (250, 20)], 6.0, (10, 120, 10), 0.8, dashes=[9.0, 4.0], cap=abi.CAP_ROUND)
+    tb.stroke([(0, 0), (255, 255)], 1.5, (0, 0, 0), 1.0)
+
+    def square(x0, y0, x1, y1):
+        return [(x0, y0, x0, y1), (x0, y1, x1, y1), (x1, y1, x1, y0), (x1, y0, x0, y0)]
+
+    tl = labels.TileLabels()
+    tl.label(text=((102, 102, 255), square(40.25, 40.5, 70.75, 52.125)))
+    tl.label(text=((255, 0, 0), square(60, 45, 90, 60)))  # collides with the first one
+    curve = [(150, 150, 150, 180)]
+    labels.flatten_quad(150, 180, 190, 165, 150, 150, curve)
+    tl.label(text=((0, 0, 0), curve))
+    ta, st = oracle.render_job(tb.build(), 0, labels=tl.build(), want_status=True)
+    assert st.tolist() == [1, 0, 1]
     b = oracle.Pixels(1)
     b.reset(None)
     b.draw_lines(oracle.ring_to_pairs([(30, 30), (220, 60)]), 12.0, (255, 200, 0), 0.5, cap=abi.CAP_SQUARE,
                  use_caps_for_dashes=True)
     b.bump_generation()
     b.blend_unfinished_pixels()
-    return a.to_rgb(), b.to_rgb()
+    return ta[..., :3], b.to_rgb()
 
 
 def test_host_mirror_builds():
