@@ -11,3 +11,11 @@ def test_fuzz_short(gpu_ctx, oracle):
 
     tiles, bad = fuzz_parity.run(budget=8.0, seed=2026, ctx=gpu_ctx, dump=False)
     assert tiles >= 12 and bad == 0
+
+
+def test_fuzz_short_with_labels(gpu_ctx, oracle):
+    """the same with a random label pass per tile: adversarial draw_line calls, icons, collisions, wide windows"""
+    from tools import fuzz_parity
+
+    tiles, bad = fuzz_parity.run(budget=8.0, seed=77, ctx=gpu_ctx, dump=False, with_labels=True)
+    assert tiles >= 12 and bad == 0

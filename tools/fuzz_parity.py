@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised GPU-vs-oracle differential fuzzing beyond the pytest suite (run on a GPU box).
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [labels]
 
 Random tiles with adversarial parameters: widths 0..40, all directions, tiny / huge dashes, every
 cap, use_caps_for_dashes, scales 1..3, far-away and huge coordinates, self-intersecting and
@@ -59,19 +59,98 @@ def make_tile(scale):
     return tb.build()
 
 
-def run(budget=60.0, seed=1, ctx=None, dump=True):
+def rand_label_text(scale):
+    """adversarial draw_line calls: random polygons with float / integer / half-integer vertices, long and tiny edges,
+    horizontal and degenerate ones, overlapping contours, both orientations, occasionally a contour far to the side"""
+    from osm_renderer_amd import labels as L
+
+    W = 256 * scale
+    mode = int(rnd.integers(0, 6))
+    if mode == 0:  # synthetic glyph run, maybe rotated
+        segs, _ = L.synth_text(rnd, float(rnd.uniform(-W / 2, 1.5 * W)), float(rnd.uniform(-W / 2, 1.5 * W)),
+                               float(rnd.choice([7.0, 10.0, 13.0, 22.0])) * scale, int(rnd.integers(1, 9)),
+                               float(rnd.choice([0.0, 0.0, rnd.uniform(-3.1, 3.1)])))
+        return segs
+    out = []
+    for _ in range(int(rnd.integers(1, 5))):
+        n = int(rnd.integers(2, 9))
+        c = rnd.uniform(-W / 2, 1.5 * W, size=2)
+        r = float(rnd.choice([0.3, 2.0, 9.0, 40.0, 300.0]))
+        pts = c + rnd.uniform(-r, r, size=(n, 2))
+        q = int(rnd.integers(0, 4))
+        if q == 0:
+            pts = np.round(pts)
+        elif q == 1:
+            pts = np.round(pts * 2) / 2
+        if mode == 5 and rnd.random() < 0.3:
+            pts[:, 0] -= 3000.0  # far to the side, same stripes: the wide-window path
+        if rnd.random() < 0.3:
+            pts[int(rnd.integers(0, n))] = pts[int(rnd.integers(0, n))]  # zero-length edge
+        if rnd.random() < 0.3:
+            pts[1, 1] = pts[0, 1]  # horizontal edge
+        closed = np.concatenate([pts, pts[:1]])
+        if rnd.random() < 0.5:
+            closed = closed[::-1]
+        for a, b in zip(closed[:-1], closed[1:]):
+            out.append((a[0], a[1], b[0], b[1]))
+    return np.array(out, dtype=np.float64).reshape(-1, 4)
+
+
+def make_labels(n_tiles, scale, image_ids, image_sizes):
+    from osm_renderer_amd import labels as L
+
+    W = 256 * scale
+    out = []
+    for _ in range(n_tiles):
+        tl = L.TileLabels()
+        for _ in range(int(rnd.integers(0, 25))):
+            icon = text = None
+            if image_ids and rnd.random() < 0.4:
+                k = int(rnd.integers(0, len(image_ids)))
+                icon = (image_ids[k] if rnd.random() < 0.95 else 99999, float(rnd.uniform(-1.2 * W, 2.2 * W)) + float(rnd.choice([0.0, 0.5])),
+                        float(rnd.uniform(-1.2 * W, 2.2 * W)))
+            if rnd.random() < 0.8:
+                text = (tuple(int(v) for v in rnd.integers(0, 256, size=3)), rand_label_text(scale))
+            tl.label(icon=icon, text=text)
+        out.append(tl.build())
+    return L.concat_labels(out)
+
+
+def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
     """Fuzz for `budget` seconds; returns (tiles rendered, mismatching tiles)."""
     global rnd
     rnd = np.random.default_rng(seed)
     ctx = ctx or Context(0)
+    images, image_ids, sizes = [], [], ((16, 16), (9, 9), (5, 23))
+    if with_labels:
+        arrays = []
+        for h, w in sizes:
+            img = rnd.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
+            img[: h // 2, :, 3] = 255
+            arrays.append(img)
+            image_ids.append(ctx.register_image(img))
+        images = [np.zeros((1, 1, 4), dtype=np.uint8) for _ in range(max(image_ids) + 1)]  # ids are registry positions
+        for i, img in zip(image_ids, arrays):
+            images[i] = img
     t0 = time.time()
     n_tiles = n_bad = 0
     while time.time() - t0 < budget:
         scale = int(rnd.choice([1, 1, 2, 3]))
         tiles = [make_tile(scale) for _ in range(12)]
         dl = display_list.concat(tiles)
-        got = ctx.render_batch_host(dl)
-        want = O.render_batch(dl, threads=12)
+        ll = make_labels(len(tiles), scale, image_ids, sizes) if with_labels else None
+        if ll is not None:
+            scene = ctx.upload(dl, ll)
+            got = ctx.render(scene).cpu().numpy()
+            st = scene.label_status()
+            scene.free()
+            want, wst = O.render_batch(dl, threads=12, images=images, labels=ll, want_status=True)
+            if not np.array_equal(st, wst):
+                n_bad += 1
+                print(f"LABEL STATUS MISMATCH seed={seed} after {n_tiles} tiles: labels {np.nonzero(st != wst)[0][:8].tolist()}")
+        else:
+            got = ctx.render_batch_host(dl)
+            want = O.render_batch(dl, threads=12)
         n_tiles += len(tiles)
         if not np.array_equal(got, want):
             for i in range(len(tiles)):
@@ -87,10 +166,15 @@ def run(budget=60.0, seed=1, ctx=None, dump=True):
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_coords.npy", tiles[i].coords)
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_dashes.npy", tiles[i].dashes)
                     np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_rings.npy", tiles[i].rings)
+                    if ll is not None:
+                        one = ll.subset([i])
+                        np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_labels.npy", one.labels)
+                        np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_segs.npy", one.segs)
     print(f"fuzz: {n_tiles} tiles in {time.time() - t0:.0f} s, {n_bad} mismatching tiles (seed {seed})")
     return n_tiles, n_bad
 
 
 if __name__ == "__main__":
-    _, bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    _, bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                 with_labels=len(sys.argv) > 3 and sys.argv[3] == "labels")
     sys.exit(1 if bad else 0)
