@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
             while (heads) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(heads);
                 heads &= heads - 1ull;
-                const uint32_t run = 1u + (j < 63u ? (uint32_t)__builtin_ctzll(~(sp >> (j + 1u))) : 0u);
+                const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((sp >> 1) >> j)); /* bit 63 of sp >> 1 is clear: finite */
                 const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j);
                 if (nj == LC_SLOW) {
                     osmt_label_seg q;
@@ -1468,6 +1468,35 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     }
                     continue;
                 }
+                if (nj == 2u) {
+                    /* the common call: one cell (A key) + its S key, same stripe, same owner: both sums in one loop */
+                    const uint32_t ka = (uint32_t)__builtin_amdgcn_readlane((int)ekey[0], (int)j);
+                    const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)ekey[1], (int)j);
+                    if ((ka >> 31) == 0u && (ks >> 31) == 1u && ((ka ^ ks) & 0x7FF00000u) == 0u) {
+                        if (((ka >> 20) & 0x7FFu) == lane) {
+                            const uint32_t ca = ka & 0xFFFFFu, cs = ks & 0xFFFFFu;
+                            if (ca != a_col) {
+                                if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+                                a_val = a_row[ca];
+                                a_col = ca;
+                            }
+                            if (cs != s_col) {
+                                if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+                                s_val = s_row[cs];
+                                s_col = cs;
+                            }
+                            c_min = min(c_min, min(ca, cs));
+                            c_max = max(c_max, max(ca, cs));
+                            uint32_t src = j, left = run;
+                            do { /* v_readlane ignores EXEC: only the owner lane executes the run's adds */
+                                a_val += readlane_f64(eval[0], src);
+                                s_val += readlane_f64(eval[1], src);
+                                ++src;
+                            } while (--left);
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < LC_MAXE; ++e) {
                     if ((uint32_t)e < nj) {
@@ -1488,11 +1517,13 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                             c_min = min(c_min, col);
                             c_max = max(c_max, col);
                         }
-                        for (uint32_t t = 0; t < run; ++t) {
-                            const double v = readlane_f64(eval[e], j + t);
-                            if (mine) cur_val += v;
-                        }
                         if (mine) {
+                            /* v_readlane ignores EXEC: only the owner lane executes the run's adds */
+                            uint32_t src = j, left = run;
+                            do {
+                                cur_val += readlane_f64(eval[e], src);
+                                ++src;
+                            } while (--left);
                             s_col = is_s ? cur_col : s_col;
                             s_val = is_s ? cur_val : s_val;
                             a_col = is_s ? a_col : cur_col;
@@ -1712,12 +1743,10 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
     const size_t EW = 3u * (size_t)OSMT_TILE_SIZE * a.scale;
     const size_t bm_bytes = ((EW * EW + 31u) / 32u) * 4u;
     if (bm_bytes <= 96u * 1024u) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            attr_set = true;
-        }
+        /* per device and cheap: set on every launch rather than caching a process-wide flag */
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (ae != hipSuccess) return ae;
         hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), bm_bytes, st, a.info,
                            a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
     } else {
