@@ -137,3 +137,33 @@ def test_label_validation_errors(gpu_ctx):
     two = concat([dl, dl])
     with pytest.raises(AssertionError):
         gpu_ctx.upload(two, labels.TileLabels().build())
+
+
+def test_reference_icons_as_fill_patterns_and_label_icons(gpu_ctx, oracle):
+    """SURVEY.md 8(f) N4: the reference's own icon files (tests/golden/ref_icons.json) as Filler::Image patterns
+    (fill.rs:36-40, opacity ignored, x mod w / y mod h) and as label icons, GPU vs oracle."""
+    import json
+    import os
+
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_icons.json")))
+    names = [k for k in fix if not k.startswith("_")]
+    imgs = {n: np.array(fix[n]["rgba"], dtype=np.uint8) for n in names}
+    ids = {n: gpu_ctx.register_image(imgs[n]) for n in names}
+    all_imgs = [np.zeros((1, 1, 4), dtype=np.uint8) for _ in range(max(ids.values()) + 1)]
+    for n in names:
+        all_imgs[ids[n]] = imgs[n]
+    tb = TileBuilder(canvas=(0xF1, 0xEE, 0xE8))
+    tb.fill_image([(5, 5), (250, 20), (200, 120), (10, 100), (5, 5)], ids["forest.png"])
+    tb.fill_image([(20, 110), (240, 130), (230, 250), (30, 240), (20, 110)], ids["scrub.png"], opacity=0.25)
+    tb.fill_image([(100, 60), (180, 70), (170, 200), (90, 180), (100, 60)], ids["military_red_hz2.png"])  # translucent hatch over both
+    tb.fill_image([(-40, -40), (60, -10), (40, 70), (-30, 50), (-40, -40)], ids["grave_yard.png"])
+    tb.fill([[(150, 150), (250, 150), (250, 250), (150, 250), (150, 150)]], (20, 30, 200), 0.4)
+    dl = tb.build()
+    tl = labels.TileLabels()
+    tl.label(icon=(ids["cafe.p.16.png"], 60.0, 60.0), text=_text((0x73, 0x4A, 0x08), 50, 70, 72, 78))
+    tl.label(icon=(ids["station.png"], 200.5, 40.5))
+    tl.label(icon=(ids["station.png"], 204.0, 44.0))  # overlaps the previous icon: fails
+    tl.label(icon=(ids["orchard.png"], 128.0, 128.0))
+    got, st = _check(gpu_ctx, oracle, dl, tl.build(), all_imgs, "reference icons")
+    assert st.tolist() == [1, 1, 0, 1]
+    assert len(np.unique(got[0].reshape(-1, 4), axis=0)) > 50
