@@ -186,6 +186,13 @@ int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba,
 int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
                              size_t out_tile_stride_bytes);
 
+/* Pinned host memory for out_rgba: with it (or any hipHostMalloc'ed / hipHostRegister'ed buffer) and a batch of
+ * >= 256 tiles, osmt_render_batch[_labels] overlaps the kernels of one 128-tile chunk with the device-to-host
+ * copy of the previous one on a second stream (the per-GPU pipeline of SURVEY.md 8(e)); pageable buffers
+ * take one blocking copy at the end.  Analogue of the reference's per-worker output Vec (drawer.rs:27-30). */
+int osmt_host_alloc(osmt_ctx* ctx, size_t bytes, void** out_ptr);
+void osmt_host_free(osmt_ctx* ctx, void* ptr);
+
 /* ---- whole path, HBM-resident (the fast path) --------------------------- */
 int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* batch, osmt_scene** out_scene);
 void osmt_scene_free(osmt_scene* scene);

@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -171,7 +172,11 @@ int validate_batch(const osmt_batch* b) {
     return OSMT_OK;
 }
 
-int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, size_t stride, bool f64, void* stream) {
+/* stages: 1 = project, 2 = per-op pre-pass, 4 = raster (with the label kernels first when the scene has labels),
+ * 8 = label kernels only (cover + resolve), 16 = with 4: the label kernels already ran for this scene.
+ * [first_job, first_job + n_range) = tiles the raster stage renders into d_out (n_range 0: all). */
+int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, size_t stride, bool f64, void* stream,
+                uint32_t first_job = 0, uint32_t n_range = 0) {
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -183,13 +188,40 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
                                    sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_op_blk, sc->d_blk, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
+    const bool want_labels = sc->n_labels && !f64;
+    if (want_labels && ((stages & 8u) || ((stages & 4u) && !(stages & 16u)))) {
+        /* the label pass does not read the area canvas: coverage + collisions first, then
+         * k_raster blends the survivors right before to_rgb_triples */
+        int rc = sync_images(ctx);
+        if (rc != OSMT_OK) return rc;
+        osmt_label_launch ll;
+        memset(&ll, 0, sizeof ll);
+        ll.info = sc->d_lab;
+        ll.n_labels = sc->n_labels;
+        ll.n_jobs = sc->n_jobs;
+        ll.scale = sc->scale;
+        ll.n_wide = sc->n_lab_wide;
+        ll.job_label_off = sc->d_job_label_off;
+        ll.segs = sc->d_lab_segs;
+        ll.wide = sc->d_lab_wide;
+        ll.plane_a = sc->d_lab_a;
+        ll.plane_s_wide = sc->d_lab_s_wide;
+        ll.bitmap = sc->d_lab_bitmap;
+        ll.ok = sc->d_lab_ok;
+        ll.err = sc->d_lab_err;
+        ll.tile_labels = sc->d_tile_labels;
+        ll.tile_label_cnt = sc->d_tile_label_cnt;
+        HIP_TRY(osmt_launch_labels(ll, st));
+    }
     if (stages & 4u) {
         int rc = sync_images(ctx);
         if (rc != OSMT_OK) return rc;
+        if (first_job > sc->n_jobs || n_range > sc->n_jobs - first_job) return fail(OSMT_INVALID_ARG, "tile range out of bounds");
+        const uint32_t n_render = n_range ? n_range : sc->n_jobs - first_job;
         osmt_raster_args a;
         memset(&a, 0, sizeof a);
-        a.jobs = sc->d_jobs;
-        a.n_jobs = sc->n_jobs;
+        a.jobs = sc->d_jobs + first_job;
+        a.n_jobs = n_render;
         a.scale = sc->scale;
         a.ops = sc->d_ops;
         a.info = sc->d_info;
@@ -209,32 +241,12 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.n_images = (uint32_t)ctx->images.size();
         a.out = d_out;
         a.out_tile_stride = stride;
-        if (sc->n_labels && !f64) {
-            /* the label pass does not read the area canvas: coverage + collisions first, then
-             * k_raster blends the survivors right before to_rgb_triples */
-            osmt_label_launch ll;
-            memset(&ll, 0, sizeof ll);
-            ll.info = sc->d_lab;
-            ll.n_labels = sc->n_labels;
-            ll.n_jobs = sc->n_jobs;
-            ll.scale = sc->scale;
-            ll.n_wide = sc->n_lab_wide;
-            ll.job_label_off = sc->d_job_label_off;
-            ll.segs = sc->d_lab_segs;
-            ll.wide = sc->d_lab_wide;
-            ll.plane_a = sc->d_lab_a;
-            ll.plane_s_wide = sc->d_lab_s_wide;
-            ll.bitmap = sc->d_lab_bitmap;
-            ll.ok = sc->d_lab_ok;
-            ll.err = sc->d_lab_err;
-            ll.tile_labels = sc->d_tile_labels;
-            ll.tile_label_cnt = sc->d_tile_label_cnt;
-            HIP_TRY(osmt_launch_labels(ll, st));
+        if (want_labels) {
             a.labels.info = sc->d_lab;
             a.labels.n_labels = sc->n_labels;
-            a.labels.job_label_off = sc->d_job_label_off;
+            a.labels.job_label_off = sc->d_job_label_off + first_job; /* values stay absolute label indices */
             a.labels.tile_labels = sc->d_tile_labels;
-            a.labels.tile_label_cnt = sc->d_tile_label_cnt;
+            a.labels.tile_label_cnt = sc->d_tile_label_cnt + first_job;
             a.labels.plane = sc->d_lab_a;
         }
         HIP_TRY(osmt_launch_raster(a, f64, st));
@@ -621,6 +633,65 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
         osmt_scene_free(sc);
         return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
     }
+    /* Output in pinned host memory (osmt_host_alloc / hipHostMalloc / a registered range) and a batch worth
+     * splitting: kernels of chunk k overlap the D2H copy of chunk k-1 on a second stream. */
+    bool pinned = false;
+    if (batch->n_jobs >= 2u * std::max<uint32_t>(1u, 128u / (batch->scale * batch->scale))) { /* the query is not free: only where it can pay */
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, out_rgba) == hipSuccess)
+            pinned = at.type == hipMemoryTypeHost;
+        else
+            (void)hipGetLastError();
+    }
+    const uint32_t chunk = std::max<uint32_t>(1u, 128u / (batch->scale * batch->scale));
+    if (pinned && batch->n_jobs >= 2u * chunk) {
+        hipStream_t s_k = nullptr, s_c = nullptr;
+        hipEvent_t done[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
+        char* d_out = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_c, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipMalloc((void**)&d_out, 2 * (size_t)chunk * tile_bytes);
+        if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "pipeline setup failed: %s", hipGetErrorString(e));
+        if (rc == OSMT_OK) rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, s_k);
+        uint32_t c = 0;
+        for (uint32_t first = 0; rc == OSMT_OK && first < batch->n_jobs; first += chunk, ++c) {
+            const uint32_t cnt = (uint32_t)std::min<size_t>(chunk, batch->n_jobs - first);
+            const int k = (int)(c & 1u);
+            char* dst = d_out + (size_t)k * chunk * tile_bytes;
+            if (c >= 2) e = hipStreamWaitEvent(s_k, freed[k], 0);
+            if (e == hipSuccess) rc = render_impl(ctx, sc, 4u | 16u, dst, tile_bytes, false, s_k, first, cnt);
+            if (rc != OSMT_OK) break;
+            if (e == hipSuccess) e = hipEventRecord(done[k], s_k);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s_c, done[k], 0);
+            if (e == hipSuccess) {
+                if (stride == tile_bytes) /* tightly packed tiles: one linear copy (2D copies are slower) */
+                    e = hipMemcpyAsync(out_rgba + (size_t)first * stride, dst, (size_t)cnt * tile_bytes, hipMemcpyDeviceToHost, s_c);
+                else
+                    e = hipMemcpy2DAsync(out_rgba + (size_t)first * stride, stride, dst, tile_bytes, tile_bytes, cnt,
+                                         hipMemcpyDeviceToHost, s_c);
+            }
+            if (e == hipSuccess) e = hipEventRecord(freed[k], s_c);
+            if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "pipelined readback failed: %s", hipGetErrorString(e));
+        }
+        if (s_k) (void)hipStreamSynchronize(s_k);
+        if (s_c) {
+            e = hipStreamSynchronize(s_c);
+            if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "pipelined readback failed: %s", hipGetErrorString(e));
+        }
+        for (int k = 0; k < 2; ++k) {
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            if (freed[k]) (void)hipEventDestroy(freed[k]);
+        }
+        if (d_out) (void)hipFree(d_out);
+        if (s_k) (void)hipStreamDestroy(s_k);
+        if (s_c) (void)hipStreamDestroy(s_c);
+        osmt_scene_free(sc);
+        return rc;
+    }
     void* d_out = nullptr;
     if (batch->n_jobs) {
         hipError_t e = hipMalloc(&d_out, batch->n_jobs * tile_bytes);
@@ -632,13 +703,31 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, nullptr);
     if (rc == OSMT_OK && batch->n_jobs) {
         hipError_t e = hipDeviceSynchronize();
-        if (e == hipSuccess)
-            e = hipMemcpy2D(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            if (stride == tile_bytes)
+                e = hipMemcpy(out_rgba, d_out, batch->n_jobs * tile_bytes, hipMemcpyDeviceToHost);
+            else
+                e = hipMemcpy2D(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost);
+        }
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
     if (d_out) (void)hipFree(d_out);
     osmt_scene_free(sc);
     return rc;
+}
+
+int osmt_host_alloc(osmt_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return OSMT_OK;
+}
+
+void osmt_host_free(osmt_ctx* ctx, void* p) {
+    if (!ctx || !p) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
 }
 
 int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tx, uint32_t ty, double scale,

@@ -136,10 +136,27 @@ class Context:
         check(load().osmt_scene_read_points(self._h, scene._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
-    def render_batch_host(self, dl: DisplayList, labels=None):
-        """osmt_render_batch / osmt_render_batch_labels: host buffers in, host RGBA8 out."""
+    def host_alloc(self, shape, dtype=np.uint8):
+        """osmt_host_alloc: a pinned numpy array (free it with host_free)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(load().osmt_host_alloc(self._h, n, C.byref(p)))
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        load().osmt_host_free(self._h, p)
+
+    def render_batch_host(self, dl: DisplayList, labels=None, out=None):
+        """osmt_render_batch / osmt_render_batch_labels: host buffers in, host RGBA8 out (`out`: e.g. host_alloc())."""
         b = dl.as_batch()
-        out = np.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
+        if out is None:
+            out = np.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
+        assert out.shape == (dl.n_jobs, dl.dim, dl.dim, 4) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
         if labels is None:
             check(load().osmt_render_batch(self._h, C.byref(b), out.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 4))
         else:

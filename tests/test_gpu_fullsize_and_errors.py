@@ -94,3 +94,29 @@ def test_empty_batch(gpu_ctx):
     dl.jobs = dl.jobs[:0]
     out = gpu_ctx.render_batch_host(dl)
     assert out.shape[0] == 0
+
+
+def test_pinned_output_takes_the_overlapped_chunk_pipeline(gpu_ctx, oracle):
+    """osmt_render_batch[_labels] into osmt_host_alloc memory with >= 256 tiles: kernels of one 128-tile chunk
+    overlap the D2H copy of the previous one; pixels equal the one-shot path and the oracle."""
+    from osm_renderer_amd import labels, synth
+
+    n = 300  # 128 + 128 + 44: a ragged last chunk
+    dl = synth.make_tiles(synth.config_tiles(n), n_poly=6, n_line=6)
+    pool = labels.make_labels(10, labels_per_tile=5, seed=21)
+    ll = labels.concat_labels([pool.subset([i % 10]) for i in range(n)])
+    pin = gpu_ctx.host_alloc((n, dl.dim, dl.dim, 4))
+    try:
+        pin[:] = 7
+        a = gpu_ctx.render_batch_host(dl, out=pin).copy()
+        b = gpu_ctx.render_batch_host(dl)  # pageable: single copy
+        assert np.array_equal(a, b)
+        pin[:] = 9
+        c = gpu_ctx.render_batch_host(dl, labels=ll, out=pin).copy()
+        d = gpu_ctx.render_batch_host(dl, labels=ll)
+        assert np.array_equal(c, d) and not np.array_equal(a, c)
+        idx = [0, 127, 128, 255, 256, 299]
+        want = oracle.render_batch(dl.subset(idx), threads=6, labels=ll.subset(idx))
+        assert np.array_equal(c[idx], want)
+    finally:
+        gpu_ctx.host_free(pin)
