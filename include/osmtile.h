@@ -63,7 +63,10 @@ typedef enum osmt_line_cap {
 
 typedef enum osmt_coord_kind {
     OSMT_COORD_LATLON_F64 = 0, /* (lat, lon) degrees; projected on the GPU (tile.rs:88-106, point.rs:11-19) */
-    OSMT_COORD_POINT_I32 = 1   /* already-projected draw::point::Point {x, y} (point.rs:5-8) */
+    OSMT_COORD_POINT_I32 = 1,  /* already-projected draw::point::Point {x, y} (point.rs:5-8) */
+    OSMT_COORD_NODE_REF = 2    /* indices into a shared node table of (lat, lon) — the layout of the reference's
+                                * geodata file, where ways hold node REFERENCES and neighbouring tiles share nodes
+                                * (reader.rs:291-336, saver.rs:54-109); SURVEY.md 8(f) N2: removes the 16 B/point stream */
 } osmt_coord_kind;
 
 /* 64-byte op header. */
@@ -120,6 +123,10 @@ typedef struct osmt_batch {
     size_t n_pts;
     const double* dashes; /* dash pool, already * scale */
     size_t n_dashes;
+    /* OSMT_COORD_NODE_REF only: point i of the pools above is nodes[node_refs[i]] */
+    const double* nodes;       /* [n_nodes][2] = (lat, lon) degrees, uploaded once per scene */
+    size_t n_nodes;
+    const uint32_t* node_refs; /* [n_pts] */
 } osmt_batch;
 
 /* ---- label pass ---------------------------------------- */

@@ -632,6 +632,10 @@ void draw_lines(const Point* pairs, size_t n_pairs, double width, const uint8_t 
 
 Point batch_point(const osmt_batch* b, const osmt_tile_job& job, uint32_t pt) {
     if (b->coord_kind == OSMT_COORD_POINT_I32) return Point{b->points[2 * (size_t)pt], b->points[2 * (size_t)pt + 1]};
+    if (b->coord_kind == OSMT_COORD_NODE_REF) { /* Way::get_node(idx) -> Node (reader.rs:291-336) -> Point::from_node */
+        const size_t n = b->node_refs[pt];
+        return point_from_node(b->nodes[2 * n], b->nodes[2 * n + 1], job.zoom, job.x, job.y, (double)b->scale);
+    }
     return point_from_node(b->latlon[2 * (size_t)pt], b->latlon[2 * (size_t)pt + 1], job.zoom, job.x, job.y,
                            (double)b->scale);
 }

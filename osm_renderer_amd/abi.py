@@ -13,7 +13,7 @@ OK, INVALID_ARG, OOM, HIP_ERROR, UNSUPPORTED, NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 OP_NONE, OP_FILL_COLOR, OP_FILL_IMAGE, OP_STROKE = 0, 1, 2, 3
 CAP_NONE, CAP_BUTT, CAP_ROUND, CAP_SQUARE = 0, 1, 2, 3
-COORD_LATLON_F64, COORD_POINT_I32 = 0, 1
+COORD_LATLON_F64, COORD_POINT_I32, COORD_NODE_REF = 0, 1, 2
 
 STAGE_PROJECT, STAGE_OPINFO, STAGE_RASTER = 1, 2, 4
 
@@ -71,6 +71,9 @@ class Batch(C.Structure):
         ("n_pts", C.c_size_t),
         ("dashes", C.POINTER(C.c_double)),
         ("n_dashes", C.c_size_t),
+        ("nodes", C.POINTER(C.c_double)),
+        ("n_nodes", C.c_size_t),
+        ("node_refs", C.POINTER(C.c_uint32)),
     ]
 
 

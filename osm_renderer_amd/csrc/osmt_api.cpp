@@ -67,7 +67,8 @@ struct osmt_scene {
     osmt_tile_job* d_jobs = nullptr;
     osmt_op* d_ops = nullptr;
     osmt_ring* d_rings = nullptr;
-    double* d_latlon = nullptr;
+    double* d_latlon = nullptr;     /* per point, or the node table (OSMT_COORD_NODE_REF) */
+    uint32_t* d_node_refs = nullptr;
     int32_t* d_pts = nullptr;
     double* d_dashes = nullptr;
     uint32_t* d_pt_job = nullptr;
@@ -121,7 +122,7 @@ int sync_images(osmt_ctx* ctx) {
 int validate_batch(const osmt_batch* b) {
     if (!b) return fail(OSMT_INVALID_ARG, "batch is NULL");
     if (b->scale < 1 || b->scale > OSMT_MAX_SCALE) return fail(OSMT_INVALID_ARG, "scale %u not in 1..%u", b->scale, OSMT_MAX_SCALE);
-    if (b->coord_kind != OSMT_COORD_LATLON_F64 && b->coord_kind != OSMT_COORD_POINT_I32)
+    if (b->coord_kind != OSMT_COORD_LATLON_F64 && b->coord_kind != OSMT_COORD_POINT_I32 && b->coord_kind != OSMT_COORD_NODE_REF)
         return fail(OSMT_INVALID_ARG, "unknown coord_kind %u", b->coord_kind);
     if (b->n_jobs >= 0x7FFFFFFFull / 64 || b->n_ops >= 0xFFFFFFFFull || b->n_rings >= 0xFFFFFFFFull ||
         b->n_pts >= 0xFFFFFFFFull || b->n_dashes >= 0xFFFFFFFFull)
@@ -131,6 +132,12 @@ int validate_batch(const osmt_batch* b) {
     if (b->n_pts) {
         if (b->coord_kind == OSMT_COORD_LATLON_F64 && !b->latlon) return fail(OSMT_INVALID_ARG, "latlon pool is NULL");
         if (b->coord_kind == OSMT_COORD_POINT_I32 && !b->points) return fail(OSMT_INVALID_ARG, "points pool is NULL");
+        if (b->coord_kind == OSMT_COORD_NODE_REF) {
+            if (!b->node_refs || !b->nodes) return fail(OSMT_INVALID_ARG, "node table / node_refs is NULL");
+            if (b->n_nodes >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "node table too large for 32-bit indices");
+            for (size_t i = 0; i < b->n_pts; ++i)
+                if (b->node_refs[i] >= b->n_nodes) return fail(OSMT_INVALID_ARG, "point %zu: node reference %u out of range", i, b->node_refs[i]);
+        }
     }
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
@@ -183,8 +190,9 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     const uint32_t W = OSMT_TILE_SIZE * sc->scale;
     if ((stages & 4u) && !d_out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
     if ((stages & 4u) && !f64 && stride < (size_t)W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
-    if ((stages & 1u) && sc->coord_kind == OSMT_COORD_LATLON_F64)
-        HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->n_pts, (double)sc->scale, sc->d_pts, st));
+    if ((stages & 1u) && sc->coord_kind != OSMT_COORD_POINT_I32)
+        HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->coord_kind == OSMT_COORD_NODE_REF ? sc->d_node_refs : nullptr,
+                                    sc->n_pts, (double)sc->scale, sc->d_pts, st));
     if (stages & 2u)
         HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
                                    sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_op_blk, sc->d_blk, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
@@ -363,10 +371,12 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
         return o;
     };
     const bool ll = b->coord_kind == OSMT_COORD_LATLON_F64;
+    const bool nr = b->coord_kind == OSMT_COORD_NODE_REF;
     const size_t o_jobs = carve(b->n_jobs * sizeof(osmt_tile_job));
     const size_t o_ops = carve(b->n_ops * sizeof(osmt_op));
     const size_t o_rings = carve(b->n_rings * sizeof(osmt_ring));
-    const size_t o_latlon = carve(ll ? b->n_pts * 16 : 0);
+    const size_t o_latlon = carve(ll ? b->n_pts * 16 : nr ? b->n_nodes * 16 : 0);
+    const size_t o_refs = carve(nr ? b->n_pts * 4 : 0);
     const size_t o_pts = carve(b->n_pts * 8);
     const size_t o_dashes = carve((b->n_dashes + 1) * 8);
     const size_t o_ptjob = carve(b->n_pts * 4);
@@ -391,6 +401,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     s->d_ops = (osmt_op*)(s->d_base + o_ops);
     s->d_rings = (osmt_ring*)(s->d_base + o_rings);
     s->d_latlon = (double*)(s->d_base + o_latlon);
+    s->d_node_refs = (uint32_t*)(s->d_base + o_refs);
     s->d_pts = (int32_t*)(s->d_base + o_pts);
     s->d_dashes = (double*)(s->d_base + o_dashes);
     s->d_pt_job = (uint32_t*)(s->d_base + o_ptjob);
@@ -413,7 +424,9 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     if (err == hipSuccess) err = up(s->d_ops, b->ops, b->n_ops * sizeof(osmt_op));
     if (err == hipSuccess) err = up(s->d_rings, b->rings, b->n_rings * sizeof(osmt_ring));
     if (err == hipSuccess && ll) err = up(s->d_latlon, b->latlon, b->n_pts * 16);
-    if (err == hipSuccess && !ll) err = up(s->d_pts, b->points, b->n_pts * 8);
+    if (err == hipSuccess && nr) err = up(s->d_latlon, b->nodes, b->n_nodes * 16);
+    if (err == hipSuccess && nr) err = up(s->d_node_refs, b->node_refs, b->n_pts * 4);
+    if (err == hipSuccess && !ll && !nr) err = up(s->d_pts, b->points, b->n_pts * 8);
     if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
     if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);

@@ -173,8 +173,8 @@ struct osmt_raster_args {
     osmt_label_args labels;  /* info == NULL: no label pass */
 };
 
-hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
-                               double scale, int32_t* pts, hipStream_t st);
+hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
+                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
                                       double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,

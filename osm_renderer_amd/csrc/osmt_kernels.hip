@@ -54,8 +54,8 @@ __device__ __forceinline__ void project_point(double lat, double lon, uint32_t z
 
 __global__ __launch_bounds__(256) void k_project(const osmt_tile_job* __restrict__ jobs,
                                                  const uint32_t* __restrict__ pt_job,
-                                                 const double2* __restrict__ latlon, uint32_t n_pts, double scale,
-                                                 int2* __restrict__ pts) {
+                                                 const double2* __restrict__ latlon, const uint32_t* __restrict__ refs,
+                                                 uint32_t n_pts, double scale, int2* __restrict__ pts) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_pts) return;
     const uint32_t j = pt_job[i];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_project(const osmt_tile_job* __restrict
         return;
     }
     const osmt_tile_job job = jobs[j];
-    const double2 ll = latlon[i];
+    const double2 ll = latlon[refs ? refs[i] : i]; /* OSMT_COORD_NODE_REF: gather from the shared node table */
     int32_t x, y;
     project_point(ll.x, ll.y, job.zoom, job.x, job.y, scale, &x, &y);
     pts[i] = make_int2(x, y);
@@ -1685,11 +1685,11 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
     if (tid == 0) g_tl_cnt[tile] = n_out;
 }
 
-hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, uint32_t n_pts,
-                               double scale, int32_t* pts, hipStream_t st) {
+hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
+                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st) {
     if (n_pts == 0) return hipSuccess;
     hipLaunchKernelGGL(k_project, dim3((n_pts + 255u) / 256u), dim3(256), 0, st, jobs, pt_job,
-                       reinterpret_cast<const double2*>(latlon), n_pts, scale, reinterpret_cast<int2*>(pts));
+                       reinterpret_cast<const double2*>(latlon), refs, n_pts, scale, reinterpret_cast<int2*>(pts));
     return hipGetLastError();
 }
 

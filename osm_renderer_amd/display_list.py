@@ -51,14 +51,18 @@ assert OP_DTYPE.itemsize == 64 and RING_DTYPE.itemsize == 8 and JOB_DTYPE.itemsi
 class DisplayList:
     """A batch of tiles (osmt_batch) backed by numpy arrays."""
 
-    def __init__(self, jobs, ops, rings, coords, dashes, coord_kind, scale):
+    def __init__(self, jobs, ops, rings, coords, dashes, coord_kind, scale, nodes=None):
         self.jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         self.ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
         self.rings = np.ascontiguousarray(rings, dtype=RING_DTYPE)
         self.coord_kind = int(coord_kind)
         self.scale = int(scale)
+        self.nodes = None
         if self.coord_kind == abi.COORD_LATLON_F64:
             self.coords = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, 2)
+        elif self.coord_kind == abi.COORD_NODE_REF:
+            self.coords = np.ascontiguousarray(coords, dtype=np.uint32).reshape(-1)  # node references
+            self.nodes = np.ascontiguousarray(nodes, dtype=np.float64).reshape(-1, 2)
         else:
             self.coords = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 2)
         self.dashes = np.ascontiguousarray(dashes, dtype=np.float64).reshape(-1)
@@ -85,6 +89,12 @@ class DisplayList:
         if self.coord_kind == abi.COORD_LATLON_F64:
             b.latlon = self.coords.ctypes.data_as(C.POINTER(C.c_double))
             b.points = None
+        elif self.coord_kind == abi.COORD_NODE_REF:
+            b.latlon = None
+            b.points = None
+            b.nodes = self.nodes.ctypes.data_as(C.POINTER(C.c_double))
+            b.n_nodes = len(self.nodes)
+            b.node_refs = self.coords.ctypes.data_as(C.POINTER(C.c_uint32))
         else:
             b.latlon = None
             b.points = self.coords.ctypes.data_as(C.POINTER(C.c_int32))
@@ -95,13 +105,22 @@ class DisplayList:
 
     def algorithmic_bytes(self):
         """B_raster = 16*N_pts + 64*N_ops + 8*N_dashes + 4*W*H per tile, summed."""
-        pt_bytes = 16 if self.coord_kind == abi.COORD_LATLON_F64 else 8
+        pt_bytes = {abi.COORD_LATLON_F64: 16, abi.COORD_NODE_REF: 4}.get(self.coord_kind, 8)
         return (
-            pt_bytes * len(self.coords)
+            (16 * len(self.nodes) if self.nodes is not None else 0)
+            + pt_bytes * len(self.coords)
             + 64 * len(self.ops)
             + 8 * len(self.dashes)
             + 4 * self.dim * self.dim * len(self.jobs)
         )
+
+    def with_node_refs(self):
+        """The same tiles with OSMT_COORD_NODE_REF coordinates: identical (lat, lon) pairs — nodes shared by the
+        rings of a way's fill/casing/stroke ops and by neighbouring tiles — are stored once."""
+        assert self.coord_kind == abi.COORD_LATLON_F64
+        nodes, refs = np.unique(self.coords.view([("lat", "f8"), ("lon", "f8")]).reshape(-1), return_inverse=True)
+        return DisplayList(self.jobs, self.ops, self.rings, refs.astype(np.uint32), self.dashes, abi.COORD_NODE_REF, self.scale,
+                           nodes=nodes.view(np.float64).reshape(-1, 2))
 
     def subset(self, idx):
         """A new DisplayList holding jobs `idx` (pools are re-packed)."""
@@ -128,7 +147,7 @@ class DisplayList:
         rings = np.concatenate(rings_l) if rings_l else np.zeros(0, RING_DTYPE)
         dashes = np.concatenate(dashes_l) if dashes_l else np.zeros(0)
         coords = self.coords[j["pt_off"] : j["pt_off"] + j["n_pts"]]
-        return DisplayList(job, ops, rings, coords, dashes, self.coord_kind, self.scale)
+        return DisplayList(job, ops, rings, coords, dashes, self.coord_kind, self.scale, nodes=self.nodes)
 
 
 def concat(lists):
@@ -136,6 +155,7 @@ def concat(lists):
     lists = list(lists)
     assert lists, "nothing to concatenate"
     ck, sc = lists[0].coord_kind, lists[0].scale
+    assert ck != abi.COORD_NODE_REF or all(dl.nodes is lists[0].nodes for dl in lists), "NODE_REF lists must share one node table"
     jobs, ops, rings, coords, dashes = [], [], [], [], []
     o_op = o_ring = o_pt = o_dash = 0
     for dl in lists:
@@ -158,7 +178,8 @@ def concat(lists):
         o_pt += len(dl.coords)
         o_dash += len(dl.dashes)
     return DisplayList(
-        np.concatenate(jobs), np.concatenate(ops), np.concatenate(rings), np.concatenate(coords), np.concatenate(dashes), ck, sc
+        np.concatenate(jobs), np.concatenate(ops), np.concatenate(rings), np.concatenate(coords), np.concatenate(dashes), ck, sc,
+        nodes=lists[0].nodes,
     )
 
 

@@ -54,6 +54,8 @@ size_t shim_sizeof(int which) {
         case 30: return offsetof(osmt_batch, coord_kind);
         case 31: return offsetof(osmt_batch, latlon);
         case 32: return offsetof(osmt_batch, dashes);
+        case 33: return offsetof(osmt_batch, nodes);
+        case 34: return offsetof(osmt_batch, node_refs);
         case 40: return offsetof(osmt_label, image_id);
         case 41: return offsetof(osmt_label, n_segs);
         case 42: return offsetof(osmt_label, icon_center_x);

@@ -47,6 +47,8 @@ def test_struct_layouts_match_the_header():
     assert s(30) == abi.Batch.coord_kind.offset
     assert s(31) == abi.Batch.latlon.offset
     assert s(32) == abi.Batch.dashes.offset
+    assert s(33) == abi.Batch.nodes.offset
+    assert s(34) == abi.Batch.node_refs.offset
     from osm_renderer_amd import labels
 
     assert s(5) == C.sizeof(abi.Label) == labels.LABEL_DTYPE.itemsize == 40
