@@ -253,6 +253,22 @@ size_t osmt_png_bound(uint32_t width, uint32_t height);
 int osmt_encode_png(const uint8_t* rgba, uint32_t width, uint32_t height, size_t row_stride_bytes, int level,
                     uint8_t* out_png, size_t out_capacity, size_t* out_len);
 
+/* ---- PNG files produced on the GPU ---------------------------------------- */
+/* The same file format as above (RGB8, one IDAT) written by a HIP kernel, one wave per tile: Paeth-filtered
+ * rows, one fixed-Huffman deflate block with distance-1 run matches, Adler-32 and chunk CRCs computed on the
+ * device.  Decoded pixels equal the framebuffer; a map tile shrinks ~4-5x, so a server moves ~50 KB per tile
+ * over PCIe instead of 256 KB and spends no host time in zlib.
+ * d_rgba: n framebuffers (RGBA8, rows tightly packed) tile_stride bytes apart; d_png: n slots png_stride >=
+ * osmt_png_device_bound(W, H) bytes apart (multiples of 4); d_len[i] = size of file i.  W multiple of 4, <= 1024. */
+size_t osmt_png_device_bound(uint32_t width, uint32_t height);
+int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride_bytes, uint32_t n, uint32_t width, uint32_t height,
+                           void* d_png, size_t png_stride_bytes, uint32_t* d_len, void* stream);
+/* Drawer::draw_tile for a batch (drawer.rs:40-58): display lists (+ labels, may be NULL) in, PNG files out.
+ * File i = out_png[out_off[i] .. out_off[i + 1]); out_off has n_jobs + 1 entries (filled even when out_capacity
+ * is too small, so the call can be repeated with out_off[n_jobs] bytes). */
+int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
+                          uint64_t* out_off);
+
 #ifdef __cplusplus
 }
 #endif

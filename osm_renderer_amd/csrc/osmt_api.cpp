@@ -729,6 +729,89 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     return rc;
 }
 
+/* ---- PNG files straight from the GPU -------------------------------------- */
+static uint32_t ihdr_crc(uint32_t W, uint32_t H) {
+    /* CRC-32 of "IHDR" + width, height, 8, 2, 0, 0, 0 (bitwise; once per call) */
+    uint8_t b[17] = {'I', 'H', 'D', 'R', (uint8_t)(W >> 24), (uint8_t)(W >> 16), (uint8_t)(W >> 8), (uint8_t)W,
+                     (uint8_t)(H >> 24), (uint8_t)(H >> 16), (uint8_t)(H >> 8), (uint8_t)H, 8, 2, 0, 0, 0};
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint8_t v : b) {
+        c ^= v;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    }
+    return ~c;
+}
+
+size_t osmt_png_device_bound(uint32_t W, uint32_t H) {
+    /* 43 header bytes + one fixed-Huffman block of at most 9 bits per filtered byte + EOB, Adler, CRC, IEND */
+    const size_t bits = 3 + (size_t)H * (3 * (size_t)W + 1) * 9 + 7;
+    return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8, 256);
+}
+
+int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,
+                           size_t png_stride, uint32_t* d_len, void* stream) {
+    if (!ctx) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (n == 0) return OSMT_OK;
+    if (!d_rgba || !d_png || !d_len) return fail(OSMT_INVALID_ARG, "NULL device pointer");
+    if (W == 0 || H == 0 || W > 1024 || (W % 4) != 0) return fail(OSMT_UNSUPPORTED, "PNG width %u not supported (multiple of 4, <= 1024)", W);
+    if (tile_stride < (size_t)W * H * 4 || (tile_stride % 4) != 0) return fail(OSMT_INVALID_ARG, "tile stride too small / not a multiple of 4");
+    if (png_stride < osmt_png_device_bound(W, H) || (png_stride % 4) != 0) return fail(OSMT_INVALID_ARG, "png_stride < osmt_png_device_bound()");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(osmt_launch_png(d_rgba, tile_stride, n, W, H, ihdr_crc(W, H), d_png, png_stride, d_len, (hipStream_t)stream));
+    return OSMT_OK;
+}
+
+int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
+                          uint64_t* out_off) {
+    if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
+    osmt_scene* sc = nullptr;
+    int rc = osmt_scene_upload(ctx, batch, &sc);
+    if (rc != OSMT_OK) return rc;
+    if (labels) rc = osmt_scene_set_labels(ctx, sc, labels);
+    const uint32_t n = (uint32_t)batch->n_jobs;
+    const uint32_t W = OSMT_TILE_SIZE * batch->scale;
+    const size_t tile_bytes = (size_t)W * W * 4, slot = osmt_png_device_bound(W, W);
+    char* d = nullptr;
+    size_t o_rgba = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0, total = 0;
+    if (rc == OSMT_OK && n) {
+        size_t off = 0;
+        auto carve = [&](size_t bytes) {
+            const size_t o = off;
+            off = align_up(off + bytes, 256);
+            return o;
+        };
+        o_rgba = carve(n * tile_bytes);
+        o_png = carve(n * slot);
+        o_len = carve(n * 4);
+        o_off = carve(n * 8);
+        o_blob = o_rgba; /* the framebuffers are dead once encoded, and a PNG slot (<= 0.85 x RGBA8) never outgrows them */
+        hipError_t e = hipMalloc((void**)&d, off);
+        if (e != hipSuccess) rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+    }
+    std::vector<uint32_t> len(n);
+    std::vector<unsigned long long> offs(n + 1, 0ull);
+    if (rc == OSMT_OK && n) rc = render_impl(ctx, sc, 7u, d + o_rgba, tile_bytes, false, nullptr);
+    if (rc == OSMT_OK && n) rc = osmt_encode_png_device(ctx, d + o_rgba, tile_bytes, n, W, W, d + o_png, slot, (uint32_t*)(d + o_len), nullptr);
+    if (rc == OSMT_OK && n) {
+        hipError_t e = hipMemcpy(len.data(), d + o_len, n * 4, hipMemcpyDeviceToHost);
+        for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + len[i];
+        total = (size_t)offs[n];
+        if (e == hipSuccess && total > out_capacity) {
+            rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %zu bytes of PNG data", out_capacity, total);
+        } else {
+            if (e == hipSuccess) e = hipMemcpy(d + o_off, offs.data(), n * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = osmt_launch_png_compact(d + o_png, slot, (const uint32_t*)(d + o_len), (const unsigned long long*)(d + o_off), n, d + o_blob, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(out_png, d + o_blob, total, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
+        }
+    }
+    for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
+    if (d) (void)hipFree(d);
+    osmt_scene_free(sc);
+    return rc;
+}
+
 int osmt_host_alloc(osmt_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out = nullptr;

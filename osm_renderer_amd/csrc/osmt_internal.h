@@ -184,6 +184,11 @@ hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_rin
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 /* label pass: cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
 hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st);
+/* RGBA8 framebuffers -> complete RGB8 PNG files, one per tile, out_len[i] bytes at out + i * out_stride */
+hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, uint32_t ihdr_crc, void* out,
+                           size_t out_stride, uint32_t* out_len, hipStream_t st);
+hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
+                                   void* blob, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "osmt_scene_upload", "osmt_scene_free", "osmt_render_scene", "osmt_render_scene_f64", "osmt_render_scene_stages",
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_scene_set_labels", "osmt_scene_read_label_status",
-    "osmt_host_alloc", "osmt_host_free",
+    "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
 ]
 
 
@@ -64,6 +64,10 @@ def load():
     L.osmt_render_batch_labels.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_scene_set_labels.argtypes = [vp, vp, C.POINTER(abi.LabelBatch)]
     L.osmt_scene_read_label_status.argtypes = [vp, vp, u8p]
+    L.osmt_png_device_bound.argtypes = [C.c_uint32, C.c_uint32]
+    L.osmt_png_device_bound.restype = C.c_size_t
+    L.osmt_encode_png_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]
+    L.osmt_render_batch_png.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.osmt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.osmt_host_free.argtypes = [vp, vp]
     L.osmt_host_free.restype = None

@@ -165,6 +165,35 @@ class Context:
                                                   dl.dim * dl.dim * 4))
         return out
 
+    # -- PNG files from the GPU ----------------------------------------------------
+    def encode_png_device(self, rgba, stream=None):
+        """osmt_encode_png_device on a uint8 cuda tensor [n, H, W, 4]: (slots uint8 [n, bound], lengths int32 [n])."""
+        torch = _torch()
+        assert rgba.is_cuda and rgba.dtype == torch.uint8 and rgba.is_contiguous()
+        n, H, W, four = rgba.shape
+        assert four == 4
+        bound = load().osmt_png_device_bound(W, H)
+        slots = torch.empty((n, bound), dtype=torch.uint8, device=rgba.device)
+        lens = torch.empty((n,), dtype=torch.int32, device=rgba.device)
+        check(load().osmt_encode_png_device(self._h, C.c_void_p(rgba.data_ptr()), H * W * 4, n, W, H, C.c_void_p(slots.data_ptr()), bound,
+                                            C.c_void_p(lens.data_ptr()), _stream_ptr(stream)))
+        return slots, lens
+
+    def render_batch_png(self, dl: DisplayList, labels=None, out=None, as_bytes=True):
+        """osmt_render_batch_png: list of PNG files (bytes), one per tile.  `out`: uint8 buffer (e.g. host_alloc) to
+        receive the files back to back; as_bytes=False returns (out, offsets) without copying."""
+        b = dl.as_batch()
+        lb = labels.as_batch() if labels is not None else None
+        off = np.zeros(dl.n_jobs + 1, dtype=np.uint64)
+        if out is None:
+            out = np.empty(dl.n_jobs * load().osmt_png_device_bound(dl.dim, dl.dim), dtype=np.uint8)
+        cap = out.size
+        check(load().osmt_render_batch_png(self._h, C.byref(b), C.byref(lb) if lb is not None else None,
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, off.ctypes.data_as(C.POINTER(C.c_uint64))))
+        if not as_bytes:
+            return out, off
+        return [out[int(off[i]) : int(off[i + 1])].tobytes() for i in range(dl.n_jobs)]
+
     # -- stages --------------------------------------------------------------------
     def project(self, latlon, zoom, tx, ty, scale=1.0):
         latlon = np.ascontiguousarray(latlon, dtype=np.float64).reshape(-1, 2)

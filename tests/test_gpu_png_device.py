@@ -1,0 +1,57 @@
+"""PNG files written by the GPU (k_png_encode): valid files whose DECODED pixels equal the
+framebuffer (the only thing the reference's tests pin, tests/test_rendering.rs:15-23), byte-identical to the CPU
+model of the encoder (tests/_png_model.py)."""
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+from osm_renderer_amd import labels, synth
+from tests import _png_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode(png):
+    from PIL import Image
+
+    return np.array(Image.open(io.BytesIO(png)).convert("RGB"))
+
+
+def test_device_png_matches_model_and_decodes(gpu_ctx):
+    import torch
+
+    rng = np.random.default_rng(3)
+    imgs = np.zeros((6, 256, 256, 4), dtype=np.uint8)
+    imgs[0] = rng.integers(0, 256, size=(256, 256, 4))                      # incompressible: every literal is 8/9 bits
+    imgs[1, :, :] = (241, 238, 232, 255)                                    # flat: runs of 768 zeros, 258-byte matches
+    imgs[2, :, :, :3] = (np.arange(256)[None, :, None] // 3).astype(np.uint8)  # short horizontal runs, all run lengths
+    imgs[3, ::2] = 255                                                      # alternating rows
+    imgs[4, :, :, 0] = rng.integers(0, 2, size=(256, 256)) * 200             # run breaks at random places
+    imgs[5, 100:140, 90:200, :3] = rng.integers(140, 256, size=(40, 110, 3))  # literals >= 144 (9-bit codes)
+    imgs[..., 3] = 255
+    slots, lens = gpu_ctx.encode_png_device(torch.from_numpy(imgs).cuda())
+    slots, lens = slots.cpu().numpy(), lens.cpu().numpy()
+    for i in range(len(imgs)):
+        png = slots[i, : lens[i]].tobytes()
+        assert np.array_equal(_decode(png), imgs[i, :, :, :3]), f"image {i}: decoded pixels differ"
+        assert png == _png_model.encode(imgs[i]), f"image {i}: bytes differ from the model"
+    assert lens[1] < 3000 and lens[0] > 196608  # flat tile ~2 KB; noise is slightly larger than raw RGB
+
+
+@pytest.mark.parametrize("scale", [1, 2])
+def test_render_batch_png_end_to_end(gpu_ctx, oracle, scale):
+    n = 5
+    dl = synth.make_tiles(synth.config_tiles(n), n_poly=20, n_line=15, scale=scale)
+    ll = labels.make_labels(n, labels_per_tile=6, scale=scale, seed=8)
+    files = gpu_ctx.render_batch_png(dl, ll)
+    want = oracle.render_batch(dl, threads=n, labels=ll)
+    raw = want[0][..., :3].nbytes
+    for i, png in enumerate(files):
+        assert np.array_equal(_decode(png), want[i][..., :3])
+        assert len(png) < raw / 2
+    # the zlib stream inside is standard: python's zlib inflates it to H * (3W + 1) filtered bytes
+    png = files[0]
+    idat_len = int.from_bytes(png[33:37], "big")
+    assert len(zlib.decompress(png[41 : 41 + idat_len])) == dl.dim * (3 * dl.dim + 1)
