@@ -745,7 +745,8 @@ static uint32_t ihdr_crc(uint32_t W, uint32_t H) {
 size_t osmt_png_device_bound(uint32_t W, uint32_t H) {
     /* 43 header bytes + one fixed-Huffman block of at most 9 bits per filtered byte + EOB, Adler, CRC, IEND */
     const size_t bits = 3 + (size_t)H * (3 * (size_t)W + 1) * 9 + 7;
-    return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8, 256);
+    /* + 4 x 3 words of slack: the fast kernel stages four row bands in the slot, each rounded up to words */
+    return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8 + 128, 256);
 }
 
 int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,

@@ -55,3 +55,23 @@ def test_render_batch_png_end_to_end(gpu_ctx, oracle, scale):
     png = files[0]
     idat_len = int.from_bytes(png[33:37], "big")
     assert len(zlib.decompress(png[41 : 41 + idat_len])) == dl.dim * (3 * dl.dim + 1)
+
+
+@pytest.mark.parametrize("shape", [(70, 128), (33, 768), (5, 1024), (64, 64)])
+def test_generic_widths_take_the_two_pass_kernel(gpu_ctx, shape):
+    """widths other than 256 / 512 (or heights that do not split into 4 bands) run the LDS two-pass kernel"""
+    import torch
+
+    H, W = shape
+    rng = np.random.default_rng(H * W)
+    imgs = np.zeros((3, H, W, 4), dtype=np.uint8)
+    imgs[0, :, :, :3] = rng.integers(0, 256, size=(H, W, 3))
+    imgs[1, :, : W // 2, :3] = (10, 200, 30)
+    imgs[2, :, :, :3] = (rng.integers(0, 4, size=(H, W, 1)) * 60).astype(np.uint8)
+    imgs[..., 3] = 255
+    slots, lens = gpu_ctx.encode_png_device(torch.from_numpy(imgs).cuda())
+    slots, lens = slots.cpu().numpy(), lens.cpu().numpy()
+    for i in range(3):
+        png = slots[i, : lens[i]].tobytes()
+        assert np.array_equal(_decode(png), imgs[i, :, :, :3])
+        assert png == _png_model.encode(imgs[i])
