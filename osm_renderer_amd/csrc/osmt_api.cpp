@@ -51,6 +51,15 @@ int osmt_fail_public(int code, const char* msg) { return fail(code, "%s", msg); 
 struct osmt_ctx {
     int device = 0;
     std::mutex mu; /* guards the image registry */
+    /* Device buffers of finished calls, kept for the next one: a per-request server loop uploads, renders and frees
+     * a scene per call, and hipMalloc / hipFree of a few hundred MB cost more than the kernels. */
+    struct cached_buf {
+        void* p;
+        size_t bytes;
+        bool used;
+    };
+    std::mutex cache_mu;
+    std::vector<cached_buf> cache;
     std::vector<osmt_image_desc> images;
     std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
     osmt_image_desc* d_images = nullptr;
@@ -99,6 +108,60 @@ struct osmt_scene {
 };
 
 namespace {
+
+constexpr size_t CACHE_KEEP_BYTES = (size_t)8 << 30; /* idle buffers beyond this are returned to the driver */
+
+hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, (size_t)2 << 20);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        osmt_ctx::cached_buf* best = nullptr;
+        for (auto& c : ctx->cache)
+            if (!c.used && c.bytes >= bytes && c.bytes <= 2 * bytes && (!best || c.bytes < best->bytes)) best = &c;
+        if (best) {
+            best->used = true;
+            *out = best->p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) { /* give the idle buffers back and retry once */
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        for (size_t i = 0; i < ctx->cache.size();) {
+            if (!ctx->cache[i].used) {
+                (void)hipFree(ctx->cache[i].p);
+                ctx->cache.erase(ctx->cache.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    ctx->cache.push_back({*out, bytes, true});
+    return hipSuccess;
+}
+
+void dev_free(osmt_ctx* ctx, void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    size_t idle = 0;
+    for (auto& c : ctx->cache) {
+        if (c.p == p) c.used = false;
+        if (!c.used) idle += c.bytes;
+    }
+    for (size_t i = 0; idle > CACHE_KEEP_BYTES && i < ctx->cache.size();) {
+        if (!ctx->cache[i].used) {
+            idle -= ctx->cache[i].bytes;
+            (void)hipFree(ctx->cache[i].p);
+            ctx->cache.erase(ctx->cache.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+}
 
 int sync_images(osmt_ctx* ctx) {
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -293,6 +356,7 @@ void osmt_destroy(osmt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->d_images) (void)hipFree(ctx->d_images);
     if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
+    for (auto& c : ctx->cache) (void)hipFree(c.p); /* scenes must be freed before their context */
     delete ctx;
 }
 
@@ -391,7 +455,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     const size_t o_opblk = carve(b->n_ops * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     s->bytes = off + 256;
-    hipError_t e = hipMalloc((void**)&s->d_base, s->bytes);
+    hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
         delete s;
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
@@ -432,7 +496,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err != hipSuccess) {
-        (void)hipFree(s->d_base);
+        dev_free(ctx, s->d_base);
         delete s;
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
@@ -443,8 +507,11 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
 void osmt_scene_free(osmt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    if (s->d_base) (void)hipFree(s->d_base);
-    if (s->d_lab_base) (void)hipFree(s->d_lab_base);
+    /* in-flight kernels of the caller's streams may still read the scene: a cached buffer can be handed to the
+     * next upload at once, so wait for the device here (hipFree used to do that implicitly) */
+    (void)hipDeviceSynchronize();
+    dev_free(s->ctx, s->d_base);
+    dev_free(s->ctx, s->d_lab_base);
     delete s;
 }
 
@@ -456,7 +523,7 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (sc->d_lab_base) (void)hipFree(sc->d_lab_base);
+    dev_free(ctx, sc->d_lab_base);
     sc->d_lab_base = nullptr;
     sc->n_labels = sc->n_label_segs = 0;
     if (!lb || lb->n_labels == 0) return OSMT_OK;
@@ -554,7 +621,7 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     const size_t o_tlc = carve((size_t)sc->n_jobs * 4);
     const size_t o_ok = carve(lb->n_labels);
     const size_t o_err = carve(4);
-    hipError_t e = hipMalloc((void**)&sc->d_lab_base, off + 256);
+    hipError_t e = dev_alloc(ctx, (void**)&sc->d_lab_base, off + 256);
     if (e != hipSuccess) {
         sc->d_lab_base = nullptr;
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) for labels failed: %s", off,
@@ -580,7 +647,7 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     if (e == hipSuccess) e = hipMemset(sc->d_lab_ok, 0, lb->n_labels);
     if (e == hipSuccess) e = hipMemset(sc->d_lab_err, 0, 4);
     if (e != hipSuccess) {
-        (void)hipFree(sc->d_lab_base);
+        dev_free(ctx, sc->d_lab_base);
         sc->d_lab_base = nullptr;
         return fail(OSMT_HIP_ERROR, "label upload failed: %s", hipGetErrorString(e));
     }
@@ -667,7 +734,7 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
             e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&d_out, 2 * (size_t)chunk * tile_bytes);
+        if (e == hipSuccess) e = dev_alloc(ctx, (void**)&d_out, 2 * (size_t)chunk * tile_bytes);
         if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "pipeline setup failed: %s", hipGetErrorString(e));
         if (rc == OSMT_OK) rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, s_k);
         uint32_t c = 0;
@@ -699,7 +766,7 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
             if (done[k]) (void)hipEventDestroy(done[k]);
             if (freed[k]) (void)hipEventDestroy(freed[k]);
         }
-        if (d_out) (void)hipFree(d_out);
+        dev_free(ctx, d_out);
         if (s_k) (void)hipStreamDestroy(s_k);
         if (s_c) (void)hipStreamDestroy(s_c);
         osmt_scene_free(sc);
@@ -707,7 +774,7 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     }
     void* d_out = nullptr;
     if (batch->n_jobs) {
-        hipError_t e = hipMalloc(&d_out, batch->n_jobs * tile_bytes);
+        hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * tile_bytes);
         if (e != hipSuccess) {
             osmt_scene_free(sc);
             return fail(OSMT_OOM, "hipMalloc(output) failed: %s", hipGetErrorString(e));
@@ -724,7 +791,7 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
         }
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
-    if (d_out) (void)hipFree(d_out);
+    dev_free(ctx, d_out);
     osmt_scene_free(sc);
     return rc;
 }
@@ -786,7 +853,7 @@ int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
         o_len = carve(n * 4);
         o_off = carve(n * 8);
         o_blob = o_rgba; /* the framebuffers are dead once encoded, and a PNG slot (<= 0.85 x RGBA8) never outgrows them */
-        hipError_t e = hipMalloc((void**)&d, off);
+        hipError_t e = dev_alloc(ctx, (void**)&d, off);
         if (e != hipSuccess) rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
     }
     std::vector<uint32_t> len(n);
@@ -808,7 +875,7 @@ int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
         }
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
-    if (d) (void)hipFree(d);
+    dev_free(ctx, d);
     osmt_scene_free(sc);
     return rc;
 }
