@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     ap.add_argument("--no-labels", action="store_true")
-    ap.add_argument("--label-tiles", type=int, default=256)
+    ap.add_argument("--label-tiles", type=int, default=1024)
     args = ap.parse_args()
 
     import numpy as np
@@ -243,7 +243,8 @@ def main():
 
             oracle_py.build()
             nt = min(16, os.cpu_count() or 1)
-            sub_dl, sub_ll = ldl.subset(range(pool)), ll.subset(range(pool))
+            n_cpu = min(n, 256)  # enough work for the difference of the two timings to stand clear of the noise
+            sub_dl, sub_ll = ldl.subset(range(n_cpu)), ll.subset(range(n_cpu))
 
             def best(fn, reps=3):
                 ts = []
@@ -258,7 +259,7 @@ def main():
             cpu_s = max(t_lab - t_plain, 1e-9)
             result["label_pass"]["cpu_baseline"] = {
                 "value": len(sub_ll.labels) / cpu_s, "unit": "labels/s", "cores": nt, "kind": "port",
-                "sample": f"{pool} tiles, {len(sub_ll.labels)} labels: oracle render with labels ({t_lab:.3f} s) minus "
+                "sample": f"{n_cpu} tiles, {len(sub_ll.labels)} labels: oracle render with labels ({t_lab:.3f} s) minus "
                           f"without ({t_plain:.3f} s), best of 3 each",
             }
         lscene.free()
