@@ -60,6 +60,9 @@ struct osmt_ctx {
     };
     std::mutex cache_mu;
     std::vector<cached_buf> cache;
+    /* idle non-blocking streams: every host-buffer call runs on its own stream, so calls from the reference's N
+     * worker threads (http_server.rs:50-83) overlap on the GPU instead of queueing behind the NULL stream */
+    std::vector<hipStream_t> idle_streams;
     std::vector<osmt_image_desc> images;
     std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
     osmt_image_desc* d_images = nullptr;
@@ -90,6 +93,10 @@ struct osmt_scene {
     uint8_t* d_opnv = nullptr;
     uint32_t* d_op_blk = nullptr;
     osmt_blk_bbox* d_blk = nullptr;
+    /* host-side tables whose upload may still be in flight on the call's stream */
+    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_lab_wide;
+    std::vector<osmt_labelinfo> h_lab_info;
+    hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
     char* d_lab_base = nullptr;
@@ -142,6 +149,24 @@ hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     ctx->cache.push_back({*out, bytes, true});
     return hipSuccess;
+}
+
+hipError_t stream_acquire(osmt_ctx* ctx, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        if (!ctx->idle_streams.empty()) {
+            *out = ctx->idle_streams.back();
+            ctx->idle_streams.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_release(osmt_ctx* ctx, hipStream_t st) {
+    if (!st) return;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    ctx->idle_streams.push_back(st);
 }
 
 void dev_free(osmt_ctx* ctx, void* p) {
@@ -357,6 +382,7 @@ void osmt_destroy(osmt_ctx* ctx) {
     if (ctx->d_images) (void)hipFree(ctx->d_images);
     if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
     for (auto& c : ctx->cache) (void)hipFree(c.p); /* scenes must be freed before their context */
+    for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -384,15 +410,25 @@ int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uin
     return OSMT_OK;
 }
 
-int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
+/* st == nullptr: blocking copies (the public osmt_scene_upload); otherwise stream-ordered on `st`, the caller
+ * synchronises the stream before the batch's host arrays go away */
+static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st) {
     if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out_scene = nullptr;
     int rc = validate_batch(b);
     if (rc != OSMT_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
 
+    osmt_scene* s = new (std::nothrow) osmt_scene();
+    if (!s) return fail(OSMT_OOM, "out of host memory");
+    s->own_stream = st;
     /* host-side index tables: point -> job (for projection), op -> stroke slot */
-    std::vector<uint32_t> pt_job(b->n_pts, 0xFFFFFFFFu), op_aux(b->n_ops, 0u), op_blk(b->n_ops, 0xFFFFFFFFu);
+    std::vector<uint32_t>& pt_job = s->h_pt_job;
+    std::vector<uint32_t>& op_aux = s->h_op_aux;
+    std::vector<uint32_t>& op_blk = s->h_op_blk;
+    pt_job.assign(b->n_pts, 0xFFFFFFFFu);
+    op_aux.assign(b->n_ops, 0u);
+    op_blk.assign(b->n_ops, 0xFFFFFFFFu);
     uint32_t n_strokes = 0;
     size_t n_blk = 0; /* 64-edge blocks of the ops with more than 64 edges */
     for (size_t j = 0; j < b->n_jobs; ++j) {
@@ -415,8 +451,6 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
         }
     }
 
-    osmt_scene* s = new (std::nothrow) osmt_scene();
-    if (!s) return fail(OSMT_OOM, "out of host memory");
     s->ctx = ctx;
     s->n_jobs = (uint32_t)b->n_jobs;
     s->n_ops = (uint32_t)b->n_ops;
@@ -481,7 +515,7 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
-        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+        return st ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t err = hipSuccess;
     if (err == hipSuccess) err = up(s->d_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
@@ -504,12 +538,17 @@ int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene
     return OSMT_OK;
 }
 
+int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) { return scene_upload_impl(ctx, b, out_scene, nullptr); }
+
 void osmt_scene_free(osmt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    /* in-flight kernels of the caller's streams may still read the scene: a cached buffer can be handed to the
-     * next upload at once, so wait for the device here (hipFree used to do that implicitly) */
-    (void)hipDeviceSynchronize();
+    /* in-flight kernels may still read the scene and a cached buffer can be handed to the next upload at once:
+     * wait for the scene's own stream (internal per-call scenes) or for the device (hipFree used to do that) */
+    if (s->own_stream)
+        (void)hipStreamSynchronize(s->own_stream);
+    else
+        (void)hipDeviceSynchronize();
     dev_free(s->ctx, s->d_base);
     dev_free(s->ctx, s->d_lab_base);
     delete s;
@@ -522,7 +561,11 @@ void osmt_scene_free(osmt_scene* s) {
 int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch* lb) {
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = sc->own_stream;
+    if (st)
+        HIP_TRY(hipStreamSynchronize(st));
+    else
+        HIP_TRY(hipDeviceSynchronize());
     dev_free(ctx, sc->d_lab_base);
     sc->d_lab_base = nullptr;
     sc->n_labels = sc->n_label_segs = 0;
@@ -543,8 +586,10 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
         images = ctx->images;
     }
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * sc->scale);
-    std::vector<osmt_labelinfo> info(lb->n_labels);
-    std::vector<uint32_t> wide;
+    std::vector<osmt_labelinfo>& info = sc->h_lab_info; /* kept alive: the upload may be stream-ordered */
+    std::vector<uint32_t>& wide = sc->h_lab_wide;
+    info.assign(lb->n_labels, osmt_labelinfo{});
+    wide.clear();
     size_t cells = 0, wide_cells = 0;
     for (uint32_t j = 0; j < sc->n_jobs; ++j) {
         for (uint32_t l = lb->job_label_off[j]; l < lb->job_label_off[j + 1]; ++l) {
@@ -640,12 +685,16 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     sc->d_lab_bitmap = (uint32_t*)(base + o_bm);
     sc->d_lab_ok = (uint8_t*)(base + o_ok);
     sc->d_lab_err = (uint32_t*)(base + o_err);
-    e = hipMemcpy(sc->d_lab, info.data(), info.size() * sizeof(osmt_labelinfo), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && lb->n_segs) e = hipMemcpy(sc->d_lab_segs, lb->segs, lb->n_segs * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !wide.empty()) e = hipMemcpy(sc->d_lab_wide, wide.data(), wide.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(sc->d_lab_ok, 0, lb->n_labels);
-    if (e == hipSuccess) e = hipMemset(sc->d_lab_err, 0, 4);
+    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        return st ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    e = up(sc->d_lab, info.data(), info.size() * sizeof(osmt_labelinfo));
+    if (e == hipSuccess) e = up(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4);
+    if (e == hipSuccess) e = up(sc->d_lab_segs, lb->segs, lb->n_segs * 32);
+    if (e == hipSuccess) e = up(sc->d_lab_wide, wide.data(), wide.size() * 4);
+    if (e == hipSuccess) e = st ? hipMemsetAsync(sc->d_lab_ok, 0, lb->n_labels, st) : hipMemset(sc->d_lab_ok, 0, lb->n_labels);
+    if (e == hipSuccess) e = st ? hipMemsetAsync(sc->d_lab_err, 0, 4, st) : hipMemset(sc->d_lab_err, 0, 4);
     if (e != hipSuccess) {
         dev_free(ctx, sc->d_lab_base);
         sc->d_lab_base = nullptr;
@@ -697,13 +746,20 @@ int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba,
 int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
                              size_t stride) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = nullptr; /* the whole call lives on its own stream: concurrent callers overlap on the GPU */
+    HIP_TRY(stream_acquire(ctx, &st));
     osmt_scene* sc = nullptr;
-    int rc = osmt_scene_upload(ctx, batch, &sc);
-    if (rc != OSMT_OK) return rc;
+    int rc = scene_upload_impl(ctx, batch, &sc, st);
+    if (rc != OSMT_OK) {
+        stream_release(ctx, st);
+        return rc;
+    }
     if (labels) {
         rc = osmt_scene_set_labels(ctx, sc, labels);
         if (rc != OSMT_OK) {
             osmt_scene_free(sc);
+            stream_release(ctx, st);
             return rc;
         }
     }
@@ -711,6 +767,7 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     const size_t tile_bytes = W * W * 4;
     if (stride < tile_bytes) {
         osmt_scene_free(sc);
+        stream_release(ctx, st);
         return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
     }
     /* Output in pinned host memory (osmt_host_alloc / hipHostMalloc / a registered range) and a batch worth
@@ -725,11 +782,10 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     }
     const uint32_t chunk = std::max<uint32_t>(1u, 128u / (batch->scale * batch->scale));
     if (pinned && batch->n_jobs >= 2u * chunk) {
-        hipStream_t s_k = nullptr, s_c = nullptr;
+        hipStream_t s_k = st, s_c = nullptr; /* kernels stay on the call's stream (the scene was uploaded there) */
         hipEvent_t done[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
         char* d_out = nullptr;
-        hipError_t e = hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_c, hipStreamNonBlocking);
+        hipError_t e = stream_acquire(ctx, &s_c);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) {
             e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
@@ -766,10 +822,10 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
             if (done[k]) (void)hipEventDestroy(done[k]);
             if (freed[k]) (void)hipEventDestroy(freed[k]);
         }
-        dev_free(ctx, d_out);
-        if (s_k) (void)hipStreamDestroy(s_k);
-        if (s_c) (void)hipStreamDestroy(s_c);
         osmt_scene_free(sc);
+        dev_free(ctx, d_out);
+        stream_release(ctx, s_c);
+        stream_release(ctx, st);
         return rc;
     }
     void* d_out = nullptr;
@@ -777,22 +833,23 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
         hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * tile_bytes);
         if (e != hipSuccess) {
             osmt_scene_free(sc);
+            stream_release(ctx, st);
             return fail(OSMT_OOM, "hipMalloc(output) failed: %s", hipGetErrorString(e));
         }
     }
-    rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, nullptr);
+    rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, st);
     if (rc == OSMT_OK && batch->n_jobs) {
-        hipError_t e = hipDeviceSynchronize();
-        if (e == hipSuccess) {
-            if (stride == tile_bytes)
-                e = hipMemcpy(out_rgba, d_out, batch->n_jobs * tile_bytes, hipMemcpyDeviceToHost);
-            else
-                e = hipMemcpy2D(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost);
-        }
+        hipError_t e;
+        if (stride == tile_bytes)
+            e = hipMemcpyAsync(out_rgba, d_out, batch->n_jobs * tile_bytes, hipMemcpyDeviceToHost, st);
+        else
+            e = hipMemcpy2DAsync(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
+    osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d_out);
-    osmt_scene_free(sc);
+    stream_release(ctx, st);
     return rc;
 }
 
@@ -832,9 +889,15 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
 int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off) {
     if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = nullptr; /* the whole call lives on its own stream */
+    HIP_TRY(stream_acquire(ctx, &st));
     osmt_scene* sc = nullptr;
-    int rc = osmt_scene_upload(ctx, batch, &sc);
-    if (rc != OSMT_OK) return rc;
+    int rc = scene_upload_impl(ctx, batch, &sc, st);
+    if (rc != OSMT_OK) {
+        stream_release(ctx, st);
+        return rc;
+    }
     if (labels) rc = osmt_scene_set_labels(ctx, sc, labels);
     const uint32_t n = (uint32_t)batch->n_jobs;
     const uint32_t W = OSMT_TILE_SIZE * batch->scale;
@@ -858,25 +921,28 @@ int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
     }
     std::vector<uint32_t> len(n);
     std::vector<unsigned long long> offs(n + 1, 0ull);
-    if (rc == OSMT_OK && n) rc = render_impl(ctx, sc, 7u, d + o_rgba, tile_bytes, false, nullptr);
-    if (rc == OSMT_OK && n) rc = osmt_encode_png_device(ctx, d + o_rgba, tile_bytes, n, W, W, d + o_png, slot, (uint32_t*)(d + o_len), nullptr);
+    if (rc == OSMT_OK && n) rc = render_impl(ctx, sc, 7u, d + o_rgba, tile_bytes, false, st);
+    if (rc == OSMT_OK && n) rc = osmt_encode_png_device(ctx, d + o_rgba, tile_bytes, n, W, W, d + o_png, slot, (uint32_t*)(d + o_len), st);
     if (rc == OSMT_OK && n) {
-        hipError_t e = hipMemcpy(len.data(), d + o_len, n * 4, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpyAsync(len.data(), d + o_len, n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + len[i];
         total = (size_t)offs[n];
         if (e == hipSuccess && total > out_capacity) {
             rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %zu bytes of PNG data", out_capacity, total);
         } else {
-            if (e == hipSuccess) e = hipMemcpy(d + o_off, offs.data(), n * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, offs.data(), n * 8, hipMemcpyHostToDevice, st);
             if (e == hipSuccess)
-                e = osmt_launch_png_compact(d + o_png, slot, (const uint32_t*)(d + o_len), (const unsigned long long*)(d + o_off), n, d + o_blob, nullptr);
-            if (e == hipSuccess) e = hipMemcpy(out_png, d + o_blob, total, hipMemcpyDeviceToHost);
+                e = osmt_launch_png_compact(d + o_png, slot, (const uint32_t*)(d + o_len), (const unsigned long long*)(d + o_off), n, d + o_blob, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_png, d + o_blob, total, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
         }
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
+    osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d);
-    osmt_scene_free(sc);
+    stream_release(ctx, st);
     return rc;
 }
 
