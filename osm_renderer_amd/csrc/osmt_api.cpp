@@ -63,6 +63,7 @@ struct osmt_ctx {
     /* idle non-blocking streams: every host-buffer call runs on its own stream, so calls from the reference's N
      * worker threads (http_server.rs:50-83) overlap on the GPU instead of queueing behind the NULL stream */
     std::vector<hipStream_t> idle_streams;
+    std::vector<cached_buf> host_cache; /* pinned staging buffers (one packed H2D copy per small call) */
     std::vector<osmt_image_desc> images;
     std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
     osmt_image_desc* d_images = nullptr;
@@ -97,6 +98,7 @@ struct osmt_scene {
     std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_lab_wide;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
+    void* h_stage = nullptr;          /* pinned staging of a packed upload, returned to the pool when the scene goes */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
     char* d_lab_base = nullptr;
@@ -167,6 +169,35 @@ void stream_release(osmt_ctx* ctx, hipStream_t st) {
     if (!st) return;
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     ctx->idle_streams.push_back(st);
+}
+
+constexpr size_t STAGE_MAX_BYTES = (size_t)4 << 20; /* calls with more input than this copy array by array */
+
+void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, (size_t)64 << 10);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        for (auto& c : ctx->host_cache)
+            if (!c.used && c.bytes >= bytes) {
+                c.used = true;
+                return c.p;
+            }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr; /* the caller falls back to per-array copies */
+    }
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    ctx->host_cache.push_back({p, bytes, true});
+    return p;
+}
+
+void stage_release(osmt_ctx* ctx, void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    for (auto& c : ctx->host_cache)
+        if (c.p == p) c.used = false;
 }
 
 void dev_free(osmt_ctx* ctx, void* p) {
@@ -383,6 +414,7 @@ void osmt_destroy(osmt_ctx* ctx) {
     if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
     for (auto& c : ctx->cache) (void)hipFree(c.p); /* scenes must be freed before their context */
     for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
+    for (auto& c : ctx->host_cache) (void)hipHostFree(c.p);
     delete ctx;
 }
 
@@ -479,6 +511,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_dashes = carve((b->n_dashes + 1) * 8);
     const size_t o_ptjob = carve(b->n_pts * 4);
     const size_t o_opaux = carve(b->n_ops * 4);
+    const size_t o_opblk = carve(b->n_ops * 4);
+    const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
     const size_t o_den = carve(b->n_pts * 8);
@@ -486,7 +520,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_opnv = carve(b->n_ops + 4);
-    const size_t o_opblk = carve(b->n_ops * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
@@ -518,6 +551,35 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         return st ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t err = hipSuccess;
+    char* stage = (st && front_bytes <= STAGE_MAX_BYTES) ? (char*)stage_acquire(ctx, front_bytes) : nullptr;
+    if (stage) {
+        /* small call: pack the arrays into pinned staging and move them with ONE copy (a dozen pageable copies cost
+         * more host time than the kernels of a single tile) */
+        auto put = [&](size_t o, const void* src, size_t bytes) {
+            if (bytes) memcpy(stage + o, src, bytes);
+        };
+        put(o_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
+        put(o_ops, b->ops, b->n_ops * sizeof(osmt_op));
+        put(o_rings, b->rings, b->n_rings * sizeof(osmt_ring));
+        if (ll) put(o_latlon, b->latlon, b->n_pts * 16);
+        if (nr) put(o_latlon, b->nodes, b->n_nodes * 16);
+        if (nr) put(o_refs, b->node_refs, b->n_pts * 4);
+        if (!ll && !nr) put(o_pts, b->points, b->n_pts * 8);
+        put(o_dashes, b->dashes, b->n_dashes * 8);
+        put(o_ptjob, pt_job.data(), b->n_pts * 4);
+        put(o_opaux, op_aux.data(), b->n_ops * 4);
+        put(o_opblk, op_blk.data(), b->n_ops * 4);
+        s->h_stage = stage;
+        err = hipMemcpyAsync(s->d_base, stage, front_bytes, hipMemcpyHostToDevice, st);
+        if (err != hipSuccess) {
+            stage_release(ctx, stage);
+            dev_free(ctx, s->d_base);
+            delete s;
+            return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
+        }
+        *out_scene = s;
+        return OSMT_OK;
+    }
     if (err == hipSuccess) err = up(s->d_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
     if (err == hipSuccess) err = up(s->d_ops, b->ops, b->n_ops * sizeof(osmt_op));
     if (err == hipSuccess) err = up(s->d_rings, b->rings, b->n_rings * sizeof(osmt_ring));
@@ -551,6 +613,7 @@ void osmt_scene_free(osmt_scene* s) {
         (void)hipDeviceSynchronize();
     dev_free(s->ctx, s->d_base);
     dev_free(s->ctx, s->d_lab_base);
+    stage_release(s->ctx, s->h_stage);
     delete s;
 }
 
