@@ -403,6 +403,31 @@ class TileBatch {
         return out;
     }
 
+    /* Drawer::draw_tile for every added tile (drawer.rs:40-58): finished RGB8 PNG files, written by the GPU */
+    std::vector<std::vector<uint8_t>> render_png() {
+        const size_t dim = TILE_SIZE * scale_;
+        osmt_batch b{};
+        b.jobs = jobs_.data();
+        b.n_jobs = jobs_.size();
+        b.ops = ops_.data();
+        b.n_ops = ops_.size();
+        b.rings = rings_.data();
+        b.n_rings = rings_.size();
+        b.coord_kind = OSMT_COORD_POINT_I32;
+        b.scale = (uint32_t)scale_;
+        b.points = points_.data();
+        b.n_pts = points_.size() / 2;
+        b.dashes = dashes_.data();
+        b.n_dashes = dashes_.size();
+        osmt_label_batch lb{labels_.data(), labels_.size(), label_off_.data(), label_segs_.data(), label_segs_.size() / 4};
+        std::vector<uint8_t> blob(jobs_.size() * osmt_png_device_bound((uint32_t)dim, (uint32_t)dim));
+        std::vector<uint64_t> off(jobs_.size() + 1);
+        check(osmt_render_batch_png(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, blob.data(), blob.size(), off.data()));
+        std::vector<std::vector<uint8_t>> out(jobs_.size());
+        for (size_t t = 0; t < jobs_.size(); ++t) out[t].assign(blob.begin() + (long)off[t], blob.begin() + (long)off[t + 1]);
+        return out;
+    }
+
   private:
     Context* ctx_;
     size_t scale_;

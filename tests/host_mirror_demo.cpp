@@ -95,6 +95,13 @@ int main(int argc, char** argv) {
         dump(both[0].triples);
         dump(both[1].triples);
         fclose(f);
+        if (argc > 2) {  // the first tile again as a PNG file written by the GPU (Drawer::draw_tile)
+            std::vector<std::vector<uint8_t>> png = batch.render_png();
+            FILE* g = fopen(argv[2], "wb");
+            if (!g) return 6;
+            fwrite(png[0].data(), 1, png[0].size(), g);
+            fclose(g);
+        }
         // error behaviour: an invalid scale surfaces as osmt::Error, not a crash
         try {
             TilePixels bad(ctx, 99);

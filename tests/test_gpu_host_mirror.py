@@ -60,9 +60,13 @@ def test_host_mirror_matches_oracle(gpu_ctx, oracle, tmp_path):
 
     torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
     env["LD_LIBRARY_PATH"] = torch_lib + ":" + env.get("LD_LIBRARY_PATH", "")
-    subprocess.check_call([build_demo(), str(out)], env=env)
+    png = tmp_path / "a.png"
+    subprocess.check_call([build_demo(), str(out), str(png)], env=env)
     raw = np.fromfile(out, dtype=np.uint8).reshape(3, 256, 256, 3)
     ta, tb = _oracle_tiles(oracle)
     np.testing.assert_array_equal(raw[0], ta)
+    from PIL import Image
+
+    np.testing.assert_array_equal(np.array(Image.open(png).convert("RGB")), ta)  # TileBatch::render_png
     np.testing.assert_array_equal(raw[1], ta)
     np.testing.assert_array_equal(raw[2], tb)

@@ -75,3 +75,34 @@ def test_generic_widths_take_the_two_pass_kernel(gpu_ctx, shape):
         png = slots[i, : lens[i]].tobytes()
         assert np.array_equal(_decode(png), imgs[i, :, :, :3])
         assert png == _png_model.encode(imgs[i])
+
+
+def test_png_fuzz_against_model(gpu_ctx):
+    """random images with random run structure (flat blocks, stripes, noise patches, gradients), 256 and 512 wide"""
+    import torch
+
+    rng = np.random.default_rng(2027)
+    for W in (256, 512):
+        imgs = np.zeros((8, W, W, 4), dtype=np.uint8)
+        for im in imgs:
+            im[..., :3] = rng.integers(0, 256, size=3)
+            for _ in range(int(rng.integers(1, 30))):
+                x0, y0 = rng.integers(0, W, size=2)
+                w, h = rng.integers(1, W, size=2)
+                kind = rng.integers(0, 4)
+                sl = (slice(y0, min(W, y0 + h)), slice(x0, min(W, x0 + w)))
+                if kind == 0:
+                    im[sl][..., :3] = rng.integers(0, 256, size=3)
+                elif kind == 1:
+                    im[sl][..., :3] = rng.integers(0, 256, size=im[sl][..., :3].shape)
+                elif kind == 2:
+                    im[sl][..., :3] = (np.arange(im[sl].shape[1])[None, :, None] * int(rng.integers(1, 9))) % 256
+                else:
+                    im[sl][..., :3] = (np.arange(im[sl].shape[0])[:, None, None] // int(rng.integers(1, 5))) % 256
+        imgs[..., 3] = 255
+        slots, lens = gpu_ctx.encode_png_device(torch.from_numpy(imgs).cuda())
+        slots, lens = slots.cpu().numpy(), lens.cpu().numpy()
+        for i in range(len(imgs)):
+            png = slots[i, : lens[i]].tobytes()
+            assert png == _png_model.encode(imgs[i]), f"W={W} image {i}: bytes differ from the model"
+            assert np.array_equal(_decode(png), imgs[i, :, :, :3])
