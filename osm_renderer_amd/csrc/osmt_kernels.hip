@@ -1309,10 +1309,12 @@ __device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
 
 #define LC_CELLS OSMT_LABEL_LDS_CELLS
 
-/* sums one draw_line call may park in its lane's registers per batch; calls that need more (long stems
- * crossing many stripes) are replayed stripe-by-stripe by the row owners instead */
-#define LC_MAXE 8
-#define LC_SLOW 0xFFu
+/* A draw_line call parks its sums in its lane's registers, one per CHANNEL = (column parity, A/S kind, stripe
+ * parity): the cells one short call touches always fall into different channels, and a given cell always falls
+ * into the same one, so "consecutive calls adding to the same cell" is simply "consecutive lanes with the same
+ * key in that channel".  Calls whose cells collide in a channel (three cells wide, ...) are replayed stripe by
+ * stripe by the row owners instead. */
+#define LC_CH 8
 #define LC_NOCOL 0xFFFFFFFFu
 
 __device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
@@ -1360,31 +1362,34 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
         for (uint32_t base = 0; base < n_segs; base += 64u) {
             /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
             const uint32_t i = base + lane;
-            bool overlaps = false;
+            bool overlaps = false, slow = false;
             osmt_label_seg sg;
-            uint32_t n = 0;
-            uint32_t ekey[LC_MAXE]; /* kind << 31 | local stripe << 20 | column */
-            double eval[LC_MAXE];
+            uint32_t chmask = 0u;
+            uint32_t ekey[LC_CH]; /* kind << 31 | local stripe << 20 | column */
+            double eval[LC_CH];
 #pragma unroll
-            for (int k = 0; k < LC_MAXE; ++k) {
-                ekey[k] = 0u;
+            for (int k = 0; k < LC_CH; ++k) {
+                ekey[k] = 0xFFFFFFFFu;
                 eval[k] = 0.0;
             }
             if (i < n_segs) {
                 sg = label_seg_prep(segs[i]);
                 overlaps = sg.yl >= band0 && sg.yf <= band1; /* also drops delta == 0 (yf > yl) */
                 if (overlaps) {
-                    int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
-                    auto emit = [&](uint32_t key, double val) {
+                    const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
+                    auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
+                        const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
+                        if ((chmask >> ch) & 1u) slow = true;
+                        chmask |= 1u << ch;
+                        const uint32_t key = (kind << 31) | (row << 20) | col;
 #pragma unroll
-                        for (int k = 0; k < LC_MAXE; ++k)
-                            if ((uint32_t)k == n) {
+                        for (int k = 0; k < LC_CH; ++k)
+                            if ((uint32_t)k == ch) {
                                 ekey[k] = key;
                                 eval[k] = val;
                             }
-                        ++n;
                     };
-                    for (int32_t yy = ya; yy <= yb; ++yy) {
+                    for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
                         /* font/rasterizer.rs:46-80 for stripe yy */
                         const double y_bottom = fmax((double)yy, sg.y_min);
                         const double y_top = fmin((double)(yy + 1), sg.y_max);
@@ -1400,11 +1405,11 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                             oob = true;
                             continue;
                         }
-                        if (n + (uint32_t)(x_to - x_from) + 2u > LC_MAXE) {
-                            n = LC_SLOW;
+                        if (x_to - x_from >= 2) { /* three cells in one stripe share a channel: replay */
+                            slow = true;
                             break;
                         }
-                        const uint32_t rowbits = (uint32_t)(yy - band0) << 20;
+                        const uint32_t row = (uint32_t)(yy - band0);
                         for (int32_t x = x_from; x <= x_to; ++x) {
                             const double x_left = fmax((double)x, x_smallest);
                             const double x_next = (double)(x + 1);
@@ -1418,32 +1423,70 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                                                                           : (y_at_left - y_bottom) + (y_at_right - y_bottom);
                                 pixel_area += trapezoid_width * trapezoid_height / 2.0;
                             }
-                            emit(rowbits | (uint32_t)(x - cx0), sg.sign * pixel_area);
+                            emit(0u, row, (uint32_t)(x - cx0), sg.sign * pixel_area);
                         }
-                        emit(0x80000000u | rowbits | (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
+                        emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
                     }
                 }
             }
-            const unsigned long long m = __ballot(overlaps);
-            /* Consecutive calls of a flattened curve mostly land in the same cells: a lane whose key set equals
-             * its predecessor's continues that lane's RUN.  Runs are applied key by key — sums to different
-             * cells are independent, sums to one cell stay in call order. */
-            bool same_prev = overlaps && n != LC_SLOW && n != 0u;
-            {
-                const uint32_t pn = (uint32_t)__shfl_up((int)n, 1);
-                same_prev = same_prev && lane != 0u && pn == n;
-#pragma unroll
-                for (int k = 0; k < LC_MAXE; ++k) same_prev = same_prev && (uint32_t)__shfl_up((int)ekey[k], 1) == ekey[k];
-            }
-            const unsigned long long sp = __ballot(same_prev) & (m << 1); /* the predecessor must be in the band too */
-            unsigned long long heads = m & ~sp;
             /* ---- phase 2, lane = stripe: the parked sums are applied strictly in call order ---- */
-            while (heads) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(heads);
-                heads &= heads - 1ull;
-                const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((sp >> 1) >> j)); /* bit 63 of sp >> 1 is clear: finite */
-                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j);
-                if (nj == LC_SLOW) {
+            unsigned long long rest = __ballot(overlaps);
+            const unsigned long long slowm = __ballot(overlaps && slow);
+            while (rest) {
+                /* calls before the next replayed one form a segment whose channels can be handled one by one: sums to
+                 * different cells are independent, sums to one cell (one channel, equal keys) stay in call order */
+                const unsigned long long sl_rest = slowm & rest;
+                const uint32_t sl = sl_rest ? (uint32_t)__builtin_ctzll(sl_rest) : 64u;
+                const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
+                const bool in_seg = (seg >> lane) & 1ull;
+#pragma unroll
+                for (int ch = 0; ch < LC_CH; ++ch) {
+                    const bool valid = in_seg && ((chmask >> ch) & 1u);
+                    const unsigned long long vm = __ballot(valid);
+                    if (!vm) continue;
+                    const uint32_t key = ekey[ch];
+                    const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1);
+                    const bool pvalid = lane != 0u && ((vm >> (lane - 1u)) & 1ull);
+                    const bool head = valid && !(pvalid && pkey == key);
+                    unsigned long long hm = __ballot(head);
+                    const unsigned long long cont = vm & ~hm; /* lanes continuing their predecessor's run */
+                    while (hm) {
+                        const uint32_t h = (uint32_t)__builtin_ctzll(hm);
+                        hm &= hm - 1ull;
+                        const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((cont >> 1) >> h));
+                        const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)h);
+                        const uint32_t col = K & 0xFFFFFu;
+                        if (((K >> 20) & 0x7FFu) == lane) { /* the stripe's owner; v_readlane below ignores EXEC */
+                            uint32_t src = h, left = run;
+                            if (K >> 31) {
+                                if (col != s_col) {
+                                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+                                    s_val = s_row[col];
+                                    s_col = col;
+                                }
+                                do {
+                                    s_val += readlane_f64(eval[ch], src);
+                                    ++src;
+                                } while (--left);
+                            } else {
+                                if (col != a_col) {
+                                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+                                    a_val = a_row[col];
+                                    a_col = col;
+                                }
+                                do {
+                                    a_val += readlane_f64(eval[ch], src);
+                                    ++src;
+                                } while (--left);
+                            }
+                            c_min = min(c_min, col);
+                            c_max = max(c_max, col);
+                        }
+                    }
+                }
+                if (sl >= 64u) break;
+                { /* the replayed call works on LDS directly: write the cached cells back first */
+                    const uint32_t j = sl;
                     osmt_label_seg q;
                     q.x0 = readlane_f64(sg.x0, j);
                     q.y0 = readlane_f64(sg.y0, j);
@@ -1454,7 +1497,6 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     q.sign = readlane_f64(sg.sign, j);
                     q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
                     q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
-                    /* the replay works on LDS directly: write the cached cells back first */
                     if (a_col != LC_NOCOL) a_row[a_col] = a_val;
                     if (s_col != LC_NOCOL) s_row[s_col] = s_val;
                     a_col = s_col = LC_NOCOL;
@@ -1466,71 +1508,8 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                             c_max = max(c_max, (uint32_t)(x_max - cx0));
                         }
                     }
-                    continue;
                 }
-                if (nj == 2u) {
-                    /* the common call: one cell (A key) + its S key, same stripe, same owner: both sums in one loop */
-                    const uint32_t ka = (uint32_t)__builtin_amdgcn_readlane((int)ekey[0], (int)j);
-                    const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)ekey[1], (int)j);
-                    if ((ka >> 31) == 0u && (ks >> 31) == 1u && ((ka ^ ks) & 0x7FF00000u) == 0u) {
-                        if (((ka >> 20) & 0x7FFu) == lane) {
-                            const uint32_t ca = ka & 0xFFFFFu, cs = ks & 0xFFFFFu;
-                            if (ca != a_col) {
-                                if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-                                a_val = a_row[ca];
-                                a_col = ca;
-                            }
-                            if (cs != s_col) {
-                                if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-                                s_val = s_row[cs];
-                                s_col = cs;
-                            }
-                            c_min = min(c_min, min(ca, cs));
-                            c_max = max(c_max, max(ca, cs));
-                            uint32_t src = j, left = run;
-                            do { /* v_readlane ignores EXEC: only the owner lane executes the run's adds */
-                                a_val += readlane_f64(eval[0], src);
-                                s_val += readlane_f64(eval[1], src);
-                                ++src;
-                            } while (--left);
-                        }
-                        continue;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < LC_MAXE; ++e) {
-                    if ((uint32_t)e < nj) {
-                        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)ekey[e], (int)j);
-                        const bool mine = ((key >> 20) & 0x7FFu) == lane;
-                        const uint32_t col = key & 0xFFFFFu;
-                        /* register selects only (no pointers to the cached values: those would be demoted to scratch) */
-                        const bool is_s = (key >> 31) != 0u;
-                        uint32_t cur_col = is_s ? s_col : a_col;
-                        double cur_val = is_s ? s_val : a_val;
-                        if (mine) {
-                            double* row = is_s ? s_row : a_row;
-                            if (col != cur_col) {
-                                if (cur_col != LC_NOCOL) row[cur_col] = cur_val;
-                                cur_val = row[col];
-                                cur_col = col;
-                            }
-                            c_min = min(c_min, col);
-                            c_max = max(c_max, col);
-                        }
-                        if (mine) {
-                            /* v_readlane ignores EXEC: only the owner lane executes the run's adds */
-                            uint32_t src = j, left = run;
-                            do {
-                                cur_val += readlane_f64(eval[e], src);
-                                ++src;
-                            } while (--left);
-                            s_col = is_s ? cur_col : s_col;
-                            s_val = is_s ? cur_val : s_val;
-                            a_col = is_s ? a_col : cur_col;
-                            a_val = is_s ? a_val : cur_val;
-                        }
-                    }
-                }
+                rest &= ~((2ull << sl) - 1ull);
             }
         }
         if (a_col != LC_NOCOL) a_row[a_col] = a_val;
