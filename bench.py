@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line with the whole-job tiles/s plus
   roofline_composite  the 8-layer @2x composite pass (the kernel the >= 40 % HBM target is on)
   cpu_baseline        the C++ oracle (restatement of the reference's Rust CPU path, NOT the
                       Rust binary) on the host cores, bounded sample of the same workload
+  png_encode          SURVEY.md 8(f) N3: the framebuffers of the step turned into PNG files on the GPU
+  label_pass          SURVEY.md 8(f) N1: the same tiles with 24 synthetic labels per tile on top
 """
 import argparse
 import json
@@ -43,6 +45,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     ap.add_argument("--no-labels", action="store_true")
+    ap.add_argument("--no-png", action="store_true")
     ap.add_argument("--label-tiles", type=int, default=1024)
     args = ap.parse_args()
 
@@ -187,6 +190,32 @@ def main():
             "tiles_per_launch": n,
         }
         del planes, cout
+
+    # ---- PNG files written by the GPU from the framebuffers of the timed steps — rank 0, N = 1 only ----
+    if rank == 0 and world == 1 and not args.no_png:
+        slots, lens = ctx.encode_png_device(out)
+        torch.cuda.synchronize()
+        reps = 10
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for _ in range(reps):
+            slots, lens = ctx.encode_png_device(out)
+        p1.record()
+        torch.cuda.synchronize()
+        p_s = p0.elapsed_time(p1) / reps / 1e3
+        png_bytes = int(lens.sum().item())
+        p_alg = out.numel() + png_bytes  # RGBA8 read once + files written once
+        result["png_encode"] = {
+            "kernel": "k_png_encode_fast (Paeth + fixed-Huffman run-length deflate + Adler-32/CRC-32, one workgroup per tile)",
+            "tiles": int(out.shape[0]),
+            "avg_launch_ms": p_s * 1e3,
+            "tiles_per_s": out.shape[0] / p_s,
+            "png_bytes_per_tile": png_bytes / out.shape[0],
+            "ratio_vs_rgba8": out.numel() / png_bytes,
+            "bound": "hbm", "achieved": p_alg / p_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": p_alg / p_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": p_alg,
+        }
+        del slots, lens
 
     # ---- label pass on top of the same area workload — rank 0, N = 1 only ----
     if rank == 0 and world == 1 and not args.no_labels:
