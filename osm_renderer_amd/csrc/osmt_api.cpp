@@ -33,6 +33,21 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+/* No C++ exception may cross the C boundary (a std::bad_alloc from a host-side table, say): every entry point
+ * runs its body through this. */
+template <class F>
+int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(OSMT_OOM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(OSMT_HIP_ERROR, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(OSMT_HIP_ERROR, "internal error");
+    }
+}
+
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \
@@ -389,7 +404,7 @@ uint32_t osmt_version(void) { return (1u << 16) | 0u; }
 
 const char* osmt_last_error(void) { return g_last_error.c_str(); }
 
-int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx) {
+static int osmt_create_body(const osmt_config* cfg, osmt_ctx** out_ctx) {
     if (!out_ctx) return fail(OSMT_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
     int n = 0;
@@ -407,6 +422,10 @@ int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx) {
     return OSMT_OK;
 }
 
+int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx) {
+    return guarded([&] { return osmt_create_body(cfg, out_ctx); });
+}
+
 void osmt_destroy(osmt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -418,7 +437,7 @@ void osmt_destroy(osmt_ctx* ctx) {
     delete ctx;
 }
 
-int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_id) {
+static int osmt_register_image_body(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_id) {
     if (!ctx || !rgba8 || !out_id) return fail(OSMT_INVALID_ARG, "NULL argument");
     if (width == 0 || height == 0) return fail(OSMT_INVALID_ARG, "empty image");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -440,6 +459,10 @@ int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uin
     ctx->images.push_back(d);
     ctx->images_dirty = true;
     return OSMT_OK;
+}
+
+int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_id) {
+    return guarded([&] { return osmt_register_image_body(ctx, rgba8, width, height, out_id); });
 }
 
 /* st == nullptr: blocking copies (the public osmt_scene_upload); otherwise stream-ordered on `st`, the caller
@@ -600,7 +623,9 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     return OSMT_OK;
 }
 
-int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) { return scene_upload_impl(ctx, b, out_scene, nullptr); }
+int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
+    return guarded([&] { return scene_upload_impl(ctx, b, out_scene, nullptr); });
+}
 
 void osmt_scene_free(osmt_scene* s) {
     if (!s) return;
@@ -621,7 +646,7 @@ void osmt_scene_free(osmt_scene* s) {
  * uploads.  Window of a label = stripes its draw_line calls can create inside labels_bb's rows
  * (tile_pixels.rs:67-72) x every column those stripes can hold a key in (+-2 cells of slack for the
  * rounding of eval_x_at_y, font/rasterizer.rs:37). */
-int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch* lb) {
+static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch* lb) {
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = sc->own_stream;
@@ -768,7 +793,11 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch*
     return OSMT_OK;
 }
 
-int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* sc, uint8_t* ok) {
+int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* sc, const osmt_label_batch* lb) {
+    return guarded([&] { return osmt_scene_set_labels_body(ctx, sc, lb); });
+}
+
+static int osmt_scene_read_label_status_body(osmt_ctx* ctx, osmt_scene* sc, uint8_t* ok) {
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     if (sc->n_labels == 0) return OSMT_OK;
     if (!ok) return fail(OSMT_INVALID_ARG, "NULL argument");
@@ -781,20 +810,37 @@ int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* sc, uint8_t* ok) {
     return OSMT_OK;
 }
 
-int osmt_render_scene(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t stride, void* stream) {
+int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* sc, uint8_t* ok) {
+    return guarded([&] { return osmt_scene_read_label_status_body(ctx, sc, ok); });
+}
+
+static int osmt_render_scene_body(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t stride, void* stream) {
     return render_impl(ctx, scene, 7u, d_out_rgba, stride, false, stream);
 }
 
-int osmt_render_scene_f64(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, void* stream) {
+int osmt_render_scene(osmt_ctx* ctx, osmt_scene* scene, void* d_out_rgba, size_t stride, void* stream) {
+    return guarded([&] { return osmt_render_scene_body(ctx, scene, d_out_rgba, stride, stream); });
+}
+
+static int osmt_render_scene_f64_body(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, void* stream) {
     return render_impl(ctx, scene, 7u, d_out_f64, 0, true, stream);
 }
 
-int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba, size_t stride,
+int osmt_render_scene_f64(osmt_ctx* ctx, osmt_scene* scene, void* d_out_f64, void* stream) {
+    return guarded([&] { return osmt_render_scene_f64_body(ctx, scene, d_out_f64, stream); });
+}
+
+static int osmt_render_scene_stages_body(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba, size_t stride,
                              void* stream) {
     return render_impl(ctx, scene, stage_mask & 7u, d_out_rgba, stride, false, stream);
 }
 
-int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
+int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_mask, void* d_out_rgba, size_t stride,
+                             void* stream) {
+    return guarded([&] { return osmt_render_scene_stages_body(ctx, scene, stage_mask, d_out_rgba, stride, stream); });
+}
+
+static int osmt_scene_read_points_body(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
     if (!ctx || !sc || !xy) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -802,11 +848,15 @@ int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
     return OSMT_OK;
 }
 
+int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
+    return guarded([&] { return osmt_scene_read_points_body(ctx, sc, xy); });
+}
+
 int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba, size_t stride) {
     return osmt_render_batch_labels(ctx, batch, nullptr, out_rgba, stride);
 }
 
-int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
+static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
                              size_t stride) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -916,6 +966,11 @@ int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_
     return rc;
 }
 
+int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
+                             size_t stride) {
+    return guarded([&] { return osmt_render_batch_labels_body(ctx, batch, labels, out_rgba, stride); });
+}
+
 /* ---- PNG files straight from the GPU -------------------------------------- */
 static uint32_t ihdr_crc(uint32_t W, uint32_t H) {
     /* CRC-32 of "IHDR" + width, height, 8, 2, 0, 0, 0 (bitwise; once per call) */
@@ -936,7 +991,7 @@ size_t osmt_png_device_bound(uint32_t W, uint32_t H) {
     return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8 + 128, 256);
 }
 
-int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,
+static int osmt_encode_png_device_body(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,
                            size_t png_stride, uint32_t* d_len, void* stream) {
     if (!ctx) return fail(OSMT_INVALID_ARG, "NULL argument");
     if (n == 0) return OSMT_OK;
@@ -949,7 +1004,12 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
     return OSMT_OK;
 }
 
-int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
+int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,
+                           size_t png_stride, uint32_t* d_len, void* stream) {
+    return guarded([&] { return osmt_encode_png_device_body(ctx, d_rgba, tile_stride, n, W, H, d_png, png_stride, d_len, stream); });
+}
+
+static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off) {
     if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1009,12 +1069,21 @@ int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
     return rc;
 }
 
-int osmt_host_alloc(osmt_ctx* ctx, size_t bytes, void** out) {
+int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
+                          uint64_t* out_off) {
+    return guarded([&] { return osmt_render_batch_png_body(ctx, batch, labels, out_png, out_capacity, out_off); });
+}
+
+static int osmt_host_alloc_body(osmt_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return OSMT_OK;
+}
+
+int osmt_host_alloc(osmt_ctx* ctx, size_t bytes, void** out) {
+    return guarded([&] { return osmt_host_alloc_body(ctx, bytes, out); });
 }
 
 void osmt_host_free(osmt_ctx* ctx, void* p) {
@@ -1023,7 +1092,7 @@ void osmt_host_free(osmt_ctx* ctx, void* p) {
     (void)hipHostFree(p);
 }
 
-int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tx, uint32_t ty, double scale,
+static int osmt_project_body(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tx, uint32_t ty, double scale,
                  int32_t* xy) {
     if (!ctx || (n && (!latlon || !xy))) return fail(OSMT_INVALID_ARG, "NULL argument");
     if (n >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "too many points");
@@ -1043,7 +1112,12 @@ int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, ui
     return OSMT_OK;
 }
 
-int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canvas[4], uint32_t n, uint32_t L,
+int osmt_project(osmt_ctx* ctx, const double* latlon, size_t n, uint8_t zoom, uint32_t tx, uint32_t ty, double scale,
+                 int32_t* xy) {
+    return guarded([&] { return osmt_project_body(ctx, latlon, n, zoom, tx, ty, scale, xy); });
+}
+
+static int osmt_composite_device_body(osmt_ctx* ctx, const void* d_planes, const double canvas[4], uint32_t n, uint32_t L,
                           uint32_t W, uint32_t H, void* d_out, void* stream) {
     if (!ctx || !canvas) return fail(OSMT_INVALID_ARG, "NULL argument");
     if ((uint64_t)W * H >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "tile too large");
@@ -1054,7 +1128,12 @@ int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canv
     return OSMT_OK;
 }
 
-int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t W,
+int osmt_composite_device(osmt_ctx* ctx, const void* d_planes, const double canvas[4], uint32_t n, uint32_t L,
+                          uint32_t W, uint32_t H, void* d_out, void* stream) {
+    return guarded([&] { return osmt_composite_device_body(ctx, d_planes, canvas, n, L, W, H, d_out, stream); });
+}
+
+static int osmt_composite_body(osmt_ctx* ctx, const double* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t W,
                    uint32_t H, uint8_t* out_rgba) {
     if (!ctx || !canvas) return fail(OSMT_INVALID_ARG, "NULL argument");
     const size_t npx = (size_t)n * W * H;
@@ -1074,6 +1153,11 @@ int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas[4], 
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(OSMT_HIP_ERROR, "osmt_composite: %s", hipGetErrorString(e));
     return rc;
+}
+
+int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t W,
+                   uint32_t H, uint8_t* out_rgba) {
+    return guarded([&] { return osmt_composite_body(ctx, planes, canvas, n, L, W, H, out_rgba); });
 }
 
 } /* extern "C" */

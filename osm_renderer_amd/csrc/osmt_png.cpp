@@ -53,7 +53,12 @@ int osmt_encode_png(const uint8_t* rgba, uint32_t width, uint32_t height, size_t
         return osmt_fail_public(OSMT_INVALID_ARG, "osmt_encode_png: output buffer smaller than osmt_png_bound()");
     /* scanlines: filter byte 0 + RGB (alpha dropped: the framebuffer's A is the constant 255) */
     const size_t line = (size_t)width * 3 + 1;
-    std::vector<uint8_t> raw(line * height);
+    std::vector<uint8_t> raw;
+    try { /* no C++ exception may cross the C boundary */
+        raw.resize(line * height);
+    } catch (...) {
+        return osmt_fail_public(OSMT_OOM, "osmt_encode_png: out of host memory");
+    }
     for (uint32_t y = 0; y < height; ++y) {
         uint8_t* d = raw.data() + y * line;
         const uint8_t* s = rgba + (size_t)y * row_stride_bytes;
@@ -80,7 +85,12 @@ int osmt_encode_png(const uint8_t* rgba, uint32_t width, uint32_t height, size_t
     ihdr[12] = 0; /* no interlace */
     off += chunk(out_png + off, "IHDR", ihdr, 13);
     uLongf zlen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(zlen);
+    std::vector<uint8_t> z;
+    try {
+        z.resize(zlen);
+    } catch (...) {
+        return osmt_fail_public(OSMT_OOM, "osmt_encode_png: out of host memory");
+    }
     if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), level) != Z_OK)
         return osmt_fail_public(OSMT_HIP_ERROR, "osmt_encode_png: zlib compress2 failed");
     off += chunk(out_png + off, "IDAT", z.data(), (uint32_t)zlen);
