@@ -32,7 +32,8 @@
  *     1135 compared pixels, 0 differ — with NOTHING fitted but the node's integer position (read off the
  *     icon): outlines and metrics come from the reference's own font through a restatement of the
  *     stb_truetype calls text_placer.rs makes (tests/golden/make_ref_label_patches.py,
- *     tests/test_reference_golden_labels.py).  A 0.1-px text offset no longer matches.  Not covered by a
+ *     tests/test_reference_golden_labels.py).  A 0.1-px text offset no longer matches.  A second crop (z14,
+ *     font-size 9) shows the same label hanging into the tile below its node's tile.  Not covered by a
  *     reference output: labels that COLLIDE (hand-derived cases in tests/test_labels_oracle.py, from the
  *     reference source) and TextPosition::Line placement (host side, outside the oracle).
  *   - NOT pinned by any reference output (the reference cannot be built here — no rustc/cargo,

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Builds tests/golden/ref_label_patches.json: a label of the reference's OWN golden image
 tests/rendered/17_expected.png (z17 mosaic, tile col 0 / row 2) together with the label display list
-(osmt_label: icon + Rasterizer::draw_line calls) that re-synthesises it.
+(osmt_label: icon + Rasterizer::draw_line calls) that re-synthesises it, plus the same station at z14 seen from
+the tile below it (see main()).
 
 The label is the metro station node "Арбатская": icon symbols/station.png (mapnik.mapcss:6073-6075) and the
 text rule mapnik.mapcss:6123-6131 (font-size 11, text-color #6666ff; nodes are placed with
@@ -307,9 +308,33 @@ def main():
             "expected_rgb": tile[y0 : y1 + 1, x0 : x1 + 1].tolist(),
         },
     }
+    # The same station at z14 (tests/rendered/14_expected.png): icon symbols/station_small.png (mapnik.mapcss:6065-6067,
+    # 6x6, found at x 135..140, y 246..251 of mosaic tile (0, 0) -> node at (138, 249)), font-size 9 (mapnik.mapcss:6113-
+    # 6121).  The label hangs over the tile's lower edge: the tile BELOW, mosaic tile (col 0, row 1), sees the same node
+    # at (138, 249 - 256 = -7) inside its 3x3 label area (tile_pixels.rs:67-72) and draws the glyphs' lowest rows.  Rows
+    # 1..4 of that tile left of x = 147 hold nothing but canvas and those glyph rows (row 0 is the mosaic's red grid line).
+    im14 = np.array(Image.open(os.path.join(REF, "tests/rendered/14_expected.png")).convert("RGB"))
+    tile14 = im14[256:512, 0:256]
+    icon14 = np.array(Image.open(os.path.join(REF, "tests/mapcss/symbols/station_small.png")).convert("RGBA"))
+    cx, cy = 138, 249 - 256
+    segs14 = center_text_segments(font, "Арбатская", 9.0, float(cx), float(cy), icon14.shape[0] // 2)
+    x0, x1, y0, y1 = 100, 146, 1, 4
+    out["station_z14_from_the_tile_above"] = {
+        "source": "tests/rendered/14_expected.png, mosaic tile (col 0, row 1), tile-relative pixel coordinates",
+        "window_x0_x1_y0_y1": [x0, x1, y0, y1],
+        "canvas": [0xF1, 0xEE, 0xE8],
+        "icon_rgba": icon14.tolist(),
+        "icon_center": [float(cx), float(cy)],
+        "text_color": [0x66, 0x66, 0xFF],
+        "segs": segs14.tolist(),
+        "mask_rows": ["1" * (x1 - x0 + 1) for _ in range(y0, y1 + 1)],
+        "expected_rgb": tile14[y0 : y1 + 1, x0 : x1 + 1].tolist(),
+    }
     with open(os.path.join(HERE, "ref_label_patches.json"), "w") as f:
         json.dump(out, f)
-    print("station: draw_line calls", len(segs), "mask px", int(mask.sum()))
+    w14 = tile14[y0 : y1 + 1, x0 : x1 + 1]
+    print("station: draw_line calls", len(segs), "mask px", int(mask.sum()), "| z14:", len(segs14), "calls,",
+          int((w14 != np.array([0xF1, 0xEE, 0xE8])).any(-1).sum()), "covered px")
 
 
 if __name__ == "__main__":
