@@ -123,3 +123,125 @@ def test_label_lists_concat_and_subset_roundtrip():
     assert np.array_equal(back.labels, ll.labels) and np.array_equal(back.segs, ll.segs)
     assert np.array_equal(back.job_label_off, ll.job_label_off)
     assert ll.algorithmic_bytes() == 40 * 20 + 32 * len(ll.segs)
+
+
+# ---- an independent, dictionary-based Python restatement of the label pass, for differential checks of the oracle ----
+def _py_rasterize(segs):
+    """font/rasterizer.rs:27-88 + :115-147 with plain dicts (BTreeMap order = sorted keys)"""
+    import math
+
+    stripes = {}
+    for x0, y0, x1, y1 in segs:
+        delta = y1 - y0
+        if delta == 0.0:
+            continue
+        sign = 1.0 if y0 <= y1 else -1.0
+        slope = (x1 - x0) / delta
+        rec = (1.0 / slope) if slope != 0.0 else math.copysign(math.inf, slope)
+        y_min, y_max = min(y0, y1), max(y0, y1)
+        for y in range(math.floor(y_min), math.floor(y_max) + 1):
+            st = stripes.setdefault(y, ({}, {}))
+            yb, yt = max(float(y), y_min), min(float(y + 1), y_max)
+            yd = yt - yb
+            xb, xt = x0 + (yb - y0) * slope, x0 + (yt - y0) * slope
+            flip, xs, xl = (False, xb, xt) if xb <= xt else (True, xt, xb)
+            x_to = math.floor(xl)
+            for x in range(math.floor(xs), x_to + 1):
+                x_left, x_next = max(float(x), xs), float(x + 1)
+                x_right = min(x_next, xl)
+                area = (x_next - x_right) * yd
+                w = x_right - x_left
+                if w > 0.0:
+                    yl, yr = y0 + (x_left - x0) * rec, y0 + (x_right - x0) * rec
+                    h = (yt - yl) + (yt - yr) if flip else (yl - yb) + (yr - yb)
+                    area += w * h / 2.0
+                st[0][x] = st[0].get(x, 0.0) + sign * area
+            st[1][x_to + 1] = st[1].get(x_to + 1, 0.0) + sign * yd
+    for y in sorted(stripes):
+        a, s = stripes[y]
+        keys = list(a) + list(s)
+        acc = 0.0
+        for x in range(min(keys), max(keys) + 1):
+            acc += s.get(x, 0.0)
+            total = min(a.get(x, 0.0) + acc, 1.0)
+            if total > 0.0:
+                yield x, y, total
+
+
+def _py_label_pass(canvas_rgb, labels_in, icons, W=256):
+    """tile_pixels.rs:131-162 + the for_labels blend (:205-223), labeler.rs:16-106; returns (rgb u8 [W][W][3], statuses)"""
+    pixels = {}
+    nxt, statuses = {}, []
+    cv = tuple(1.0 * (c / 255.0) for c in canvas_rgb)
+
+    def set_label_pixel(x, y, color):
+        if x < -W or x > 2 * W - 1 or y < -W or y > 2 * W - 1:
+            return True
+        gen = len(statuses)
+        if (x, y) in nxt and nxt[(x, y)][1] < gen and statuses[nxt[(x, y)][1]]:
+            return False
+        nxt[(x, y)] = (color, gen)
+        return True
+
+    for icon, text in labels_in:
+        ok = True
+        if icon is not None:
+            img, cx, cy = icon
+            h, w, _ = img.shape
+            sx, sy = int(cx - w / 2.0), int(cy - h / 2.0)
+            for x in range(w):
+                for y in range(h):
+                    r, g, b, a = [int(v) for v in img[y, x]]
+                    o = a / 255.0
+                    if not set_label_pixel(sx + x, sy + y, (o * (r / 255.0), o * (g / 255.0), o * (b / 255.0), o)):
+                        ok = False
+                        break
+                if not ok:
+                    break
+        if ok and text is not None:
+            color, segs = text
+            for x, y, t in _py_rasterize(segs):
+                if not set_label_pixel(x, y, tuple(t * (c / 255.0) for c in color) + (t,)):
+                    ok = False
+                    break
+        statuses.append(ok)
+    out = np.zeros((W, W, 3), dtype=np.uint8)
+    for y in range(W):
+        for x in range(W):
+            p = cv
+            if (x, y) in nxt and statuses[nxt[(x, y)][1]]:
+                c = nxt[(x, y)][0]
+                p = tuple(c[k] + (1.0 - c[3]) * p[k] for k in range(3))
+            out[y, x] = [int(255.0 * v) for v in p]
+    return out, statuses
+
+
+def test_oracle_label_pass_against_an_independent_python_model(oracle):
+    """random crowded labels (text runs, icons, both): verdicts and every pixel equal the dictionary-based model"""
+    rng = np.random.default_rng(99)
+    icons = [rng.integers(0, 256, size=(9, 9, 4)).astype(np.uint8), rng.integers(0, 256, size=(5, 12, 4)).astype(np.uint8)]
+    icons[0][:3, :, 3] = 255
+    outcomes = []
+    for trial in range(3):
+        tl = labels.TileLabels()
+        model_in = []
+        for _ in range(30):
+            cx, cy = float(rng.integers(-20, 110)) + 0.5 * float(rng.integers(0, 2)), float(rng.integers(-20, 110))
+            icon = text = None
+            if rng.random() < 0.5:
+                k = int(rng.integers(0, 2))
+                icon = (k, cx, cy)
+            if rng.random() < 0.8:
+                segs, _ = labels.synth_text(rng, cx - 20.0, cy + 8.0, float(rng.choice([9.0, 13.0])), int(rng.integers(1, 5)),
+                                            float(rng.choice([0.0, 0.4])))
+                text = (tuple(int(v) for v in rng.integers(0, 256, size=3)), segs)
+            tl.label(icon=icon, text=text)
+            model_in.append(((icons[icon[0]], icon[1], icon[2]) if icon else None, text))
+        canvas = (0xF1, 0xEE, 0xE8)
+        dl = TileBuilder(canvas=canvas).build()
+        got, st = oracle.render_job(dl, 0, images=icons, labels=tl.build(), want_status=True)
+        want, wst = _py_label_pass(canvas, model_in, icons)
+        assert st.tolist() == [1 if v else 0 for v in wst], trial
+        assert np.array_equal(got[..., :3], want), trial
+        outcomes.extend(wst)
+    assert 10 <= sum(outcomes) <= len(outcomes) - 5  # both verdicts occur
