@@ -348,6 +348,10 @@ def main():
         if args.tiles == 1024 and args.scale == 1 and args.n_poly == 50 and args.n_line == 40:
             result["roofline"]["traffic"] = tr["k_raster"]["traffic_bytes_per_launch_fetch_x2"]
             result["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC pass of an earlier run of this command"
+        if "png_encode" in result and "k_png_encode_fast" in tr and args.tiles == 1024 and args.scale == 1:
+            result["png_encode"]["traffic"] = tr["k_png_encode_fast"]["traffic_bytes_per_launch_fetch_x2"]
+        if "label_pass" in result and "k_label_cover" in tr and args.label_tiles == 1024 and args.scale == 1:
+            result["label_pass"]["traffic_k_label_cover"] = tr["k_label_cover"]["traffic_bytes_per_launch_fetch_x2"]
         if "roofline_composite" in result and args.composite_tiles == 64:
             result["roofline_composite"]["traffic"] = tr["k_composite"]["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
