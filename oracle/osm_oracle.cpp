@@ -40,7 +40,8 @@
  *     crates not vendored — and tests/osm/nano_moscow.osm is absent): Square/Butt caps,
  *     use_caps_for_dashes = false, image fills.  For these the
  *     oracle is checked only against the hand-derived vectors K1..K8 (tests/golden/kat.json,
- *     derived from the reference SOURCE).  Status of those parts: PARITY UNPINNED.
+ *     derived from the reference SOURCE) and against a second, independent Python restatement
+ *     (tests/_py_area_model.py).  Status of those parts: PARITY UNPINNED.
  *
  * Rust -> C++ semantics kept on purpose:
  *   f64::round -> std::round (half away from zero); `as i32` / `as u8` ->
