@@ -5,9 +5,12 @@
  *   k_opinfo     per-op pixel extents, traveled distances and dash tables
  *                (src/draw/line.rs:21-33, src/draw/opacity_calculator.rs:16-30,98-143)
  *   k_raster     fill_contour + draw_lines + set_pixel/blend + to_rgb_triples, fused per
- *                32x32-pixel sub-tile (src/draw/fill.rs, line.rs, opacity_calculator.rs,
+ *                32x16-pixel sub-tile (src/draw/fill.rs, line.rs, opacity_calculator.rs,
  *                tile_pixels.rs, drawer.rs:133-219)
  *   k_composite  blend_pixel over L resident layers + to_rgb_triples (tile_pixels.rs:205-223,164-181)
+ *
+ * The label pass (k_label_cover / k_label_resolve) lives in osmt_labels.hip — k_raster<LABELS> here blends its
+ * survivors — and the PNG encoder (k_png_encode*) in osmt_pngenc.hip.
  *
  * Everything is f64 / integer and compiled with -ffp-contract=off: the reference never
  * forms an FMA and its u8 output is a truncation, so contraction would flip pixels
@@ -1231,1092 +1234,6 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
 }  // namespace
 
 /* ---- launchers (C++ internal interface, see osmt_internal.h) ---------------- */
-/* ------------------------------------------------------------------------- */
-/* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
- *
- * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; the wave digests the
- *                  draw_line calls 64 at a time (one call per lane: the y-independent part of draw_line,
- *                  two f64 divisions) into LDS, then every lane walks the calls that cross the band IN
- *                  CALL ORDER and adds those that cross its stripe into its own row of the LDS-resident
- *                  A / S accumulators — the per-key f64 sums therefore happen in exactly the reference's
- *                  order (BTreeMap entry += ..., :77,:80) with no atomics.  Then the lane runs
- *                  save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and the band is
- *                  copied out coalesced: total = min(a + s_acc, 1.0) per cell, 0 where the stripe has no key.
- * k_label_resolve  one workgroup per tile, labels strictly in draw order: a label succeeds iff none of
- *                  the pixels it would set (icon rectangle, then cells with total > 0) inside labels_bb
- *                  belongs to an earlier SUCCEEDED label (set_label_pixel, tile_pixels.rs:131-148;
- *                  pixels of failed labels are overwritten freely); succeeded labels mark their pixels
- *                  in a (3W)^2-bit ownership map.  The early `return false` of draw_icon /
- *                  save_to_figure only skips pixels of a label that is not blended anyway.
- * k_raster<LABELS> blends the succeeded labels over the area canvas before to_rgb_triples. */
-/* draw_line for stripe y (font/rasterizer.rs:46-80) into the stripe's own accumulator rows */
-__device__ __forceinline__ bool label_stripe(const osmt_label_seg& sg, int32_t y, int32_t cx0, uint32_t cols, double* a_row,
-                                             double* s_row, int32_t& x_min, int32_t& x_max) {
-    const double x0 = sg.x0, y0 = sg.y0, slope = sg.slope, recip = sg.slope_recip, sign = sg.sign;
-    const double y_bottom = fmax((double)y, sg.y_min);
-    const double y_top = fmin((double)(y + 1), sg.y_max);
-    const double y_delta = y_top - y_bottom;
-    const double x_at_bottom = x0 + (y_bottom - y0) * slope;
-    const double x_at_top = x0 + (y_top - y0) * slope;
-    const bool flip_edge = !(x_at_bottom <= x_at_top);
-    const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
-    const double x_largest = flip_edge ? x_at_bottom : x_at_top;
-    const int32_t x_to = (int32_t)floor(x_largest);
-    const int32_t x_from = (int32_t)floor(x_smallest);
-    if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) return false; /* cannot happen: the window is conservative */
-    for (int32_t x = x_from; x <= x_to; ++x) {
-        const double x_left = fmax((double)x, x_smallest);
-        const double x_next = (double)(x + 1);
-        const double x_right = fmin(x_next, x_largest);
-        double pixel_area = (x_next - x_right) * y_delta;
-        const double trapezoid_width = x_right - x_left;
-        if (trapezoid_width > 0.0) {
-            const double y_at_left = y0 + (x_left - x0) * recip;
-            const double y_at_right = y0 + (x_right - x0) * recip;
-            const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
-                                                      : (y_at_left - y_bottom) + (y_at_right - y_bottom);
-            pixel_area += trapezoid_width * trapezoid_height / 2.0;
-        }
-        a_row[x - cx0] += sign * pixel_area;
-    }
-    s_row[x_to + 1 - cx0] += sign * y_delta;
-    x_min = min(x_min, x_from);
-    x_max = max(x_max, x_to + 1);
-    return true;
-}
-
-/* the y-independent part of draw_line (font/rasterizer.rs:27-41) */
-__device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
-    const double x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
-    osmt_label_seg r;
-    const double delta = y1 - y0;
-    r.x0 = x0;
-    r.y0 = y0;
-    r.sign = (y0 <= y1) ? 1.0 : -1.0;
-    r.slope = (x1 - x0) / delta;
-    r.slope_recip = 1.0 / r.slope;
-    r.y_min = fmin(y0, y1);
-    r.y_max = fmax(y0, y1);
-    if (delta == 0.0) {
-        r.yf = 1;
-        r.yl = 0;
-    } else {
-        r.yf = (int32_t)floor(r.y_min);
-        r.yl = (int32_t)floor(r.y_max);
-    }
-    return r;
-}
-
-#define LC_CELLS OSMT_LABEL_LDS_CELLS
-
-/* A draw_line call parks its sums in its lane's registers, one per CHANNEL = (column parity, A/S kind, stripe
- * parity): the cells one short call touches always fall into different channels, and a given cell always falls
- * into the same one, so "consecutive calls adding to the same cell" is simply "consecutive lanes with the same
- * key in that channel".  Calls whose cells collide in a channel (three cells wide, ...) are replayed stripe by
- * stripe by the row owners instead. */
-#define LC_CH 8
-#define LC_NOCOL 0xFFFFFFFFu
-
-__device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)j);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)j);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-
-__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab, uint32_t n_labels,
-                                                    const double4* __restrict__ g_seg, double* __restrict__ g_a,
-                                                    uint32_t* g_err) {
-    __shared__ double sh_a[LC_CELLS];
-    __shared__ double sh_s[LC_CELLS];
-    const uint32_t l = blockIdx.x;
-    if (l >= n_labels) return;
-    const osmt_labelinfo* __restrict__ li = g_lab + l;
-    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0 || li->cols > LC_CELLS) return;
-    const uint32_t lane = threadIdx.x;
-    const int32_t ry0 = li->ry0, cx0 = li->cx0;
-    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
-    const uint32_t n_segs = li->n_segs;
-    const double4* __restrict__ segs = g_seg + li->seg_off;
-    double* __restrict__ A = g_a + li->plane_off;
-    const uint32_t band_rows = min(64u, LC_CELLS / cols);
-    bool oob = false;
-    for (uint32_t rbase = 0; rbase < R; rbase += band_rows) {
-        const uint32_t nrow = min(band_rows, R - rbase);
-        const uint32_t cnt = nrow * cols;
-        for (uint32_t i = lane; i < cnt; i += 64u) {
-            sh_a[i] = 0.0;
-            sh_s[i] = 0.0;
-        }
-        __syncthreads();
-        const bool active = lane < nrow;
-        const int32_t y = ry0 + (int32_t)(rbase + lane);
-        double* a_row = sh_a + (active ? lane * cols : 0u);
-        double* s_row = sh_s + (active ? lane * cols : 0u);
-        /* the stripe owner keeps the cell it is adding to in a register (consecutive calls of a curve land in
-         * the same cell): LDS is touched only when the cell changes */
-        uint32_t a_col = LC_NOCOL, s_col = LC_NOCOL;
-        double a_val = 0.0, s_val = 0.0;
-        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys (x - cx0) */
-        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
-        for (uint32_t base = 0; base < n_segs; base += 64u) {
-            /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
-            const uint32_t i = base + lane;
-            bool overlaps = false, slow = false;
-            osmt_label_seg sg;
-            uint32_t chmask = 0u;
-            uint32_t ekey[LC_CH]; /* kind << 31 | local stripe << 20 | column */
-            double eval[LC_CH];
-#pragma unroll
-            for (int k = 0; k < LC_CH; ++k) {
-                ekey[k] = 0xFFFFFFFFu;
-                eval[k] = 0.0;
-            }
-            if (i < n_segs) {
-                sg = label_seg_prep(segs[i]);
-                overlaps = sg.yl >= band0 && sg.yf <= band1; /* also drops delta == 0 (yf > yl) */
-                if (overlaps) {
-                    const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
-                    auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
-                        const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
-                        if ((chmask >> ch) & 1u) slow = true;
-                        chmask |= 1u << ch;
-                        const uint32_t key = (kind << 31) | (row << 20) | col;
-#pragma unroll
-                        for (int k = 0; k < LC_CH; ++k)
-                            if ((uint32_t)k == ch) {
-                                ekey[k] = key;
-                                eval[k] = val;
-                            }
-                    };
-                    for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
-                        /* font/rasterizer.rs:46-80 for stripe yy */
-                        const double y_bottom = fmax((double)yy, sg.y_min);
-                        const double y_top = fmin((double)(yy + 1), sg.y_max);
-                        const double y_delta = y_top - y_bottom;
-                        const double x_at_bottom = sg.x0 + (y_bottom - sg.y0) * sg.slope;
-                        const double x_at_top = sg.x0 + (y_top - sg.y0) * sg.slope;
-                        const bool flip_edge = !(x_at_bottom <= x_at_top);
-                        const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
-                        const double x_largest = flip_edge ? x_at_bottom : x_at_top;
-                        const int32_t x_to = (int32_t)floor(x_largest);
-                        const int32_t x_from = (int32_t)floor(x_smallest);
-                        if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
-                            oob = true;
-                            continue;
-                        }
-                        if (x_to - x_from >= 2) { /* three cells in one stripe share a channel: replay */
-                            slow = true;
-                            break;
-                        }
-                        const uint32_t row = (uint32_t)(yy - band0);
-                        for (int32_t x = x_from; x <= x_to; ++x) {
-                            const double x_left = fmax((double)x, x_smallest);
-                            const double x_next = (double)(x + 1);
-                            const double x_right = fmin(x_next, x_largest);
-                            double pixel_area = (x_next - x_right) * y_delta;
-                            const double trapezoid_width = x_right - x_left;
-                            if (trapezoid_width > 0.0) {
-                                const double y_at_left = sg.y0 + (x_left - sg.x0) * sg.slope_recip;
-                                const double y_at_right = sg.y0 + (x_right - sg.x0) * sg.slope_recip;
-                                const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
-                                                                          : (y_at_left - y_bottom) + (y_at_right - y_bottom);
-                                pixel_area += trapezoid_width * trapezoid_height / 2.0;
-                            }
-                            emit(0u, row, (uint32_t)(x - cx0), sg.sign * pixel_area);
-                        }
-                        emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
-                    }
-                }
-            }
-            /* ---- phase 2, lane = stripe: the parked sums are applied strictly in call order ---- */
-            unsigned long long rest = __ballot(overlaps);
-            const unsigned long long slowm = __ballot(overlaps && slow);
-            while (rest) {
-                /* calls before the next replayed one form a segment whose channels can be handled one by one: sums to
-                 * different cells are independent, sums to one cell (one channel, equal keys) stay in call order */
-                const unsigned long long sl_rest = slowm & rest;
-                const uint32_t sl = sl_rest ? (uint32_t)__builtin_ctzll(sl_rest) : 64u;
-                const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
-                const bool in_seg = (seg >> lane) & 1ull;
-#pragma unroll
-                for (int ch = 0; ch < LC_CH; ++ch) {
-                    const bool valid = in_seg && ((chmask >> ch) & 1u);
-                    const unsigned long long vm = __ballot(valid);
-                    if (!vm) continue;
-                    const uint32_t key = ekey[ch];
-                    const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1);
-                    const bool pvalid = lane != 0u && ((vm >> (lane - 1u)) & 1ull);
-                    const bool head = valid && !(pvalid && pkey == key);
-                    unsigned long long hm = __ballot(head);
-                    const unsigned long long cont = vm & ~hm; /* lanes continuing their predecessor's run */
-                    while (hm) {
-                        const uint32_t h = (uint32_t)__builtin_ctzll(hm);
-                        hm &= hm - 1ull;
-                        const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((cont >> 1) >> h));
-                        const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)h);
-                        const uint32_t col = K & 0xFFFFFu;
-                        if (((K >> 20) & 0x7FFu) == lane) { /* the stripe's owner; v_readlane below ignores EXEC */
-                            uint32_t src = h, left = run;
-                            if (K >> 31) {
-                                if (col != s_col) {
-                                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-                                    s_val = s_row[col];
-                                    s_col = col;
-                                }
-                                do {
-                                    s_val += readlane_f64(eval[ch], src);
-                                    ++src;
-                                } while (--left);
-                            } else {
-                                if (col != a_col) {
-                                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-                                    a_val = a_row[col];
-                                    a_col = col;
-                                }
-                                do {
-                                    a_val += readlane_f64(eval[ch], src);
-                                    ++src;
-                                } while (--left);
-                            }
-                            c_min = min(c_min, col);
-                            c_max = max(c_max, col);
-                        }
-                    }
-                }
-                if (sl >= 64u) break;
-                { /* the replayed call works on LDS directly: write the cached cells back first */
-                    const uint32_t j = sl;
-                    osmt_label_seg q;
-                    q.x0 = readlane_f64(sg.x0, j);
-                    q.y0 = readlane_f64(sg.y0, j);
-                    q.slope = readlane_f64(sg.slope, j);
-                    q.slope_recip = readlane_f64(sg.slope_recip, j);
-                    q.y_min = readlane_f64(sg.y_min, j);
-                    q.y_max = readlane_f64(sg.y_max, j);
-                    q.sign = readlane_f64(sg.sign, j);
-                    q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
-                    q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
-                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-                    a_col = s_col = LC_NOCOL;
-                    if (active && y >= q.yf && y <= q.yl) {
-                        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
-                        oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
-                        if (x_min <= x_max) {
-                            c_min = min(c_min, (uint32_t)(x_min - cx0));
-                            c_max = max(c_max, (uint32_t)(x_max - cx0));
-                        }
-                    }
-                }
-                rest &= ~((2ull << sl) - 1ull);
-            }
-        }
-        if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-        if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-        /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
-        if (active && c_min <= c_max) {
-            double s_acc = 0.0;
-            for (uint32_t c = c_min; c <= c_max; ++c) {
-                s_acc += s_row[c];
-                a_row[c] = fmin(a_row[c] + s_acc, 1.0);
-            }
-        }
-        __syncthreads();
-        double* __restrict__ dst = A + (size_t)rbase * cols;
-        for (uint32_t i = lane; i < cnt; i += 64u) dst[i] = sh_a[i];
-        __syncthreads();
-    }
-    if (oob) atomicOr(g_err, 1u);
-}
-
-/* Windows wider than LC_CELLS columns (a glyph far to the side of labels_bb in a stripe that crosses it):
- * the same walk with the accumulator rows in global memory. */
-__global__ __launch_bounds__(64) void k_label_cover_wide(const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_wide,
-                                                         uint32_t n_wide, const double4* __restrict__ g_seg, double* g_a, double* g_s,
-                                                         uint32_t* g_err) {
-    if (blockIdx.x >= n_wide) return;
-    const osmt_labelinfo* __restrict__ li = g_lab + g_wide[blockIdx.x];
-    const uint32_t lane = threadIdx.x;
-    const int32_t ry0 = li->ry0, cx0 = li->cx0;
-    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
-    const uint32_t n_segs = li->n_segs;
-    const double4* __restrict__ segs = g_seg + li->seg_off;
-    double* A = g_a + li->plane_off;
-    double* S = g_s + li->wide_off;
-    bool oob = false;
-    for (uint32_t rbase = 0; rbase < R; rbase += 64u) {
-        const uint32_t nrow = min(64u, R - rbase);
-        {
-            const size_t cnt = (size_t)nrow * cols;
-            for (size_t i = lane; i < cnt; i += 64u) {
-                A[(size_t)rbase * cols + i] = 0.0;
-                S[i] = 0.0;
-            }
-        }
-        __syncthreads(); /* one wave per block: orders the zeroing before the row owners' read-modify-writes */
-        const bool active = lane < nrow;
-        const int32_t y = ry0 + (int32_t)(rbase + lane);
-        double* a_row = A + (size_t)(rbase + (active ? lane : 0u)) * cols;
-        double* s_row = S + (size_t)(active ? lane : 0u) * cols;
-        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
-        for (uint32_t si = 0; si < n_segs; ++si) {
-            const osmt_label_seg sg = label_seg_prep(segs[si]);
-            if (!active || y < sg.yf || y > sg.yl) continue;
-            oob |= !label_stripe(sg, y, cx0, cols, a_row, s_row, x_min, x_max);
-        }
-        if (active && x_min <= x_max) {
-            double s_acc = 0.0;
-            for (int32_t x = x_min; x <= x_max; ++x) {
-                s_acc += s_row[x - cx0];
-                a_row[x - cx0] = fmin(a_row[x - cx0] + s_acc, 1.0);
-            }
-        }
-        __syncthreads();
-    }
-    if (oob) atomicOr(g_err, 1u);
-}
-
-#define OSMT_LABEL_RESOLVE_THREADS 256
-/* LDS_BM: the (3W)^2-bit ownership map lives in LDS (scale 1: 72 KB); otherwise in global memory. */
-template <bool LDS_BM>
-__global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
-    const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_job_label_off, uint32_t n_jobs, uint32_t scale,
-    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok, osmt_tile_label* __restrict__ g_tl,
-    uint32_t* __restrict__ g_tl_cnt) {
-    extern __shared__ uint32_t sh_bm[];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_jobs) return;
-    const uint32_t tid = threadIdx.x;
-    const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
-    const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
-    const size_t words = ((size_t)EW * EW + 31u) / 32u;
-    uint32_t* bm = LDS_BM ? sh_bm : g_bitmap + (size_t)tile * words;
-    for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
-    if (!LDS_BM) __threadfence();
-    __syncthreads();
-    auto test = [&](uint32_t bit) -> bool {
-        if (LDS_BM) return (bm[bit >> 5] >> (bit & 31u)) & 1u;
-        return (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
-    };
-    const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
-    uint32_t n_out = 0; /* thread 0: succeeded labels that reach into the tile itself */
-    for (uint32_t l = l0; l < l1; ++l) {
-        const osmt_labelinfo* __restrict__ li = g_lab + l;
-        const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
-        const uint32_t iw = li->icon_w, ih = li->icon_h;
-        const bool has_cells = li->has_text && li->ry0 <= li->ry1 && li->cols > 0;
-        const int32_t ry0 = li->ry0, cx0 = li->cx0;
-        const uint32_t cols = li->cols;
-        const uint32_t n_cells = has_cells ? (uint32_t)(li->ry1 - ry0 + 1) * cols : 0u;
-        const double* __restrict__ A = g_a + li->plane_off;
-        bool failed = false;
-        for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
-            bool hit = false;
-            for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
-                const int32_t x = ix0 + (int32_t)(i % iw), y = iy0 + (int32_t)(i / iw);
-                if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
-                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
-                if (pass == 0)
-                    hit |= test(bit);
-                else
-                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
-            }
-            for (uint32_t i = tid; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) {
-                if (!(A[i] > 0.0)) continue;
-                const int32_t x = cx0 + (int32_t)(i % cols), y = ry0 + (int32_t)(i / cols);
-                if (x < -W || x >= 2 * W) continue; /* rows are clipped already */
-                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
-                if (pass == 0)
-                    hit |= test(bit);
-                else
-                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
-            }
-            if (pass == 0) {
-                failed = __syncthreads_or(hit ? 1 : 0) != 0;
-                if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
-                if (failed) break;
-            } else {
-                if (!LDS_BM) __threadfence();
-                __syncthreads();
-            }
-        }
-        if (!failed && tid == 0) {
-            /* what k_raster has to look at: the label's pixels clipped to the tile [0, W)^2 */
-            int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
-            if (has_cells) {
-                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = li->ry1;
-            }
-            if (iw) {
-                bx0 = min(bx0, ix0), bx1 = max(bx1, ix0 + (int32_t)iw - 1);
-                by0 = min(by0, iy0), by1 = max(by1, iy0 + (int32_t)ih - 1);
-            }
-            bx0 = max(bx0, 0), by0 = max(by0, 0), bx1 = min(bx1, W - 1), by1 = min(by1, W - 1);
-            if (bx0 <= bx1 && by0 <= by1) {
-                osmt_tile_label e;
-                e.x0 = (int16_t)bx0, e.y0 = (int16_t)by0, e.x1 = (int16_t)bx1, e.y1 = (int16_t)by1;
-                e.label = l;
-                e._pad = 0;
-                g_tl[l0 + n_out++] = e;
-            }
-        }
-    }
-    if (tid == 0) g_tl_cnt[tile] = n_out;
-}
-
-/* ------------------------------------------------------------------------- */
-/* PNG encoding on the GPU (rgb_triples_to_png, png_writer.rs:4-21): one wave per tile
- * turns an RGBA8 framebuffer into a complete RGB8 PNG file — Paeth-filtered rows, ONE fixed-Huffman deflate
- * block whose only matches are distance-1 runs, Adler-32, chunk CRCs — so that a serving pipeline moves
- * ~50 KB per tile over PCIe instead of 256 KB and the host does no zlib work.  The reference's tests compare
- * decoded pixels only (tests/test_rendering.rs:15-23), so the encoder is free to differ from the png crate.
- *
- * Per row (3W+1 filtered bytes in LDS, one wave): lanes own contiguous byte spans; a byte starts a run when it differs
- * from its predecessor; a run (v, L) becomes literal(v), matches(len <= 258, dist 1) for the other L-1 bytes,
- * and at most two trailing literals.  Bit counts are prefix-summed across lanes and tokens are OR-ed into an LDS
- * bit buffer; rows are sized first so that every row knows its bit position in the file (see k_png_encode). */
-#define PNG_HDR_BYTES 43u /* 8 signature + 25 IHDR + 4 IDAT length + 4 "IDAT" + 2 zlib header */
-
-__device__ __forceinline__ void png_lit(uint32_t v, uint32_t& bits, uint32_t& n) {
-    if (v < 144u) {
-        bits = __brev(0x30u + v) >> 24;
-        n = 8u;
-    } else {
-        bits = __brev(0x190u + (v - 144u)) >> 23;
-        n = 9u;
-    }
-}
-/* match of length L (3..258) at distance 1: length code + extra bits + the 5-bit distance code 0 */
-__device__ __forceinline__ void png_run(uint32_t L, uint32_t& bits, uint32_t& n) {
-    uint32_t idx, eb = 0u, ev = 0u;
-    if (L == 258u) {
-        idx = 28u;
-    } else if (L <= 10u) {
-        idx = L - 3u;
-    } else {
-        const uint32_t l = L - 3u;
-        eb = (31u - (uint32_t)__clz((int)l)) - 2u;
-        idx = 4u + 4u * eb + ((l >> eb) & 3u);
-        ev = l & ((1u << eb) - 1u);
-    }
-    uint32_t hb, hn;
-    if (idx <= 22u) { /* codes 257..279: 7 bits */
-        hb = __brev(idx + 1u) >> 25;
-        hn = 7u;
-    } else { /* 280..285: 8 bits */
-        hb = __brev(0xC0u + idx - 23u) >> 24;
-        hn = 8u;
-    }
-    bits = hb | (ev << hn);
-    n = hn + eb + 5u;
-}
-/* bits of the tokens of run (v, L) */
-__device__ __forceinline__ uint32_t png_run_bits(uint32_t v, uint32_t L) {
-    const uint32_t ln = v < 144u ? 8u : 9u;
-    uint32_t total = ln, R = L - 1u;
-    while (R >= 258u) { /* code 285: 8 + 0 + 5 bits; at most 11 rounds per 1024-px row (no integer division) */
-        total += 13u;
-        R -= 258u;
-    }
-    if (R >= 3u) {
-        uint32_t b, n;
-        png_run(R, b, n);
-        total += n;
-    } else {
-        total += R * ln;
-    }
-    return total;
-}
-
-__device__ __forceinline__ void png_put(uint32_t* buf, uint32_t& pos, uint32_t bits, uint32_t n) {
-    const uint32_t w = pos >> 5, sh = pos & 31u;
-    atomicOr(buf + w, bits << sh);
-    if (sh + n > 32u) atomicOr(buf + w + 1u, bits >> (32u - sh));
-    pos += n;
-}
-
-#define PNG_MAX_W 1024u
-#ifndef OSMT_V_PNG_WAVES
-#define OSMT_V_PNG_WAVES 4
-#endif
-#define PNG_WAVES ((uint32_t)OSMT_V_PNG_WAVES)
-
-/* filtered row y (Paeth, type 4) of the tile into f[0 .. 3W]; executed by one wave */
-__device__ __forceinline__ void png_filter_row(const uint8_t* __restrict__ src, uint32_t W, uint32_t y, uint32_t lane, uint8_t* f) {
-    const uint32_t* __restrict__ row = reinterpret_cast<const uint32_t*>(src + (size_t)y * W * 4u);
-    const uint32_t* __restrict__ up = reinterpret_cast<const uint32_t*>(src + (size_t)(y ? y - 1u : 0u) * W * 4u);
-    if (lane == 0) f[0] = 4u;
-    for (uint32_t p = lane; p < W; p += 64u) {
-        const uint32_t cur = row[p];
-        const uint32_t a4 = p ? row[p - 1u] : 0u;
-        const uint32_t b4 = y ? up[p] : 0u;
-        const uint32_t c4 = (p && y) ? up[p - 1u] : 0u;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const int a = (int)((a4 >> (8 * ch)) & 0xFFu), b = (int)((b4 >> (8 * ch)) & 0xFFu), c = (int)((c4 >> (8 * ch)) & 0xFFu);
-            const int pp = a + b - c;
-            const int pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
-            const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-            f[1u + 3u * p + (uint32_t)ch] = (uint8_t)((int)((cur >> (8 * ch)) & 0xFFu) - pred);
-        }
-    }
-}
-
-/* One row of the filtered stream, one wave.  EMIT = false: returns the row's bit count (lane-uniform) and its
- * Adler partial sums; EMIT = true: ORs the tokens into `bits` (zeroed, LDS) starting at bit 0. */
-template <bool EMIT>
-__device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB, uint32_t lane, uint32_t* bits, uint32_t& adler1,
-                                                   uint32_t& adler2) {
-    const uint32_t span = (NB - 1u + 63u) / 64u;
-    const uint32_t s0 = min(NB, 1u + lane * span), s1 = min(NB, s0 + span);
-    uint32_t first_start = 0xFFFFFFFFu;
-    uint32_t a1 = 0u, a2 = 0u;
-    for (uint32_t k = s0; k < s1; ++k) {
-        const uint32_t v = f[k];
-        if (first_start == 0xFFFFFFFFu && (k == 1u || v != f[k - 1u])) first_start = k;
-        if (!EMIT) {
-            a1 += v;
-            a2 += (NB - k) * v;
-        }
-    }
-    const unsigned long long has = __ballot(first_start != 0xFFFFFFFFu);
-    const unsigned long long later = lane < 63u ? (has >> (lane + 1u)) : 0ull;
-    const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
-    const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
-    const uint32_t nxt_pos = later ? nxt_pos_raw : NB; /* where the run that leaves this span ends */
-    uint32_t my_bits = lane == 0 ? 8u : 0u; /* the filter-type byte: literal(4) */
-    for (uint32_t k = s0; k < s1;) {
-        const uint32_t v = f[k];
-        const bool is_start = k == 1u || v != f[k - 1u];
-        uint32_t e = k + 1u;
-        while (e < s1 && f[e] == v) ++e;
-        if (is_start) my_bits += png_run_bits(v, ((e == s1) ? nxt_pos : e) - k);
-        k = e;
-    }
-    uint32_t incl = my_bits;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-        if ((int)lane >= d) incl += t;
-    }
-    const uint32_t row_bits = (uint32_t)__shfl((int)incl, 63);
-    if (!EMIT) {
-        if (lane == 0) {
-            a1 += 4u;
-            a2 += NB * 4u;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            a1 += (uint32_t)__shfl_xor((int)a1, d);
-            a2 += (uint32_t)__shfl_xor((int)a2, d);
-        }
-        adler1 = a1;
-        adler2 = a2;
-        return row_bits;
-    }
-    uint32_t pos = incl - my_bits;
-    if (lane == 0) {
-        uint32_t b, n;
-        png_lit(4u, b, n);
-        png_put(bits, pos, b, n);
-    }
-    for (uint32_t k = s0; k < s1;) {
-        const uint32_t v = f[k];
-        const bool is_start = k == 1u || v != f[k - 1u];
-        uint32_t e = k + 1u;
-        while (e < s1 && f[e] == v) ++e;
-        if (is_start) {
-            const uint32_t end = (e == s1) ? nxt_pos : e;
-            uint32_t lb, ln;
-            png_lit(v, lb, ln);
-            png_put(bits, pos, lb, ln);
-            uint32_t R = end - k - 1u;
-            while (R >= 3u) {
-                const uint32_t m = min(R, 258u);
-                uint32_t b, n;
-                png_run(m, b, n);
-                png_put(bits, pos, b, n);
-                R -= m;
-            }
-            for (; R; --R) png_put(bits, pos, lb, ln);
-        }
-        k = e;
-    }
-    return row_bits;
-}
-
-/* One workgroup (4 waves) per tile.  Pass 1: every wave sizes its rows (bits + Adler sums); a scan gives each
- * row its bit position in the file; pass 2: every wave re-filters its rows, builds the row's bits in LDS and
- * stores them shifted to that position — interior words plainly, the first and last word of a row (shared with
- * its neighbours) with atomicOr into words zeroed between the passes. */
-__global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
-                                                              uint32_t W, uint32_t H, uint32_t ihdr_crc, uint8_t* g_out,
-                                                              size_t out_stride, uint32_t* __restrict__ g_len) {
-    __shared__ uint8_t sh_f[PNG_WAVES][3u * PNG_MAX_W + 4u];
-    __shared__ uint32_t sh_bits[PNG_WAVES][(9u * (3u * PNG_MAX_W + 1u)) / 32u + 4u];
-    __shared__ uint32_t sh_rowpos[PNG_MAX_W + 1u]; /* pass 1: bits of row y; after the scan: its absolute bit position */
-    __shared__ uint32_t sh_a1[PNG_MAX_W], sh_a2[PNG_MAX_W];
-    __shared__ uint32_t sh_crc_tab[256];
-    __shared__ uint32_t sh_col[32];
-    __shared__ uint32_t sh_raw[64 * PNG_WAVES];
-    __shared__ uint32_t sh_adler;
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint8_t* __restrict__ src = g_rgba + (size_t)tile * tile_stride;
-    uint8_t* out = g_out + (size_t)tile * out_stride;
-    uint32_t* out_w = reinterpret_cast<uint32_t*>(out);
-    const uint32_t NB = 3u * W + 1u; /* bytes of one filtered row incl. the filter-type byte */
-
-    for (uint32_t i = tid; i < 256u; i += 64u * PNG_WAVES) { /* CRC-32 (reflected 0xEDB88320) byte table */
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        sh_crc_tab[i] = c;
-    }
-    /* ---- pass 1: size every row ---- */
-    for (uint32_t y = wave; y < H; y += PNG_WAVES) {
-        png_filter_row(src, W, y, lane, sh_f[wave]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t a1, a2;
-        const uint32_t rb = png_row_tokens<false>(sh_f[wave], NB, lane, nullptr, a1, a2);
-        if (lane == 0) {
-            sh_rowpos[y] = rb;
-            sh_a1[y] = a1;
-            sh_a2[y] = a2;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    /* ---- row positions (bit 0 of the deflate stream = byte 43, after the 3 block-header bits) + Adler-32 ---- */
-    if (tid == 0) {
-        uint32_t pos = PNG_HDR_BYTES * 8u + 3u;
-        uint32_t A = 1u, B = 0u;
-        for (uint32_t y = 0; y < H; ++y) {
-            const uint32_t rb = sh_rowpos[y];
-            sh_rowpos[y] = pos;
-            pos += rb;
-            B = (uint32_t)(((unsigned long long)B + (unsigned long long)NB * A + sh_a2[y]) % 65521ull);
-            A = (A + sh_a1[y]) % 65521u;
-        }
-        sh_rowpos[H] = pos; /* end-of-block code goes here */
-        sh_adler = (B << 16) | A;
-        /* signature, IHDR, IDAT length placeholder, "IDAT", zlib header (0x78 0x01), block header bits 1,1,0 */
-        out_w[0] = 0x474E5089u;
-        out_w[1] = 0x0A1A0A0Du;
-        out_w[2] = 0x0D000000u;
-        out_w[3] = 0x52444849u;
-        out_w[4] = __builtin_bswap32(W);
-        out_w[5] = __builtin_bswap32(H);
-        out_w[6] = 0x00000208u;
-        out_w[7] = (ihdr_crc >> 24 << 8) | (((ihdr_crc >> 16) & 0xFFu) << 16) | (((ihdr_crc >> 8) & 0xFFu) << 24);
-        out_w[8] = (ihdr_crc & 0xFFu);
-        out_w[9] = 0x41444900u;
-    }
-    __syncthreads();
-    /* words shared by two rows (and the word the stream ends in) start from zero; word 10 carries 'T', the zlib
-     * header and the block header */
-    for (uint32_t y = tid; y <= H; y += 64u * PNG_WAVES) {
-        const uint32_t w = sh_rowpos[y] >> 5;
-        if (w != 10u) out_w[w] = 0u;
-        if (y == H) out_w[w + 1u] = 0u; /* the 7 EOB bits may spill into the next word */
-    }
-    if (tid == 0) out_w[10] = 0x00017854u | (3u << 24);
-    __threadfence_block();
-    __syncthreads();
-    /* ---- pass 2: emit ---- */
-    const uint32_t nwords_row = (9u * NB) / 32u + 2u;
-    for (uint32_t y = wave; y < H; y += PNG_WAVES) {
-        png_filter_row(src, W, y, lane, sh_f[wave]);
-        for (uint32_t i = lane; i < nwords_row; i += 64u) sh_bits[wave][i] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t a1, a2;
-        const uint32_t row_bits = png_row_tokens<true>(sh_f[wave], NB, lane, sh_bits[wave], a1, a2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t gbit = sh_rowpos[y];
-        const uint32_t sh = gbit & 31u, wb = gbit >> 5;
-        const uint32_t n_out = ((gbit + row_bits - 1u) >> 5) - wb + 1u; /* words holding bits of this row */
-        for (uint32_t k = lane; k < n_out; k += 64u) {
-            uint32_t w = sh ? (sh_bits[wave][k] << sh) : sh_bits[wave][k];
-            if (k && sh) w |= sh_bits[wave][k - 1u] >> (32u - sh);
-            /* the row's first word, and its last one unless the row ends exactly on a word boundary, are shared
-             * with the neighbouring rows (pre-zeroed above); everything else is this row's alone */
-            const bool shared = k == 0u || (k + 1u == n_out && ((gbit + row_bits) & 31u) != 0u);
-            if (shared)
-                atomicOr(out_w + wb + k, w);
-            else
-                out_w[wb + k] = w;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __threadfence_block();
-    __syncthreads();
-    /* end of block (7 zero bits: already there), pad to a byte, Adler-32, IDAT length */
-    const uint32_t gend = sh_rowpos[H] + 7u;
-    const uint32_t endb = (gend + 7u) >> 3; /* first byte after the deflate stream */
-    if (tid == 0) {
-        const uint32_t adler = sh_adler;
-        out[endb + 0u] = (uint8_t)(adler >> 24);
-        out[endb + 1u] = (uint8_t)(adler >> 16);
-        out[endb + 2u] = (uint8_t)(adler >> 8);
-        out[endb + 3u] = (uint8_t)adler;
-        const uint32_t idat_len = 2u + (endb - PNG_HDR_BYTES) + 4u;
-        out[33] = (uint8_t)(idat_len >> 24);
-        out[34] = (uint8_t)(idat_len >> 16);
-        out[35] = (uint8_t)(idat_len >> 8);
-        out[36] = (uint8_t)idat_len;
-    }
-    __threadfence_block();
-    __syncthreads();
-    /* CRC-32 of "IDAT" + data = bytes [37, endb + 4): per-thread raw CRCs of equal blocks, then combined */
-    const uint32_t NT = 64u * PNG_WAVES;
-    const uint32_t c0 = 37u, c1 = endb + 4u;
-    const uint32_t blk = (c1 - c0 + NT - 1u) / NT;
-    {
-        const uint32_t b0 = min(c1, c0 + tid * blk), b1 = min(c1, b0 + blk);
-        uint32_t s = 0u;
-        for (uint32_t k = b0; k < b1; ++k) s = sh_crc_tab[(s ^ out[k]) & 0xFFu] ^ (s >> 8);
-        sh_raw[tid] = s;
-        if (tid < 32u) { /* column `tid` of the operator "advance the CRC register over blk zero bytes" */
-            uint32_t c = 1u << tid;
-            for (uint32_t k = 0; k < blk; ++k) c = sh_crc_tab[c & 0xFFu] ^ (c >> 8);
-            sh_col[tid] = c;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t s = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < NT; ++i) {
-            const uint32_t b0 = min(c1, c0 + i * blk), b1 = min(c1, b0 + blk);
-            const uint32_t len = b1 - b0;
-            if (!len) break;
-            if (len == blk) {
-                uint32_t t = 0u;
-                for (uint32_t b = 0; b < 32u; ++b)
-                    if ((s >> b) & 1u) t ^= sh_col[b];
-                s = t;
-            } else {
-                for (uint32_t k = 0; k < len; ++k) s = sh_crc_tab[s & 0xFFu] ^ (s >> 8);
-            }
-            s ^= sh_raw[i];
-        }
-        const uint32_t crc = ~s;
-        uint32_t o = c1;
-        out[o++] = (uint8_t)(crc >> 24);
-        out[o++] = (uint8_t)(crc >> 16);
-        out[o++] = (uint8_t)(crc >> 8);
-        out[o++] = (uint8_t)crc;
-        const uint8_t iend[12] = {0, 0, 0, 0, 0x49, 0x45, 0x4E, 0x44, 0xAE, 0x42, 0x60, 0x82};
-        for (int k = 0; k < 12; ++k) out[o++] = iend[k];
-        g_len[tile] = o;
-    }
-}
-
-/* Fast path of k_png_encode for W = 64 * PX (PX = 4: 256-px tiles, PX = 8: 512): ONE tokenisation pass.
- * Wave w owns the band of rows [w*H/4, (w+1)*H/4) and walks it top to bottom; a lane owns PX consecutive pixels,
- * whose raw values, the row above (carried in registers from the previous iteration) and the 3*PX filtered bytes
- * all live in registers — run starts, run ends inside the lane and token sizes are straight-line code, the next
- * row's pixels are fetched while the current one is tokenised.  Band 0 appends its rows directly behind the
- * file header; bands 1..3 append into staging areas further up the tile's slot (bit 0 of a word), and once the
- * band lengths are known they are moved down, bit-shifted, behind their predecessors (dst <= src, chunked
- * read-then-write).  Adler-32 per band, combined like zlib's adler32_combine. */
-template <int PX>
-__global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
-                                                         uint32_t H, uint32_t ihdr_crc, uint8_t* g_out, size_t out_stride,
-                                                         uint32_t band_cap_words, uint32_t* __restrict__ g_len) {
-    constexpr uint32_t W = 64u * PX, NB = 3u * W + 1u, NBY = 3u * PX; /* bytes per lane */
-    constexpr uint32_t ROWW = (9u * NB) / 32u + 3u;
-    __shared__ uint32_t sh_bits[4][ROWW];
-    __shared__ uint32_t sh_crc_tab[256];
-    __shared__ uint32_t sh_col[32];
-    __shared__ uint32_t sh_raw[256];
-    __shared__ uint32_t sh_carry[4];
-    __shared__ uint32_t sh_band_bits[4], sh_band_a[4], sh_band_b[4];
-    __shared__ uint32_t sh_move[256 + 1];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint8_t* __restrict__ src = g_rgba + (size_t)tile * tile_stride;
-    uint8_t* out = g_out + (size_t)tile * out_stride;
-    uint32_t* out_w = reinterpret_cast<uint32_t*>(out);
-    for (uint32_t i = tid; i < 256u; i += 256u) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        sh_crc_tab[i] = c;
-    }
-    const uint32_t rows = H / 4u, y_begin = wave * rows, y_end = y_begin + rows;
-    /* where this band's bits go while it is being produced */
-    const uint32_t stage_w = wave == 0u ? 0u : 11u + wave * band_cap_words; /* band 0: the file itself */
-    uint32_t gbit = wave == 0u ? PNG_HDR_BYTES * 8u + 3u : 0u;               /* bit cursor relative to out_w[stage_w] */
-    uint32_t carry = wave == 0u ? (0x00017854u | (3u << 24)) : 0u;           /* band 0 continues word 10 */
-    if (tid == 0) {
-        out_w[0] = 0x474E5089u;
-        out_w[1] = 0x0A1A0A0Du;
-        out_w[2] = 0x0D000000u;
-        out_w[3] = 0x52444849u;
-        out_w[4] = __builtin_bswap32(W);
-        out_w[5] = __builtin_bswap32(H);
-        out_w[6] = 0x00000208u;
-        out_w[7] = (ihdr_crc >> 24 << 8) | (((ihdr_crc >> 16) & 0xFFu) << 16) | (((ihdr_crc >> 8) & 0xFFu) << 24);
-        out_w[8] = (ihdr_crc & 0xFFu);
-        out_w[9] = 0x41444900u;
-    }
-    uint32_t adler_a = 1u, adler_b = 0u;
-    uint32_t cur[PX], prev[PX], nxt[PX];
-    {
-        const uint4* __restrict__ r = reinterpret_cast<const uint4*>(src + (size_t)y_begin * W * 4u) + lane * (PX / 4);
-#pragma unroll
-        for (int q = 0; q < PX / 4; ++q) {
-            const uint4 v = r[q];
-            cur[4 * q] = v.x, cur[4 * q + 1] = v.y, cur[4 * q + 2] = v.z, cur[4 * q + 3] = v.w;
-        }
-        if (y_begin) {
-            const uint4* __restrict__ u = reinterpret_cast<const uint4*>(src + (size_t)(y_begin - 1u) * W * 4u) + lane * (PX / 4);
-#pragma unroll
-            for (int q = 0; q < PX / 4; ++q) {
-                const uint4 v = u[q];
-                prev[4 * q] = v.x, prev[4 * q + 1] = v.y, prev[4 * q + 2] = v.z, prev[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < PX; ++j) prev[j] = 0u;
-        }
-    }
-    const uint32_t base = 1u + lane * NBY; /* stream index of this lane's first filtered byte */
-    for (uint32_t y = y_begin; y < y_end; ++y) {
-        if (y + 1u < y_end) { /* fetch the next row now */
-            const uint4* __restrict__ r = reinterpret_cast<const uint4*>(src + (size_t)(y + 1u) * W * 4u) + lane * (PX / 4);
-#pragma unroll
-            for (int q = 0; q < PX / 4; ++q) {
-                const uint4 v = r[q];
-                nxt[4 * q] = v.x, nxt[4 * q + 1] = v.y, nxt[4 * q + 2] = v.z, nxt[4 * q + 3] = v.w;
-            }
-        }
-        /* ---- Paeth filter, bytes in registers ---- */
-        uint32_t fb[NBY];
-        {
-            uint32_t la = (uint32_t)__shfl_up((int)cur[PX - 1], 1), lc = (uint32_t)__shfl_up((int)prev[PX - 1], 1);
-            if (lane == 0) la = lc = 0u;
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const uint32_t a4 = j ? cur[j - 1] : la, c4 = j ? prev[j - 1] : lc, b4 = prev[j], x4 = cur[j];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const int a = (int)((a4 >> (8 * ch)) & 0xFFu), b = (int)((b4 >> (8 * ch)) & 0xFFu), c = (int)((c4 >> (8 * ch)) & 0xFFu);
-                    const int pp = a + b - c;
-                    const int pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
-                    const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    fb[3 * j + ch] = (uint32_t)((int)((x4 >> (8 * ch)) & 0xFFu) - pred) & 0xFFu;
-                }
-            }
-        }
-        /* ---- run starts and, for each byte, the next start inside the lane ---- */
-        const uint32_t pbyte = (uint32_t)__shfl_up((int)fb[NBY - 1], 1);
-        uint32_t startmask = 0u;
-#pragma unroll
-        for (int i = 0; i < (int)NBY; ++i) {
-            const bool st = i ? (fb[i] != fb[i - 1]) : (lane == 0u || fb[0] != pbyte);
-            startmask |= (st ? 1u : 0u) << i;
-        }
-        const uint32_t first_start = startmask ? base + (uint32_t)__builtin_ctz(startmask) : 0xFFFFFFFFu;
-        const unsigned long long has = __ballot(startmask != 0u);
-        const unsigned long long later = lane < 63u ? (has >> (lane + 1u)) : 0ull;
-        const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
-        const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
-        const uint32_t nxt_pos = later ? nxt_pos_raw : NB;
-        /* ---- size, prefix, emit ---- */
-        uint32_t my_bits = lane == 0u ? 8u : 0u, a1 = lane == 0u ? 4u : 0u, a2 = lane == 0u ? NB * 4u : 0u;
-#pragma unroll
-        for (int i = 0; i < (int)NBY; ++i) {
-            a1 += fb[i];
-            a2 += (NB - (base + (uint32_t)i)) * fb[i];
-            if ((startmask >> i) & 1u) {
-                const uint32_t rest = startmask >> (i + 1); /* i + 1 < 32 always: NBY <= 24 */
-                const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
-                my_bits += png_run_bits(fb[i], end - (base + (uint32_t)i));
-            }
-        }
-        uint32_t incl = my_bits;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-            if ((int)lane >= d) incl += t;
-        }
-        const uint32_t row_bits = (uint32_t)__shfl((int)incl, 63);
-        uint32_t* bits = sh_bits[wave];
-        for (uint32_t i = lane; i < ROWW; i += 64u) bits[i] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t pos = incl - my_bits;
-        if (lane == 0u) {
-            uint32_t b, n;
-            png_lit(4u, b, n);
-            png_put(bits, pos, b, n);
-        }
-#pragma unroll
-        for (int i = 0; i < (int)NBY; ++i) {
-            if ((startmask >> i) & 1u) {
-                const uint32_t rest = startmask >> (i + 1);
-                const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
-                uint32_t lb, ln;
-                png_lit(fb[i], lb, ln);
-                png_put(bits, pos, lb, ln);
-                uint32_t R = end - (base + (uint32_t)i) - 1u;
-                while (R >= 3u) {
-                    const uint32_t m = min(R, 258u);
-                    uint32_t b, n;
-                    png_run(m, b, n);
-                    png_put(bits, pos, b, n);
-                    R -= m;
-                }
-                for (; R; --R) png_put(bits, pos, lb, ln);
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            a1 += (uint32_t)__shfl_xor((int)a1, d);
-            a2 += (uint32_t)__shfl_xor((int)a2, d);
-        }
-        adler_b = (uint32_t)(((unsigned long long)adler_b + (unsigned long long)NB * adler_a + a2) % 65521ull);
-        adler_a = (adler_a + a1) % 65521u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        /* ---- append the row at the band's bit cursor ---- */
-        {
-            const uint32_t sh = gbit & 31u, wb = gbit >> 5;
-            const uint32_t gend = gbit + row_bits;
-            const uint32_t n_out = (gend >> 5) - wb + 1u; /* words touched; the last one is the new carry */
-            for (uint32_t k = lane; k < n_out; k += 64u) {
-                uint32_t w = sh ? (bits[k] << sh) : bits[k];
-                if (k)
-                    w |= sh ? (bits[k - 1u] >> (32u - sh)) : 0u;
-                else
-                    w |= carry;
-                if (k + 1u < n_out)
-                    out_w[stage_w + wb + k] = w;
-                else
-                    sh_carry[wave] = w;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            gbit = gend;
-            carry = (gbit & 31u) ? sh_carry[wave] : 0u;
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            prev[j] = cur[j];
-            cur[j] = nxt[j];
-        }
-    }
-    /* flush the band's partial word (upper bits zero) and publish its length and checksum */
-    if (lane == 0u) {
-        if (gbit & 31u) out_w[stage_w + (gbit >> 5)] = carry;
-        sh_band_bits[wave] = wave == 0u ? gbit - (PNG_HDR_BYTES * 8u + 3u) : gbit;
-        sh_band_a[wave] = adler_a;
-        sh_band_b[wave] = adler_b;
-    }
-    __threadfence_block();
-    __syncthreads();
-    /* ---- move bands 1..3 down behind their predecessors ---- */
-    uint32_t endpos = PNG_HDR_BYTES * 8u + 3u + sh_band_bits[0];
-    for (uint32_t b = 1; b < 4u; ++b) {
-        const uint32_t L = sh_band_bits[b];
-        const uint32_t sw = 11u + b * band_cap_words; /* staging: bit 0 of out_w[sw] */
-        const uint32_t sh = endpos & 31u, wb = endpos >> 5;
-        const uint32_t n_src = (L + 31u) >> 5;
-        const uint32_t n_dst = ((endpos + L + 31u) >> 5) - wb; /* destination words holding bits of this band */
-        for (uint32_t c = 0; c < n_dst; c += 256u) {
-            const uint32_t k = c + tid;
-            uint32_t w = 0u;
-            if (k < n_dst) {
-                const uint32_t s_cur = k < n_src ? out_w[sw + k] : 0u;
-                const uint32_t s_prev = (k && k - 1u < n_src) ? out_w[sw + k - 1u] : 0u;
-                w = sh ? ((s_cur << sh) | (s_prev >> (32u - sh))) : s_cur;
-                if (k == 0u && sh) w |= out_w[wb]; /* the predecessor's partial last word */
-            }
-            __syncthreads(); /* every source word of this chunk is read before any destination word is written */
-            if (k < n_dst) out_w[wb + k] = w;
-            __threadfence_block();
-            __syncthreads();
-        }
-        endpos += L;
-    }
-    /* end of block: 7 zero bits (the word after the last one may receive some of them) */
-    if (tid == 0) {
-        if (((endpos + 7u) >> 5) != (endpos >> 5) || !(endpos & 31u)) out_w[(endpos + 7u) >> 5] = 0u;
-        /* Adler-32 of the concatenation (zlib's adler32_combine): A = A1 + A2 - 1, B = B1 + B2 + len2 * (A1 - 1) */
-        unsigned long long A = sh_band_a[0], B = sh_band_b[0];
-        const unsigned long long len2 = (unsigned long long)rows * NB;
-        for (uint32_t b = 1; b < 4u; ++b) {
-            const unsigned long long A2 = sh_band_a[b], B2 = sh_band_b[b];
-            B = (B + B2 + (len2 % 65521ull) * ((A + 65520ull) % 65521ull)) % 65521ull;
-            A = (A + A2 + 65520ull) % 65521ull;
-        }
-        sh_move[0] = (uint32_t)((B << 16) | A);
-    }
-    __threadfence_block();
-    __syncthreads();
-    const uint32_t gend = endpos + 7u;
-    const uint32_t endb = (gend + 7u) >> 3;
-    if (tid == 0) {
-        const uint32_t adler = sh_move[0];
-        out[endb + 0u] = (uint8_t)(adler >> 24);
-        out[endb + 1u] = (uint8_t)(adler >> 16);
-        out[endb + 2u] = (uint8_t)(adler >> 8);
-        out[endb + 3u] = (uint8_t)adler;
-        const uint32_t idat_len = 2u + (endb - PNG_HDR_BYTES) + 4u;
-        out[33] = (uint8_t)(idat_len >> 24);
-        out[34] = (uint8_t)(idat_len >> 16);
-        out[35] = (uint8_t)(idat_len >> 8);
-        out[36] = (uint8_t)idat_len;
-    }
-    __threadfence_block();
-    __syncthreads();
-    const uint32_t c0 = 37u, c1 = endb + 4u;
-    const uint32_t blk = (c1 - c0 + 255u) / 256u;
-    {
-        const uint32_t b0 = min(c1, c0 + tid * blk), b1 = min(c1, b0 + blk);
-        uint32_t s = 0u;
-        for (uint32_t k = b0; k < b1; ++k) s = sh_crc_tab[(s ^ out[k]) & 0xFFu] ^ (s >> 8);
-        sh_raw[tid] = s;
-        if (tid < 32u) {
-            uint32_t c = 1u << tid;
-            for (uint32_t k = 0; k < blk; ++k) c = sh_crc_tab[c & 0xFFu] ^ (c >> 8);
-            sh_col[tid] = c;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t s = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < 256u; ++i) {
-            const uint32_t b0 = min(c1, c0 + i * blk), b1 = min(c1, b0 + blk);
-            const uint32_t len = b1 - b0;
-            if (!len) break;
-            if (len == blk) {
-                uint32_t t = 0u;
-                for (uint32_t b = 0; b < 32u; ++b)
-                    if ((s >> b) & 1u) t ^= sh_col[b];
-                s = t;
-            } else {
-                for (uint32_t k = 0; k < len; ++k) s = sh_crc_tab[s & 0xFFu] ^ (s >> 8);
-            }
-            s ^= sh_raw[i];
-        }
-        const uint32_t crc = ~s;
-        uint32_t o = c1;
-        out[o++] = (uint8_t)(crc >> 24);
-        out[o++] = (uint8_t)(crc >> 16);
-        out[o++] = (uint8_t)(crc >> 8);
-        out[o++] = (uint8_t)crc;
-        const uint8_t iend[12] = {0, 0, 0, 0, 0x49, 0x45, 0x4E, 0x44, 0xAE, 0x42, 0x60, 0x82};
-        for (int k = 0; k < 12; ++k) out[o++] = iend[k];
-        g_len[tile] = o;
-    }
-}
-
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
                                uint32_t n_pts, double scale, int32_t* pts, hipStream_t st) {
     if (n_pts == 0) return hipSuccess;
@@ -2362,71 +1279,6 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
         if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true, false); else OSMT_LAUNCH_RASTER(false, false, false);
     }
 #undef OSMT_LAUNCH_RASTER
-    return hipGetLastError();
-}
-
-hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
-    if (a.n_labels == 0 || a.n_jobs == 0) return hipSuccess;
-    const double4* segs = reinterpret_cast<const double4*>(a.segs);
-    hipLaunchKernelGGL(k_label_cover, dim3(a.n_labels), dim3(64), 0, st, a.info, a.n_labels, segs, a.plane_a, a.err);
-    if (a.n_wide)
-        hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
-                           a.plane_s_wide, a.err);
-    const size_t EW = 3u * (size_t)OSMT_TILE_SIZE * a.scale;
-    const size_t bm_bytes = ((EW * EW + 31u) / 32u) * 4u;
-    if (bm_bytes <= 96u * 1024u) {
-        /* per device and cheap: set on every launch rather than caching a process-wide flag */
-        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (ae != hipSuccess) return ae;
-        hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), bm_bytes, st, a.info,
-                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
-    } else {
-        hipLaunchKernelGGL(k_label_resolve<false>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, a.info,
-                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
-    }
-    return hipGetLastError();
-}
-
-/* gathers the variable-length PNG files of a batch into one blob: tile i -> blob[off[i] .. off[i] + len[i]) */
-__global__ __launch_bounds__(256) void k_png_compact(const uint8_t* __restrict__ slots, size_t slot_stride,
-                                                     const uint32_t* __restrict__ len, const unsigned long long* __restrict__ off,
-                                                     uint32_t n, uint8_t* __restrict__ blob) {
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n) return;
-    const uint8_t* __restrict__ src = slots + (size_t)tile * slot_stride;
-    uint8_t* __restrict__ dst = blob + off[tile];
-    const uint32_t L = len[tile];
-    for (uint32_t i = threadIdx.x; i < L; i += 256u) dst[i] = src[i];
-}
-
-hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
-                                   void* blob, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_png_compact, dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(slots), slot_stride, len, off, n,
-                       reinterpret_cast<uint8_t*>(blob));
-    return hipGetLastError();
-}
-
-hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, uint32_t ihdr_crc, void* out,
-                           size_t out_stride, uint32_t* out_len, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    if (W > PNG_MAX_W) return hipErrorInvalidValue;
-    if ((W == 256u || W == 512u) && (H % 4u) == 0u && H >= 4u) {
-        /* staging capacity of one band: H/4 rows of at most 9 bits per filtered byte */
-        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * 9u + 31u) / 32u + 2u);
-        if ((size_t)(11u + 4u * band_cap_words) * 4u + 64u <= out_stride) {
-            if (W == 256u)
-                hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
-                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
-            else
-                hipLaunchKernelGGL((k_png_encode_fast<8>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
-                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL(k_png_encode, dim3(n), dim3(64 * PNG_WAVES), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, W, H, ihdr_crc,
-                       reinterpret_cast<uint8_t*>(out), out_stride, out_len);
     return hipGetLastError();
 }
 

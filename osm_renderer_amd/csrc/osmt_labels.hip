@@ -1,0 +1,465 @@
+/*
+ * osmt_labels.hip — the label pass on the GPU: glyph coverage (font/rasterizer.rs), icon blits
+ * (labeler.rs:91-106) and label collisions (tile_pixels.rs:131-162).  The survivors are blended by k_raster<LABELS>
+ * (osmt_kernels.hip).  gfx950 only; -ffp-contract=off (the reference never fuses a*b+c).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "osmt_internal.h"
+
+/* ------------------------------------------------------------------------- */
+/* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
+ *
+ * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; the wave digests the
+ *                  draw_line calls 64 at a time (one call per lane: the y-independent part of draw_line,
+ *                  two f64 divisions) into LDS, then every lane walks the calls that cross the band IN
+ *                  CALL ORDER and adds those that cross its stripe into its own row of the LDS-resident
+ *                  A / S accumulators — the per-key f64 sums therefore happen in exactly the reference's
+ *                  order (BTreeMap entry += ..., :77,:80) with no atomics.  Then the lane runs
+ *                  save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and the band is
+ *                  copied out coalesced: total = min(a + s_acc, 1.0) per cell, 0 where the stripe has no key.
+ * k_label_resolve  one workgroup per tile, labels strictly in draw order: a label succeeds iff none of
+ *                  the pixels it would set (icon rectangle, then cells with total > 0) inside labels_bb
+ *                  belongs to an earlier SUCCEEDED label (set_label_pixel, tile_pixels.rs:131-148;
+ *                  pixels of failed labels are overwritten freely); succeeded labels mark their pixels
+ *                  in a (3W)^2-bit ownership map.  The early `return false` of draw_icon /
+ *                  save_to_figure only skips pixels of a label that is not blended anyway.
+ * k_raster<LABELS> blends the succeeded labels over the area canvas before to_rgb_triples. */
+/* draw_line for stripe y (font/rasterizer.rs:46-80) into the stripe's own accumulator rows */
+__device__ __forceinline__ bool label_stripe(const osmt_label_seg& sg, int32_t y, int32_t cx0, uint32_t cols, double* a_row,
+                                             double* s_row, int32_t& x_min, int32_t& x_max) {
+    const double x0 = sg.x0, y0 = sg.y0, slope = sg.slope, recip = sg.slope_recip, sign = sg.sign;
+    const double y_bottom = fmax((double)y, sg.y_min);
+    const double y_top = fmin((double)(y + 1), sg.y_max);
+    const double y_delta = y_top - y_bottom;
+    const double x_at_bottom = x0 + (y_bottom - y0) * slope;
+    const double x_at_top = x0 + (y_top - y0) * slope;
+    const bool flip_edge = !(x_at_bottom <= x_at_top);
+    const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+    const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+    const int32_t x_to = (int32_t)floor(x_largest);
+    const int32_t x_from = (int32_t)floor(x_smallest);
+    if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) return false; /* cannot happen: the window is conservative */
+    for (int32_t x = x_from; x <= x_to; ++x) {
+        const double x_left = fmax((double)x, x_smallest);
+        const double x_next = (double)(x + 1);
+        const double x_right = fmin(x_next, x_largest);
+        double pixel_area = (x_next - x_right) * y_delta;
+        const double trapezoid_width = x_right - x_left;
+        if (trapezoid_width > 0.0) {
+            const double y_at_left = y0 + (x_left - x0) * recip;
+            const double y_at_right = y0 + (x_right - x0) * recip;
+            const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                      : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+            pixel_area += trapezoid_width * trapezoid_height / 2.0;
+        }
+        a_row[x - cx0] += sign * pixel_area;
+    }
+    s_row[x_to + 1 - cx0] += sign * y_delta;
+    x_min = min(x_min, x_from);
+    x_max = max(x_max, x_to + 1);
+    return true;
+}
+
+/* the y-independent part of draw_line (font/rasterizer.rs:27-41) */
+__device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
+    const double x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w;
+    osmt_label_seg r;
+    const double delta = y1 - y0;
+    r.x0 = x0;
+    r.y0 = y0;
+    r.sign = (y0 <= y1) ? 1.0 : -1.0;
+    r.slope = (x1 - x0) / delta;
+    r.slope_recip = 1.0 / r.slope;
+    r.y_min = fmin(y0, y1);
+    r.y_max = fmax(y0, y1);
+    if (delta == 0.0) {
+        r.yf = 1;
+        r.yl = 0;
+    } else {
+        r.yf = (int32_t)floor(r.y_min);
+        r.yl = (int32_t)floor(r.y_max);
+    }
+    return r;
+}
+
+#define LC_CELLS OSMT_LABEL_LDS_CELLS
+
+/* A draw_line call parks its sums in its lane's registers, one per CHANNEL = (column parity, A/S kind, stripe
+ * parity): the cells one short call touches always fall into different channels, and a given cell always falls
+ * into the same one, so "consecutive calls adding to the same cell" is simply "consecutive lanes with the same
+ * key in that channel".  Calls whose cells collide in a channel (three cells wide, ...) are replayed stripe by
+ * stripe by the row owners instead. */
+#define LC_CH 8
+#define LC_NOCOL 0xFFFFFFFFu
+
+__device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)j);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab, uint32_t n_labels,
+                                                    const double4* __restrict__ g_seg, double* __restrict__ g_a,
+                                                    uint32_t* g_err) {
+    __shared__ double sh_a[LC_CELLS];
+    __shared__ double sh_s[LC_CELLS];
+    const uint32_t l = blockIdx.x;
+    if (l >= n_labels) return;
+    const osmt_labelinfo* __restrict__ li = g_lab + l;
+    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0 || li->cols > LC_CELLS) return;
+    const uint32_t lane = threadIdx.x;
+    const int32_t ry0 = li->ry0, cx0 = li->cx0;
+    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
+    const uint32_t n_segs = li->n_segs;
+    const double4* __restrict__ segs = g_seg + li->seg_off;
+    double* __restrict__ A = g_a + li->plane_off;
+    const uint32_t band_rows = min(64u, LC_CELLS / cols);
+    bool oob = false;
+    for (uint32_t rbase = 0; rbase < R; rbase += band_rows) {
+        const uint32_t nrow = min(band_rows, R - rbase);
+        const uint32_t cnt = nrow * cols;
+        for (uint32_t i = lane; i < cnt; i += 64u) {
+            sh_a[i] = 0.0;
+            sh_s[i] = 0.0;
+        }
+        __syncthreads();
+        const bool active = lane < nrow;
+        const int32_t y = ry0 + (int32_t)(rbase + lane);
+        double* a_row = sh_a + (active ? lane * cols : 0u);
+        double* s_row = sh_s + (active ? lane * cols : 0u);
+        /* the stripe owner keeps the cell it is adding to in a register (consecutive calls of a curve land in
+         * the same cell): LDS is touched only when the cell changes */
+        uint32_t a_col = LC_NOCOL, s_col = LC_NOCOL;
+        double a_val = 0.0, s_val = 0.0;
+        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys (x - cx0) */
+        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
+        for (uint32_t base = 0; base < n_segs; base += 64u) {
+            /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
+            const uint32_t i = base + lane;
+            bool overlaps = false, slow = false;
+            osmt_label_seg sg;
+            uint32_t chmask = 0u;
+            uint32_t ekey[LC_CH]; /* kind << 31 | local stripe << 20 | column */
+            double eval[LC_CH];
+#pragma unroll
+            for (int k = 0; k < LC_CH; ++k) {
+                ekey[k] = 0xFFFFFFFFu;
+                eval[k] = 0.0;
+            }
+            if (i < n_segs) {
+                sg = label_seg_prep(segs[i]);
+                overlaps = sg.yl >= band0 && sg.yf <= band1; /* also drops delta == 0 (yf > yl) */
+                if (overlaps) {
+                    const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
+                    auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
+                        const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
+                        if ((chmask >> ch) & 1u) slow = true;
+                        chmask |= 1u << ch;
+                        const uint32_t key = (kind << 31) | (row << 20) | col;
+#pragma unroll
+                        for (int k = 0; k < LC_CH; ++k)
+                            if ((uint32_t)k == ch) {
+                                ekey[k] = key;
+                                eval[k] = val;
+                            }
+                    };
+                    for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
+                        /* font/rasterizer.rs:46-80 for stripe yy */
+                        const double y_bottom = fmax((double)yy, sg.y_min);
+                        const double y_top = fmin((double)(yy + 1), sg.y_max);
+                        const double y_delta = y_top - y_bottom;
+                        const double x_at_bottom = sg.x0 + (y_bottom - sg.y0) * sg.slope;
+                        const double x_at_top = sg.x0 + (y_top - sg.y0) * sg.slope;
+                        const bool flip_edge = !(x_at_bottom <= x_at_top);
+                        const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+                        const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+                        const int32_t x_to = (int32_t)floor(x_largest);
+                        const int32_t x_from = (int32_t)floor(x_smallest);
+                        if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
+                            oob = true;
+                            continue;
+                        }
+                        if (x_to - x_from >= 2) { /* three cells in one stripe share a channel: replay */
+                            slow = true;
+                            break;
+                        }
+                        const uint32_t row = (uint32_t)(yy - band0);
+                        for (int32_t x = x_from; x <= x_to; ++x) {
+                            const double x_left = fmax((double)x, x_smallest);
+                            const double x_next = (double)(x + 1);
+                            const double x_right = fmin(x_next, x_largest);
+                            double pixel_area = (x_next - x_right) * y_delta;
+                            const double trapezoid_width = x_right - x_left;
+                            if (trapezoid_width > 0.0) {
+                                const double y_at_left = sg.y0 + (x_left - sg.x0) * sg.slope_recip;
+                                const double y_at_right = sg.y0 + (x_right - sg.x0) * sg.slope_recip;
+                                const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                                          : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+                                pixel_area += trapezoid_width * trapezoid_height / 2.0;
+                            }
+                            emit(0u, row, (uint32_t)(x - cx0), sg.sign * pixel_area);
+                        }
+                        emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
+                    }
+                }
+            }
+            /* ---- phase 2, lane = stripe: the parked sums are applied strictly in call order ---- */
+            unsigned long long rest = __ballot(overlaps);
+            const unsigned long long slowm = __ballot(overlaps && slow);
+            while (rest) {
+                /* calls before the next replayed one form a segment whose channels can be handled one by one: sums to
+                 * different cells are independent, sums to one cell (one channel, equal keys) stay in call order */
+                const unsigned long long sl_rest = slowm & rest;
+                const uint32_t sl = sl_rest ? (uint32_t)__builtin_ctzll(sl_rest) : 64u;
+                const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
+                const bool in_seg = (seg >> lane) & 1ull;
+#pragma unroll
+                for (int ch = 0; ch < LC_CH; ++ch) {
+                    const bool valid = in_seg && ((chmask >> ch) & 1u);
+                    const unsigned long long vm = __ballot(valid);
+                    if (!vm) continue;
+                    const uint32_t key = ekey[ch];
+                    const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1);
+                    const bool pvalid = lane != 0u && ((vm >> (lane - 1u)) & 1ull);
+                    const bool head = valid && !(pvalid && pkey == key);
+                    unsigned long long hm = __ballot(head);
+                    const unsigned long long cont = vm & ~hm; /* lanes continuing their predecessor's run */
+                    while (hm) {
+                        const uint32_t h = (uint32_t)__builtin_ctzll(hm);
+                        hm &= hm - 1ull;
+                        const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((cont >> 1) >> h));
+                        const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)h);
+                        const uint32_t col = K & 0xFFFFFu;
+                        if (((K >> 20) & 0x7FFu) == lane) { /* the stripe's owner; v_readlane below ignores EXEC */
+                            uint32_t src = h, left = run;
+                            if (K >> 31) {
+                                if (col != s_col) {
+                                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+                                    s_val = s_row[col];
+                                    s_col = col;
+                                }
+                                do {
+                                    s_val += readlane_f64(eval[ch], src);
+                                    ++src;
+                                } while (--left);
+                            } else {
+                                if (col != a_col) {
+                                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+                                    a_val = a_row[col];
+                                    a_col = col;
+                                }
+                                do {
+                                    a_val += readlane_f64(eval[ch], src);
+                                    ++src;
+                                } while (--left);
+                            }
+                            c_min = min(c_min, col);
+                            c_max = max(c_max, col);
+                        }
+                    }
+                }
+                if (sl >= 64u) break;
+                { /* the replayed call works on LDS directly: write the cached cells back first */
+                    const uint32_t j = sl;
+                    osmt_label_seg q;
+                    q.x0 = readlane_f64(sg.x0, j);
+                    q.y0 = readlane_f64(sg.y0, j);
+                    q.slope = readlane_f64(sg.slope, j);
+                    q.slope_recip = readlane_f64(sg.slope_recip, j);
+                    q.y_min = readlane_f64(sg.y_min, j);
+                    q.y_max = readlane_f64(sg.y_max, j);
+                    q.sign = readlane_f64(sg.sign, j);
+                    q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
+                    q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
+                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+                    a_col = s_col = LC_NOCOL;
+                    if (active && y >= q.yf && y <= q.yl) {
+                        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
+                        oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
+                        if (x_min <= x_max) {
+                            c_min = min(c_min, (uint32_t)(x_min - cx0));
+                            c_max = max(c_max, (uint32_t)(x_max - cx0));
+                        }
+                    }
+                }
+                rest &= ~((2ull << sl) - 1ull);
+            }
+        }
+        if (a_col != LC_NOCOL) a_row[a_col] = a_val;
+        if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+        /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
+        if (active && c_min <= c_max) {
+            double s_acc = 0.0;
+            for (uint32_t c = c_min; c <= c_max; ++c) {
+                s_acc += s_row[c];
+                a_row[c] = fmin(a_row[c] + s_acc, 1.0);
+            }
+        }
+        __syncthreads();
+        double* __restrict__ dst = A + (size_t)rbase * cols;
+        for (uint32_t i = lane; i < cnt; i += 64u) dst[i] = sh_a[i];
+        __syncthreads();
+    }
+    if (oob) atomicOr(g_err, 1u);
+}
+
+/* Windows wider than LC_CELLS columns (a glyph far to the side of labels_bb in a stripe that crosses it):
+ * the same walk with the accumulator rows in global memory. */
+__global__ __launch_bounds__(64) void k_label_cover_wide(const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_wide,
+                                                         uint32_t n_wide, const double4* __restrict__ g_seg, double* g_a, double* g_s,
+                                                         uint32_t* g_err) {
+    if (blockIdx.x >= n_wide) return;
+    const osmt_labelinfo* __restrict__ li = g_lab + g_wide[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const int32_t ry0 = li->ry0, cx0 = li->cx0;
+    const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
+    const uint32_t n_segs = li->n_segs;
+    const double4* __restrict__ segs = g_seg + li->seg_off;
+    double* A = g_a + li->plane_off;
+    double* S = g_s + li->wide_off;
+    bool oob = false;
+    for (uint32_t rbase = 0; rbase < R; rbase += 64u) {
+        const uint32_t nrow = min(64u, R - rbase);
+        {
+            const size_t cnt = (size_t)nrow * cols;
+            for (size_t i = lane; i < cnt; i += 64u) {
+                A[(size_t)rbase * cols + i] = 0.0;
+                S[i] = 0.0;
+            }
+        }
+        __syncthreads(); /* one wave per block: orders the zeroing before the row owners' read-modify-writes */
+        const bool active = lane < nrow;
+        const int32_t y = ry0 + (int32_t)(rbase + lane);
+        double* a_row = A + (size_t)(rbase + (active ? lane : 0u)) * cols;
+        double* s_row = S + (size_t)(active ? lane : 0u) * cols;
+        int32_t x_min = INT32_MAX, x_max = INT32_MIN;
+        for (uint32_t si = 0; si < n_segs; ++si) {
+            const osmt_label_seg sg = label_seg_prep(segs[si]);
+            if (!active || y < sg.yf || y > sg.yl) continue;
+            oob |= !label_stripe(sg, y, cx0, cols, a_row, s_row, x_min, x_max);
+        }
+        if (active && x_min <= x_max) {
+            double s_acc = 0.0;
+            for (int32_t x = x_min; x <= x_max; ++x) {
+                s_acc += s_row[x - cx0];
+                a_row[x - cx0] = fmin(a_row[x - cx0] + s_acc, 1.0);
+            }
+        }
+        __syncthreads();
+    }
+    if (oob) atomicOr(g_err, 1u);
+}
+
+#define OSMT_LABEL_RESOLVE_THREADS 256
+/* LDS_BM: the (3W)^2-bit ownership map lives in LDS (scale 1: 72 KB); otherwise in global memory. */
+template <bool LDS_BM>
+__global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
+    const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_job_label_off, uint32_t n_jobs, uint32_t scale,
+    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok, osmt_tile_label* __restrict__ g_tl,
+    uint32_t* __restrict__ g_tl_cnt) {
+    extern __shared__ uint32_t sh_bm[];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_jobs) return;
+    const uint32_t tid = threadIdx.x;
+    const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
+    const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
+    const size_t words = ((size_t)EW * EW + 31u) / 32u;
+    uint32_t* bm = LDS_BM ? sh_bm : g_bitmap + (size_t)tile * words;
+    for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
+    if (!LDS_BM) __threadfence();
+    __syncthreads();
+    auto test = [&](uint32_t bit) -> bool {
+        if (LDS_BM) return (bm[bit >> 5] >> (bit & 31u)) & 1u;
+        return (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
+    };
+    const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
+    uint32_t n_out = 0; /* thread 0: succeeded labels that reach into the tile itself */
+    for (uint32_t l = l0; l < l1; ++l) {
+        const osmt_labelinfo* __restrict__ li = g_lab + l;
+        const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
+        const uint32_t iw = li->icon_w, ih = li->icon_h;
+        const bool has_cells = li->has_text && li->ry0 <= li->ry1 && li->cols > 0;
+        const int32_t ry0 = li->ry0, cx0 = li->cx0;
+        const uint32_t cols = li->cols;
+        const uint32_t n_cells = has_cells ? (uint32_t)(li->ry1 - ry0 + 1) * cols : 0u;
+        const double* __restrict__ A = g_a + li->plane_off;
+        bool failed = false;
+        for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
+            bool hit = false;
+            for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
+                const int32_t x = ix0 + (int32_t)(i % iw), y = iy0 + (int32_t)(i / iw);
+                if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
+                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
+                if (pass == 0)
+                    hit |= test(bit);
+                else
+                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            }
+            for (uint32_t i = tid; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) {
+                if (!(A[i] > 0.0)) continue;
+                const int32_t x = cx0 + (int32_t)(i % cols), y = ry0 + (int32_t)(i / cols);
+                if (x < -W || x >= 2 * W) continue; /* rows are clipped already */
+                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
+                if (pass == 0)
+                    hit |= test(bit);
+                else
+                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            }
+            if (pass == 0) {
+                failed = __syncthreads_or(hit ? 1 : 0) != 0;
+                if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
+                if (failed) break;
+            } else {
+                if (!LDS_BM) __threadfence();
+                __syncthreads();
+            }
+        }
+        if (!failed && tid == 0) {
+            /* what k_raster has to look at: the label's pixels clipped to the tile [0, W)^2 */
+            int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+            if (has_cells) {
+                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = li->ry1;
+            }
+            if (iw) {
+                bx0 = min(bx0, ix0), bx1 = max(bx1, ix0 + (int32_t)iw - 1);
+                by0 = min(by0, iy0), by1 = max(by1, iy0 + (int32_t)ih - 1);
+            }
+            bx0 = max(bx0, 0), by0 = max(by0, 0), bx1 = min(bx1, W - 1), by1 = min(by1, W - 1);
+            if (bx0 <= bx1 && by0 <= by1) {
+                osmt_tile_label e;
+                e.x0 = (int16_t)bx0, e.y0 = (int16_t)by0, e.x1 = (int16_t)bx1, e.y1 = (int16_t)by1;
+                e.label = l;
+                e._pad = 0;
+                g_tl[l0 + n_out++] = e;
+            }
+        }
+    }
+    if (tid == 0) g_tl_cnt[tile] = n_out;
+}
+
+hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
+    if (a.n_labels == 0 || a.n_jobs == 0) return hipSuccess;
+    const double4* segs = reinterpret_cast<const double4*>(a.segs);
+    hipLaunchKernelGGL(k_label_cover, dim3(a.n_labels), dim3(64), 0, st, a.info, a.n_labels, segs, a.plane_a, a.err);
+    if (a.n_wide)
+        hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
+                           a.plane_s_wide, a.err);
+    const size_t EW = 3u * (size_t)OSMT_TILE_SIZE * a.scale;
+    const size_t bm_bytes = ((EW * EW + 31u) / 32u) * 4u;
+    if (bm_bytes <= 96u * 1024u) {
+        /* per device and cheap: set on every launch rather than caching a process-wide flag */
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (ae != hipSuccess) return ae;
+        hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), bm_bytes, st, a.info,
+                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+    } else {
+        hipLaunchKernelGGL(k_label_resolve<false>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, a.info,
+                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+    }
+    return hipGetLastError();
+}

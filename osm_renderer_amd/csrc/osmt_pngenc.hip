@@ -1,0 +1,703 @@
+/*
+ * osmt_pngenc.hip — PNG files written by the GPU (rgb_triples_to_png, png_writer.rs:4-21).
+ * gfx950 only.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "osmt_internal.h"
+
+/* ------------------------------------------------------------------------- */
+/* PNG encoding on the GPU (rgb_triples_to_png, png_writer.rs:4-21): one wave per tile
+ * turns an RGBA8 framebuffer into a complete RGB8 PNG file — Paeth-filtered rows, ONE fixed-Huffman deflate
+ * block whose only matches are distance-1 runs, Adler-32, chunk CRCs — so that a serving pipeline moves
+ * ~50 KB per tile over PCIe instead of 256 KB and the host does no zlib work.  The reference's tests compare
+ * decoded pixels only (tests/test_rendering.rs:15-23), so the encoder is free to differ from the png crate.
+ *
+ * Per row (3W+1 filtered bytes in LDS, one wave): lanes own contiguous byte spans; a byte starts a run when it differs
+ * from its predecessor; a run (v, L) becomes literal(v), matches(len <= 258, dist 1) for the other L-1 bytes,
+ * and at most two trailing literals.  Bit counts are prefix-summed across lanes and tokens are OR-ed into an LDS
+ * bit buffer; rows are sized first so that every row knows its bit position in the file (see k_png_encode). */
+#define PNG_HDR_BYTES 43u /* 8 signature + 25 IHDR + 4 IDAT length + 4 "IDAT" + 2 zlib header */
+
+__device__ __forceinline__ void png_lit(uint32_t v, uint32_t& bits, uint32_t& n) {
+    if (v < 144u) {
+        bits = __brev(0x30u + v) >> 24;
+        n = 8u;
+    } else {
+        bits = __brev(0x190u + (v - 144u)) >> 23;
+        n = 9u;
+    }
+}
+/* match of length L (3..258) at distance 1: length code + extra bits + the 5-bit distance code 0 */
+__device__ __forceinline__ void png_run(uint32_t L, uint32_t& bits, uint32_t& n) {
+    uint32_t idx, eb = 0u, ev = 0u;
+    if (L == 258u) {
+        idx = 28u;
+    } else if (L <= 10u) {
+        idx = L - 3u;
+    } else {
+        const uint32_t l = L - 3u;
+        eb = (31u - (uint32_t)__clz((int)l)) - 2u;
+        idx = 4u + 4u * eb + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1u);
+    }
+    uint32_t hb, hn;
+    if (idx <= 22u) { /* codes 257..279: 7 bits */
+        hb = __brev(idx + 1u) >> 25;
+        hn = 7u;
+    } else { /* 280..285: 8 bits */
+        hb = __brev(0xC0u + idx - 23u) >> 24;
+        hn = 8u;
+    }
+    bits = hb | (ev << hn);
+    n = hn + eb + 5u;
+}
+/* bits of the tokens of run (v, L) */
+__device__ __forceinline__ uint32_t png_run_bits(uint32_t v, uint32_t L) {
+    const uint32_t ln = v < 144u ? 8u : 9u;
+    uint32_t total = ln, R = L - 1u;
+    while (R >= 258u) { /* code 285: 8 + 0 + 5 bits; at most 11 rounds per 1024-px row (no integer division) */
+        total += 13u;
+        R -= 258u;
+    }
+    if (R >= 3u) {
+        uint32_t b, n;
+        png_run(R, b, n);
+        total += n;
+    } else {
+        total += R * ln;
+    }
+    return total;
+}
+
+__device__ __forceinline__ void png_put(uint32_t* buf, uint32_t& pos, uint32_t bits, uint32_t n) {
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    atomicOr(buf + w, bits << sh);
+    if (sh + n > 32u) atomicOr(buf + w + 1u, bits >> (32u - sh));
+    pos += n;
+}
+
+#define PNG_MAX_W 1024u
+#ifndef OSMT_V_PNG_WAVES
+#define OSMT_V_PNG_WAVES 4
+#endif
+#define PNG_WAVES ((uint32_t)OSMT_V_PNG_WAVES)
+
+/* filtered row y (Paeth, type 4) of the tile into f[0 .. 3W]; executed by one wave */
+__device__ __forceinline__ void png_filter_row(const uint8_t* __restrict__ src, uint32_t W, uint32_t y, uint32_t lane, uint8_t* f) {
+    const uint32_t* __restrict__ row = reinterpret_cast<const uint32_t*>(src + (size_t)y * W * 4u);
+    const uint32_t* __restrict__ up = reinterpret_cast<const uint32_t*>(src + (size_t)(y ? y - 1u : 0u) * W * 4u);
+    if (lane == 0) f[0] = 4u;
+    for (uint32_t p = lane; p < W; p += 64u) {
+        const uint32_t cur = row[p];
+        const uint32_t a4 = p ? row[p - 1u] : 0u;
+        const uint32_t b4 = y ? up[p] : 0u;
+        const uint32_t c4 = (p && y) ? up[p - 1u] : 0u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int a = (int)((a4 >> (8 * ch)) & 0xFFu), b = (int)((b4 >> (8 * ch)) & 0xFFu), c = (int)((c4 >> (8 * ch)) & 0xFFu);
+            const int pp = a + b - c;
+            const int pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
+            const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            f[1u + 3u * p + (uint32_t)ch] = (uint8_t)((int)((cur >> (8 * ch)) & 0xFFu) - pred);
+        }
+    }
+}
+
+/* One row of the filtered stream, one wave.  EMIT = false: returns the row's bit count (lane-uniform) and its
+ * Adler partial sums; EMIT = true: ORs the tokens into `bits` (zeroed, LDS) starting at bit 0. */
+template <bool EMIT>
+__device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB, uint32_t lane, uint32_t* bits, uint32_t& adler1,
+                                                   uint32_t& adler2) {
+    const uint32_t span = (NB - 1u + 63u) / 64u;
+    const uint32_t s0 = min(NB, 1u + lane * span), s1 = min(NB, s0 + span);
+    uint32_t first_start = 0xFFFFFFFFu;
+    uint32_t a1 = 0u, a2 = 0u;
+    for (uint32_t k = s0; k < s1; ++k) {
+        const uint32_t v = f[k];
+        if (first_start == 0xFFFFFFFFu && (k == 1u || v != f[k - 1u])) first_start = k;
+        if (!EMIT) {
+            a1 += v;
+            a2 += (NB - k) * v;
+        }
+    }
+    const unsigned long long has = __ballot(first_start != 0xFFFFFFFFu);
+    const unsigned long long later = lane < 63u ? (has >> (lane + 1u)) : 0ull;
+    const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
+    const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
+    const uint32_t nxt_pos = later ? nxt_pos_raw : NB; /* where the run that leaves this span ends */
+    uint32_t my_bits = lane == 0 ? 8u : 0u; /* the filter-type byte: literal(4) */
+    for (uint32_t k = s0; k < s1;) {
+        const uint32_t v = f[k];
+        const bool is_start = k == 1u || v != f[k - 1u];
+        uint32_t e = k + 1u;
+        while (e < s1 && f[e] == v) ++e;
+        if (is_start) my_bits += png_run_bits(v, ((e == s1) ? nxt_pos : e) - k);
+        k = e;
+    }
+    uint32_t incl = my_bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if ((int)lane >= d) incl += t;
+    }
+    const uint32_t row_bits = (uint32_t)__shfl((int)incl, 63);
+    if (!EMIT) {
+        if (lane == 0) {
+            a1 += 4u;
+            a2 += NB * 4u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            a1 += (uint32_t)__shfl_xor((int)a1, d);
+            a2 += (uint32_t)__shfl_xor((int)a2, d);
+        }
+        adler1 = a1;
+        adler2 = a2;
+        return row_bits;
+    }
+    uint32_t pos = incl - my_bits;
+    if (lane == 0) {
+        uint32_t b, n;
+        png_lit(4u, b, n);
+        png_put(bits, pos, b, n);
+    }
+    for (uint32_t k = s0; k < s1;) {
+        const uint32_t v = f[k];
+        const bool is_start = k == 1u || v != f[k - 1u];
+        uint32_t e = k + 1u;
+        while (e < s1 && f[e] == v) ++e;
+        if (is_start) {
+            const uint32_t end = (e == s1) ? nxt_pos : e;
+            uint32_t lb, ln;
+            png_lit(v, lb, ln);
+            png_put(bits, pos, lb, ln);
+            uint32_t R = end - k - 1u;
+            while (R >= 3u) {
+                const uint32_t m = min(R, 258u);
+                uint32_t b, n;
+                png_run(m, b, n);
+                png_put(bits, pos, b, n);
+                R -= m;
+            }
+            for (; R; --R) png_put(bits, pos, lb, ln);
+        }
+        k = e;
+    }
+    return row_bits;
+}
+
+/* One workgroup (4 waves) per tile.  Pass 1: every wave sizes its rows (bits + Adler sums); a scan gives each
+ * row its bit position in the file; pass 2: every wave re-filters its rows, builds the row's bits in LDS and
+ * stores them shifted to that position — interior words plainly, the first and last word of a row (shared with
+ * its neighbours) with atomicOr into words zeroed between the passes. */
+__global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
+                                                              uint32_t W, uint32_t H, uint32_t ihdr_crc, uint8_t* g_out,
+                                                              size_t out_stride, uint32_t* __restrict__ g_len) {
+    __shared__ uint8_t sh_f[PNG_WAVES][3u * PNG_MAX_W + 4u];
+    __shared__ uint32_t sh_bits[PNG_WAVES][(9u * (3u * PNG_MAX_W + 1u)) / 32u + 4u];
+    __shared__ uint32_t sh_rowpos[PNG_MAX_W + 1u]; /* pass 1: bits of row y; after the scan: its absolute bit position */
+    __shared__ uint32_t sh_a1[PNG_MAX_W], sh_a2[PNG_MAX_W];
+    __shared__ uint32_t sh_crc_tab[256];
+    __shared__ uint32_t sh_col[32];
+    __shared__ uint32_t sh_raw[64 * PNG_WAVES];
+    __shared__ uint32_t sh_adler;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint8_t* __restrict__ src = g_rgba + (size_t)tile * tile_stride;
+    uint8_t* out = g_out + (size_t)tile * out_stride;
+    uint32_t* out_w = reinterpret_cast<uint32_t*>(out);
+    const uint32_t NB = 3u * W + 1u; /* bytes of one filtered row incl. the filter-type byte */
+
+    for (uint32_t i = tid; i < 256u; i += 64u * PNG_WAVES) { /* CRC-32 (reflected 0xEDB88320) byte table */
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        sh_crc_tab[i] = c;
+    }
+    /* ---- pass 1: size every row ---- */
+    for (uint32_t y = wave; y < H; y += PNG_WAVES) {
+        png_filter_row(src, W, y, lane, sh_f[wave]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t a1, a2;
+        const uint32_t rb = png_row_tokens<false>(sh_f[wave], NB, lane, nullptr, a1, a2);
+        if (lane == 0) {
+            sh_rowpos[y] = rb;
+            sh_a1[y] = a1;
+            sh_a2[y] = a2;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    /* ---- row positions (bit 0 of the deflate stream = byte 43, after the 3 block-header bits) + Adler-32 ---- */
+    if (tid == 0) {
+        uint32_t pos = PNG_HDR_BYTES * 8u + 3u;
+        uint32_t A = 1u, B = 0u;
+        for (uint32_t y = 0; y < H; ++y) {
+            const uint32_t rb = sh_rowpos[y];
+            sh_rowpos[y] = pos;
+            pos += rb;
+            B = (uint32_t)(((unsigned long long)B + (unsigned long long)NB * A + sh_a2[y]) % 65521ull);
+            A = (A + sh_a1[y]) % 65521u;
+        }
+        sh_rowpos[H] = pos; /* end-of-block code goes here */
+        sh_adler = (B << 16) | A;
+        /* signature, IHDR, IDAT length placeholder, "IDAT", zlib header (0x78 0x01), block header bits 1,1,0 */
+        out_w[0] = 0x474E5089u;
+        out_w[1] = 0x0A1A0A0Du;
+        out_w[2] = 0x0D000000u;
+        out_w[3] = 0x52444849u;
+        out_w[4] = __builtin_bswap32(W);
+        out_w[5] = __builtin_bswap32(H);
+        out_w[6] = 0x00000208u;
+        out_w[7] = (ihdr_crc >> 24 << 8) | (((ihdr_crc >> 16) & 0xFFu) << 16) | (((ihdr_crc >> 8) & 0xFFu) << 24);
+        out_w[8] = (ihdr_crc & 0xFFu);
+        out_w[9] = 0x41444900u;
+    }
+    __syncthreads();
+    /* words shared by two rows (and the word the stream ends in) start from zero; word 10 carries 'T', the zlib
+     * header and the block header */
+    for (uint32_t y = tid; y <= H; y += 64u * PNG_WAVES) {
+        const uint32_t w = sh_rowpos[y] >> 5;
+        if (w != 10u) out_w[w] = 0u;
+        if (y == H) out_w[w + 1u] = 0u; /* the 7 EOB bits may spill into the next word */
+    }
+    if (tid == 0) out_w[10] = 0x00017854u | (3u << 24);
+    __threadfence_block();
+    __syncthreads();
+    /* ---- pass 2: emit ---- */
+    const uint32_t nwords_row = (9u * NB) / 32u + 2u;
+    for (uint32_t y = wave; y < H; y += PNG_WAVES) {
+        png_filter_row(src, W, y, lane, sh_f[wave]);
+        for (uint32_t i = lane; i < nwords_row; i += 64u) sh_bits[wave][i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t a1, a2;
+        const uint32_t row_bits = png_row_tokens<true>(sh_f[wave], NB, lane, sh_bits[wave], a1, a2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t gbit = sh_rowpos[y];
+        const uint32_t sh = gbit & 31u, wb = gbit >> 5;
+        const uint32_t n_out = ((gbit + row_bits - 1u) >> 5) - wb + 1u; /* words holding bits of this row */
+        for (uint32_t k = lane; k < n_out; k += 64u) {
+            uint32_t w = sh ? (sh_bits[wave][k] << sh) : sh_bits[wave][k];
+            if (k && sh) w |= sh_bits[wave][k - 1u] >> (32u - sh);
+            /* the row's first word, and its last one unless the row ends exactly on a word boundary, are shared
+             * with the neighbouring rows (pre-zeroed above); everything else is this row's alone */
+            const bool shared = k == 0u || (k + 1u == n_out && ((gbit + row_bits) & 31u) != 0u);
+            if (shared)
+                atomicOr(out_w + wb + k, w);
+            else
+                out_w[wb + k] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence_block();
+    __syncthreads();
+    /* end of block (7 zero bits: already there), pad to a byte, Adler-32, IDAT length */
+    const uint32_t gend = sh_rowpos[H] + 7u;
+    const uint32_t endb = (gend + 7u) >> 3; /* first byte after the deflate stream */
+    if (tid == 0) {
+        const uint32_t adler = sh_adler;
+        out[endb + 0u] = (uint8_t)(adler >> 24);
+        out[endb + 1u] = (uint8_t)(adler >> 16);
+        out[endb + 2u] = (uint8_t)(adler >> 8);
+        out[endb + 3u] = (uint8_t)adler;
+        const uint32_t idat_len = 2u + (endb - PNG_HDR_BYTES) + 4u;
+        out[33] = (uint8_t)(idat_len >> 24);
+        out[34] = (uint8_t)(idat_len >> 16);
+        out[35] = (uint8_t)(idat_len >> 8);
+        out[36] = (uint8_t)idat_len;
+    }
+    __threadfence_block();
+    __syncthreads();
+    /* CRC-32 of "IDAT" + data = bytes [37, endb + 4): per-thread raw CRCs of equal blocks, then combined */
+    const uint32_t NT = 64u * PNG_WAVES;
+    const uint32_t c0 = 37u, c1 = endb + 4u;
+    const uint32_t blk = (c1 - c0 + NT - 1u) / NT;
+    {
+        const uint32_t b0 = min(c1, c0 + tid * blk), b1 = min(c1, b0 + blk);
+        uint32_t s = 0u;
+        for (uint32_t k = b0; k < b1; ++k) s = sh_crc_tab[(s ^ out[k]) & 0xFFu] ^ (s >> 8);
+        sh_raw[tid] = s;
+        if (tid < 32u) { /* column `tid` of the operator "advance the CRC register over blk zero bytes" */
+            uint32_t c = 1u << tid;
+            for (uint32_t k = 0; k < blk; ++k) c = sh_crc_tab[c & 0xFFu] ^ (c >> 8);
+            sh_col[tid] = c;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t s = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < NT; ++i) {
+            const uint32_t b0 = min(c1, c0 + i * blk), b1 = min(c1, b0 + blk);
+            const uint32_t len = b1 - b0;
+            if (!len) break;
+            if (len == blk) {
+                uint32_t t = 0u;
+                for (uint32_t b = 0; b < 32u; ++b)
+                    if ((s >> b) & 1u) t ^= sh_col[b];
+                s = t;
+            } else {
+                for (uint32_t k = 0; k < len; ++k) s = sh_crc_tab[s & 0xFFu] ^ (s >> 8);
+            }
+            s ^= sh_raw[i];
+        }
+        const uint32_t crc = ~s;
+        uint32_t o = c1;
+        out[o++] = (uint8_t)(crc >> 24);
+        out[o++] = (uint8_t)(crc >> 16);
+        out[o++] = (uint8_t)(crc >> 8);
+        out[o++] = (uint8_t)crc;
+        const uint8_t iend[12] = {0, 0, 0, 0, 0x49, 0x45, 0x4E, 0x44, 0xAE, 0x42, 0x60, 0x82};
+        for (int k = 0; k < 12; ++k) out[o++] = iend[k];
+        g_len[tile] = o;
+    }
+}
+
+/* Fast path of k_png_encode for W = 64 * PX (PX = 4: 256-px tiles, PX = 8: 512): ONE tokenisation pass.
+ * Wave w owns the band of rows [w*H/4, (w+1)*H/4) and walks it top to bottom; a lane owns PX consecutive pixels,
+ * whose raw values, the row above (carried in registers from the previous iteration) and the 3*PX filtered bytes
+ * all live in registers — run starts, run ends inside the lane and token sizes are straight-line code, the next
+ * row's pixels are fetched while the current one is tokenised.  Band 0 appends its rows directly behind the
+ * file header; bands 1..3 append into staging areas further up the tile's slot (bit 0 of a word), and once the
+ * band lengths are known they are moved down, bit-shifted, behind their predecessors (dst <= src, chunked
+ * read-then-write).  Adler-32 per band, combined like zlib's adler32_combine. */
+template <int PX>
+__global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
+                                                         uint32_t H, uint32_t ihdr_crc, uint8_t* g_out, size_t out_stride,
+                                                         uint32_t band_cap_words, uint32_t* __restrict__ g_len) {
+    constexpr uint32_t W = 64u * PX, NB = 3u * W + 1u, NBY = 3u * PX; /* bytes per lane */
+    constexpr uint32_t ROWW = (9u * NB) / 32u + 3u;
+    __shared__ uint32_t sh_bits[4][ROWW];
+    __shared__ uint32_t sh_crc_tab[256];
+    __shared__ uint32_t sh_col[32];
+    __shared__ uint32_t sh_raw[256];
+    __shared__ uint32_t sh_carry[4];
+    __shared__ uint32_t sh_band_bits[4], sh_band_a[4], sh_band_b[4];
+    __shared__ uint32_t sh_move[256 + 1];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint8_t* __restrict__ src = g_rgba + (size_t)tile * tile_stride;
+    uint8_t* out = g_out + (size_t)tile * out_stride;
+    uint32_t* out_w = reinterpret_cast<uint32_t*>(out);
+    for (uint32_t i = tid; i < 256u; i += 256u) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        sh_crc_tab[i] = c;
+    }
+    const uint32_t rows = H / 4u, y_begin = wave * rows, y_end = y_begin + rows;
+    /* where this band's bits go while it is being produced */
+    const uint32_t stage_w = wave == 0u ? 0u : 11u + wave * band_cap_words; /* band 0: the file itself */
+    uint32_t gbit = wave == 0u ? PNG_HDR_BYTES * 8u + 3u : 0u;               /* bit cursor relative to out_w[stage_w] */
+    uint32_t carry = wave == 0u ? (0x00017854u | (3u << 24)) : 0u;           /* band 0 continues word 10 */
+    if (tid == 0) {
+        out_w[0] = 0x474E5089u;
+        out_w[1] = 0x0A1A0A0Du;
+        out_w[2] = 0x0D000000u;
+        out_w[3] = 0x52444849u;
+        out_w[4] = __builtin_bswap32(W);
+        out_w[5] = __builtin_bswap32(H);
+        out_w[6] = 0x00000208u;
+        out_w[7] = (ihdr_crc >> 24 << 8) | (((ihdr_crc >> 16) & 0xFFu) << 16) | (((ihdr_crc >> 8) & 0xFFu) << 24);
+        out_w[8] = (ihdr_crc & 0xFFu);
+        out_w[9] = 0x41444900u;
+    }
+    uint32_t adler_a = 1u, adler_b = 0u;
+    uint32_t cur[PX], prev[PX], nxt[PX];
+    {
+        const uint4* __restrict__ r = reinterpret_cast<const uint4*>(src + (size_t)y_begin * W * 4u) + lane * (PX / 4);
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+            const uint4 v = r[q];
+            cur[4 * q] = v.x, cur[4 * q + 1] = v.y, cur[4 * q + 2] = v.z, cur[4 * q + 3] = v.w;
+        }
+        if (y_begin) {
+            const uint4* __restrict__ u = reinterpret_cast<const uint4*>(src + (size_t)(y_begin - 1u) * W * 4u) + lane * (PX / 4);
+#pragma unroll
+            for (int q = 0; q < PX / 4; ++q) {
+                const uint4 v = u[q];
+                prev[4 * q] = v.x, prev[4 * q + 1] = v.y, prev[4 * q + 2] = v.z, prev[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) prev[j] = 0u;
+        }
+    }
+    const uint32_t base = 1u + lane * NBY; /* stream index of this lane's first filtered byte */
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        if (y + 1u < y_end) { /* fetch the next row now */
+            const uint4* __restrict__ r = reinterpret_cast<const uint4*>(src + (size_t)(y + 1u) * W * 4u) + lane * (PX / 4);
+#pragma unroll
+            for (int q = 0; q < PX / 4; ++q) {
+                const uint4 v = r[q];
+                nxt[4 * q] = v.x, nxt[4 * q + 1] = v.y, nxt[4 * q + 2] = v.z, nxt[4 * q + 3] = v.w;
+            }
+        }
+        /* ---- Paeth filter, bytes in registers ---- */
+        uint32_t fb[NBY];
+        {
+            uint32_t la = (uint32_t)__shfl_up((int)cur[PX - 1], 1), lc = (uint32_t)__shfl_up((int)prev[PX - 1], 1);
+            if (lane == 0) la = lc = 0u;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const uint32_t a4 = j ? cur[j - 1] : la, c4 = j ? prev[j - 1] : lc, b4 = prev[j], x4 = cur[j];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const int a = (int)((a4 >> (8 * ch)) & 0xFFu), b = (int)((b4 >> (8 * ch)) & 0xFFu), c = (int)((c4 >> (8 * ch)) & 0xFFu);
+                    const int pp = a + b - c;
+                    const int pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
+                    const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    fb[3 * j + ch] = (uint32_t)((int)((x4 >> (8 * ch)) & 0xFFu) - pred) & 0xFFu;
+                }
+            }
+        }
+        /* ---- run starts and, for each byte, the next start inside the lane ---- */
+        const uint32_t pbyte = (uint32_t)__shfl_up((int)fb[NBY - 1], 1);
+        uint32_t startmask = 0u;
+#pragma unroll
+        for (int i = 0; i < (int)NBY; ++i) {
+            const bool st = i ? (fb[i] != fb[i - 1]) : (lane == 0u || fb[0] != pbyte);
+            startmask |= (st ? 1u : 0u) << i;
+        }
+        const uint32_t first_start = startmask ? base + (uint32_t)__builtin_ctz(startmask) : 0xFFFFFFFFu;
+        const unsigned long long has = __ballot(startmask != 0u);
+        const unsigned long long later = lane < 63u ? (has >> (lane + 1u)) : 0ull;
+        const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
+        const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
+        const uint32_t nxt_pos = later ? nxt_pos_raw : NB;
+        /* ---- size, prefix, emit ---- */
+        uint32_t my_bits = lane == 0u ? 8u : 0u, a1 = lane == 0u ? 4u : 0u, a2 = lane == 0u ? NB * 4u : 0u;
+#pragma unroll
+        for (int i = 0; i < (int)NBY; ++i) {
+            a1 += fb[i];
+            a2 += (NB - (base + (uint32_t)i)) * fb[i];
+            if ((startmask >> i) & 1u) {
+                const uint32_t rest = startmask >> (i + 1); /* i + 1 < 32 always: NBY <= 24 */
+                const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
+                my_bits += png_run_bits(fb[i], end - (base + (uint32_t)i));
+            }
+        }
+        uint32_t incl = my_bits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        const uint32_t row_bits = (uint32_t)__shfl((int)incl, 63);
+        uint32_t* bits = sh_bits[wave];
+        for (uint32_t i = lane; i < ROWW; i += 64u) bits[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t pos = incl - my_bits;
+        if (lane == 0u) {
+            uint32_t b, n;
+            png_lit(4u, b, n);
+            png_put(bits, pos, b, n);
+        }
+#pragma unroll
+        for (int i = 0; i < (int)NBY; ++i) {
+            if ((startmask >> i) & 1u) {
+                const uint32_t rest = startmask >> (i + 1);
+                const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
+                uint32_t lb, ln;
+                png_lit(fb[i], lb, ln);
+                png_put(bits, pos, lb, ln);
+                uint32_t R = end - (base + (uint32_t)i) - 1u;
+                while (R >= 3u) {
+                    const uint32_t m = min(R, 258u);
+                    uint32_t b, n;
+                    png_run(m, b, n);
+                    png_put(bits, pos, b, n);
+                    R -= m;
+                }
+                for (; R; --R) png_put(bits, pos, lb, ln);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            a1 += (uint32_t)__shfl_xor((int)a1, d);
+            a2 += (uint32_t)__shfl_xor((int)a2, d);
+        }
+        adler_b = (uint32_t)(((unsigned long long)adler_b + (unsigned long long)NB * adler_a + a2) % 65521ull);
+        adler_a = (adler_a + a1) % 65521u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        /* ---- append the row at the band's bit cursor ---- */
+        {
+            const uint32_t sh = gbit & 31u, wb = gbit >> 5;
+            const uint32_t gend = gbit + row_bits;
+            const uint32_t n_out = (gend >> 5) - wb + 1u; /* words touched; the last one is the new carry */
+            for (uint32_t k = lane; k < n_out; k += 64u) {
+                uint32_t w = sh ? (bits[k] << sh) : bits[k];
+                if (k)
+                    w |= sh ? (bits[k - 1u] >> (32u - sh)) : 0u;
+                else
+                    w |= carry;
+                if (k + 1u < n_out)
+                    out_w[stage_w + wb + k] = w;
+                else
+                    sh_carry[wave] = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gbit = gend;
+            carry = (gbit & 31u) ? sh_carry[wave] : 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            prev[j] = cur[j];
+            cur[j] = nxt[j];
+        }
+    }
+    /* flush the band's partial word (upper bits zero) and publish its length and checksum */
+    if (lane == 0u) {
+        if (gbit & 31u) out_w[stage_w + (gbit >> 5)] = carry;
+        sh_band_bits[wave] = wave == 0u ? gbit - (PNG_HDR_BYTES * 8u + 3u) : gbit;
+        sh_band_a[wave] = adler_a;
+        sh_band_b[wave] = adler_b;
+    }
+    __threadfence_block();
+    __syncthreads();
+    /* ---- move bands 1..3 down behind their predecessors ---- */
+    uint32_t endpos = PNG_HDR_BYTES * 8u + 3u + sh_band_bits[0];
+    for (uint32_t b = 1; b < 4u; ++b) {
+        const uint32_t L = sh_band_bits[b];
+        const uint32_t sw = 11u + b * band_cap_words; /* staging: bit 0 of out_w[sw] */
+        const uint32_t sh = endpos & 31u, wb = endpos >> 5;
+        const uint32_t n_src = (L + 31u) >> 5;
+        const uint32_t n_dst = ((endpos + L + 31u) >> 5) - wb; /* destination words holding bits of this band */
+        for (uint32_t c = 0; c < n_dst; c += 256u) {
+            const uint32_t k = c + tid;
+            uint32_t w = 0u;
+            if (k < n_dst) {
+                const uint32_t s_cur = k < n_src ? out_w[sw + k] : 0u;
+                const uint32_t s_prev = (k && k - 1u < n_src) ? out_w[sw + k - 1u] : 0u;
+                w = sh ? ((s_cur << sh) | (s_prev >> (32u - sh))) : s_cur;
+                if (k == 0u && sh) w |= out_w[wb]; /* the predecessor's partial last word */
+            }
+            __syncthreads(); /* every source word of this chunk is read before any destination word is written */
+            if (k < n_dst) out_w[wb + k] = w;
+            __threadfence_block();
+            __syncthreads();
+        }
+        endpos += L;
+    }
+    /* end of block: 7 zero bits (the word after the last one may receive some of them) */
+    if (tid == 0) {
+        if (((endpos + 7u) >> 5) != (endpos >> 5) || !(endpos & 31u)) out_w[(endpos + 7u) >> 5] = 0u;
+        /* Adler-32 of the concatenation (zlib's adler32_combine): A = A1 + A2 - 1, B = B1 + B2 + len2 * (A1 - 1) */
+        unsigned long long A = sh_band_a[0], B = sh_band_b[0];
+        const unsigned long long len2 = (unsigned long long)rows * NB;
+        for (uint32_t b = 1; b < 4u; ++b) {
+            const unsigned long long A2 = sh_band_a[b], B2 = sh_band_b[b];
+            B = (B + B2 + (len2 % 65521ull) * ((A + 65520ull) % 65521ull)) % 65521ull;
+            A = (A + A2 + 65520ull) % 65521ull;
+        }
+        sh_move[0] = (uint32_t)((B << 16) | A);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t gend = endpos + 7u;
+    const uint32_t endb = (gend + 7u) >> 3;
+    if (tid == 0) {
+        const uint32_t adler = sh_move[0];
+        out[endb + 0u] = (uint8_t)(adler >> 24);
+        out[endb + 1u] = (uint8_t)(adler >> 16);
+        out[endb + 2u] = (uint8_t)(adler >> 8);
+        out[endb + 3u] = (uint8_t)adler;
+        const uint32_t idat_len = 2u + (endb - PNG_HDR_BYTES) + 4u;
+        out[33] = (uint8_t)(idat_len >> 24);
+        out[34] = (uint8_t)(idat_len >> 16);
+        out[35] = (uint8_t)(idat_len >> 8);
+        out[36] = (uint8_t)idat_len;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t c0 = 37u, c1 = endb + 4u;
+    const uint32_t blk = (c1 - c0 + 255u) / 256u;
+    {
+        const uint32_t b0 = min(c1, c0 + tid * blk), b1 = min(c1, b0 + blk);
+        uint32_t s = 0u;
+        for (uint32_t k = b0; k < b1; ++k) s = sh_crc_tab[(s ^ out[k]) & 0xFFu] ^ (s >> 8);
+        sh_raw[tid] = s;
+        if (tid < 32u) {
+            uint32_t c = 1u << tid;
+            for (uint32_t k = 0; k < blk; ++k) c = sh_crc_tab[c & 0xFFu] ^ (c >> 8);
+            sh_col[tid] = c;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t s = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < 256u; ++i) {
+            const uint32_t b0 = min(c1, c0 + i * blk), b1 = min(c1, b0 + blk);
+            const uint32_t len = b1 - b0;
+            if (!len) break;
+            if (len == blk) {
+                uint32_t t = 0u;
+                for (uint32_t b = 0; b < 32u; ++b)
+                    if ((s >> b) & 1u) t ^= sh_col[b];
+                s = t;
+            } else {
+                for (uint32_t k = 0; k < len; ++k) s = sh_crc_tab[s & 0xFFu] ^ (s >> 8);
+            }
+            s ^= sh_raw[i];
+        }
+        const uint32_t crc = ~s;
+        uint32_t o = c1;
+        out[o++] = (uint8_t)(crc >> 24);
+        out[o++] = (uint8_t)(crc >> 16);
+        out[o++] = (uint8_t)(crc >> 8);
+        out[o++] = (uint8_t)crc;
+        const uint8_t iend[12] = {0, 0, 0, 0, 0x49, 0x45, 0x4E, 0x44, 0xAE, 0x42, 0x60, 0x82};
+        for (int k = 0; k < 12; ++k) out[o++] = iend[k];
+        g_len[tile] = o;
+    }
+}
+
+/* gathers the variable-length PNG files of a batch into one blob: tile i -> blob[off[i] .. off[i] + len[i]) */
+__global__ __launch_bounds__(256) void k_png_compact(const uint8_t* __restrict__ slots, size_t slot_stride,
+                                                     const uint32_t* __restrict__ len, const unsigned long long* __restrict__ off,
+                                                     uint32_t n, uint8_t* __restrict__ blob) {
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n) return;
+    const uint8_t* __restrict__ src = slots + (size_t)tile * slot_stride;
+    uint8_t* __restrict__ dst = blob + off[tile];
+    const uint32_t L = len[tile];
+    for (uint32_t i = threadIdx.x; i < L; i += 256u) dst[i] = src[i];
+}
+
+hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
+                                   void* blob, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_png_compact, dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(slots), slot_stride, len, off, n,
+                       reinterpret_cast<uint8_t*>(blob));
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, uint32_t ihdr_crc, void* out,
+                           size_t out_stride, uint32_t* out_len, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (W > PNG_MAX_W) return hipErrorInvalidValue;
+    if ((W == 256u || W == 512u) && (H % 4u) == 0u && H >= 4u) {
+        /* staging capacity of one band: H/4 rows of at most 9 bits per filtered byte */
+        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * 9u + 31u) / 32u + 2u);
+        if ((size_t)(11u + 4u * band_cap_words) * 4u + 64u <= out_stride) {
+            if (W == 256u)
+                hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
+                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
+            else
+                hipLaunchKernelGGL((k_png_encode_fast<8>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
+                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL(k_png_encode, dim3(n), dim3(64 * PNG_WAVES), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, W, H, ihdr_crc,
+                       reinterpret_cast<uint8_t*>(out), out_stride, out_len);
+    return hipGetLastError();
+}
