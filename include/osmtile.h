@@ -172,6 +172,8 @@ typedef struct osmt_scene osmt_scene; /* a batch resident in HBM + its workspace
 /* ---- lifecycle --------------------------------------------------------- */
 /* Drawer::new (drawer.rs:33-38) + per-worker TilePixels::new (tile_pixels.rs:57-87). */
 int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx);
+/* Scenes hold a reference on their context: destroying a context that still has scenes only drops the handle; its
+ * device buffers, streams and icon registry go with the last osmt_scene_free (no use-after-free in either order). */
 void osmt_destroy(osmt_ctx* ctx);
 /* anyhow::Error text (http_server.rs:127-132 prints it); thread-local, never NULL. */
 const char* osmt_last_error(void);
@@ -182,6 +184,20 @@ uint32_t osmt_version(void);
 /* Icon::load result (icon.rs:14-58): straight-alpha RGBA8 pixels, row-major;
  * stored premultiplied exactly as RgbaColor::from_components (tile_pixels.rs:21-23). */
 int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_image_id);
+
+/* ---- display-list validation (host only, no device needed) ----------------- */
+/* The checks every upload runs first; what the reference's type system and borrow checker guarantee for
+ * Drawer::draw_to_pixels' arguments (drawer.rs:60-67) has to be verified at a C boundary.  OSMT_OK, or
+ * OSMT_INVALID_ARG / OSMT_UNSUPPORTED with the reason in osmt_last_error():
+ *   - indices in range; the jobs' op ranges PARTITION the op pool (every op belongs to exactly one job — the per-op
+ *     pre-pass runs over the whole pool) and their point ranges do not overlap (a point is projected against the
+ *     tile of the job that owns it);
+ *   - zoom <= OSMT_MAX_ZOOM, scale in 1..OSMT_MAX_SCALE, opacity in [0, 2^52], finite widths, known caps, dash lists
+ *     non-empty (Some([]) panics in the reference, opacity_calculator.rs:109) and <= OSMT_MAX_DASHES;
+ *   - coordinates the integer walks can hold: |x|, |y| <= 2^28 for OSMT_COORD_POINT_I32; finite (lat, lon) inside the
+ *     Web-Mercator square (|lat| <= 85.06, |lon| <= 180) otherwise — beyond it Point::from_node saturates
+ *     (point.rs:11-19) and the reference itself draws garbage. */
+int osmt_validate_batch(const osmt_batch* batch);
 
 /* ---- whole path, host buffers (Drawer::draw_to_pixels, drawer.rs:60-131) -- */
 /* out_rgba: n_jobs tiles of (256*scale)^2 RGBA8 pixels (A = 255), tile i at

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,9 +82,17 @@ struct osmt_ctx {
     std::vector<cached_buf> host_cache; /* pinned staging buffers (one packed H2D copy per small call) */
     std::vector<osmt_image_desc> images;
     std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
+    /* Device copy of the registry.  A registration followed by a render makes a NEW pair of buffers; the old pair
+     * moves to `image_graveyard` and lives until the context goes, so a kernel launched by another worker thread
+     * with the previous snapshot never reads freed memory (registrations are rare: once per icon at start-up). */
     osmt_image_desc* d_images = nullptr;
     double4* d_image_pool = nullptr;
+    uint32_t d_n_images = 0;
+    std::vector<void*> image_graveyard;
     bool images_dirty = false;
+    /* one reference for the handle returned by osmt_create + one per live scene: osmt_destroy on a context that still
+     * has scenes only drops the handle's reference, the last osmt_scene_free tears the context down */
+    std::atomic<int> refs{1};
 };
 
 struct osmt_scene {
@@ -113,6 +122,11 @@ struct osmt_scene {
     std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_lab_wide;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
+    /* public scenes: one event per stream the scene was rendered on, recorded behind the last launch that reads it.
+     * osmt_scene_free / set_labels / read_* wait for THESE events only — never for the device — so worker threads
+     * with their own scenes and streams do not stall each other (http_server.rs:50-83: independent workers). */
+    std::mutex use_mu;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> last_use;
     void* h_stage = nullptr;          /* pinned staging of a packed upload, returned to the pool when the scene goes */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
@@ -133,6 +147,7 @@ struct osmt_scene {
 
 namespace {
 
+constexpr double OSMT_MAX_ABS_LAT = 85.06; /* Web-Mercator limit 85.0511..., with a little slack */
 constexpr size_t CACHE_KEEP_BYTES = (size_t)8 << 30; /* idle buffers beyond this are returned to the driver */
 
 hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
@@ -234,23 +249,115 @@ void dev_free(osmt_ctx* ctx, void* p) {
     }
 }
 
-int sync_images(osmt_ctx* ctx) {
+struct image_snapshot {
+    const osmt_image_desc* desc = nullptr;
+    const double4* pool = nullptr;
+    uint32_t n = 0;
+};
+
+/* Brings the device copy of the icon registry up to date and returns a consistent (descriptors, pool, count) triple
+ * that stays valid for the life of the context. */
+int sync_images(osmt_ctx* ctx, image_snapshot* snap) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!ctx->images_dirty) return OSMT_OK;
+    if (ctx->images_dirty) {
+        osmt_image_desc* nd = nullptr;
+        double4* np = nullptr;
+        if (!ctx->images.empty()) {
+            HIP_TRY(hipMalloc((void**)&nd, ctx->images.size() * sizeof(osmt_image_desc)));
+            hipError_t e = hipMalloc((void**)&np, ctx->image_pool_host.size() * sizeof(double));
+            if (e == hipSuccess) e = hipMemcpy(nd, ctx->images.data(), ctx->images.size() * sizeof(osmt_image_desc), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(np, ctx->image_pool_host.data(), ctx->image_pool_host.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(nd);
+                if (np) (void)hipFree(np);
+                return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "icon registry upload failed: %s", hipGetErrorString(e));
+            }
+        }
+        if (ctx->d_images) ctx->image_graveyard.push_back(ctx->d_images);
+        if (ctx->d_image_pool) ctx->image_graveyard.push_back(ctx->d_image_pool);
+        ctx->d_images = nd;
+        ctx->d_image_pool = np;
+        ctx->d_n_images = (uint32_t)ctx->images.size();
+        ctx->images_dirty = false;
+    }
+    if (snap) {
+        snap->desc = ctx->d_images;
+        snap->pool = ctx->d_image_pool;
+        snap->n = ctx->d_n_images;
+    }
+    return OSMT_OK;
+}
+
+void ctx_teardown(osmt_ctx* ctx) {
+    (void)hipSetDevice(ctx->device);
     if (ctx->d_images) (void)hipFree(ctx->d_images);
     if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
-    ctx->d_images = nullptr;
-    ctx->d_image_pool = nullptr;
-    if (!ctx->images.empty()) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_images, ctx->images.size() * sizeof(osmt_image_desc)));
-        HIP_TRY(hipMalloc((void**)&ctx->d_image_pool, ctx->image_pool_host.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(ctx->d_images, ctx->images.data(), ctx->images.size() * sizeof(osmt_image_desc),
-                          hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->d_image_pool, ctx->image_pool_host.data(), ctx->image_pool_host.size() * sizeof(double),
-                          hipMemcpyHostToDevice));
-    }
-    ctx->images_dirty = false;
+    for (void* p : ctx->image_graveyard) (void)hipFree(p);
+    for (auto& c : ctx->cache) (void)hipFree(c.p);
+    for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
+    for (auto& c : ctx->host_cache) (void)hipHostFree(c.p);
+    delete ctx;
+}
+
+void ctx_release(osmt_ctx* ctx) {
+    if (ctx->refs.fetch_sub(1) == 1) ctx_teardown(ctx);
+}
+
+/* Device -> host copy of finished data on a private pooled stream: a NULL-stream hipMemcpy would order itself against
+ * every blocking stream of the process. */
+hipError_t copy_back(osmt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    hipStream_t st = nullptr;
+    hipError_t e = stream_acquire(ctx, &st);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    stream_release(ctx, st);
+    return e;
+}
+
+/* Host-buffer entry points: an internal error of the label coverage kernels (window overflow) must not return OSMT_OK
+ * with wrong pixels.  Called after the call's work was enqueued on `st`; synchronises it. */
+int label_error_check(osmt_scene* sc, hipStream_t st) {
+    if (!sc->n_labels) return OSMT_OK;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, sc->d_lab_err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err) return fail(OSMT_HIP_ERROR, "label coverage window overflow (internal error %u)", err);
     return OSMT_OK;
+}
+
+/* The scene object itself (device buffers are returned by the caller first). */
+void scene_delete(osmt_scene* s) {
+    for (auto& u : s->last_use) (void)hipEventDestroy(u.second);
+    osmt_ctx* ctx = s->ctx;
+    delete s;
+    if (ctx) ctx_release(ctx);
+}
+
+/* Records "the scene was last read here" behind the launches just issued on `st` (public scenes only). */
+hipError_t scene_mark_use(osmt_scene* sc, hipStream_t st) {
+    if (sc->own_stream) return hipSuccess; /* per-call scenes live and die on their own stream */
+    std::lock_guard<std::mutex> lk(sc->use_mu);
+    for (auto& u : sc->last_use)
+        if (u.first == st) return hipEventRecord(u.second, st);
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    sc->last_use.emplace_back(st, ev);
+    return hipEventRecord(ev, st);
+}
+
+/* Blocks the calling thread until every launch that reads or writes the scene has finished — and nothing else. */
+hipError_t scene_wait_idle(osmt_scene* sc) {
+    if (sc->own_stream) return hipStreamSynchronize(sc->own_stream);
+    std::lock_guard<std::mutex> lk(sc->use_mu);
+    hipError_t first = hipSuccess;
+    for (auto& u : sc->last_use) {
+        const hipError_t e = hipEventSynchronize(u.second);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
 }
 
 int validate_batch(const osmt_batch* b) {
@@ -273,35 +380,54 @@ int validate_batch(const osmt_batch* b) {
                 if (b->node_refs[i] >= b->n_nodes) return fail(OSMT_INVALID_ARG, "point %zu: node reference %u out of range", i, b->node_refs[i]);
         }
     }
-    for (size_t j = 0; j < b->n_jobs; ++j) {
-        const osmt_tile_job& job = b->jobs[j];
-        if (job.zoom > OSMT_MAX_ZOOM) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u > MAX_ZOOM (src/tile.rs:5)", j, job.zoom);
-        if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
-        if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
-        for (uint32_t k = 0; k < job.n_ops; ++k) {
-            const osmt_op& op = b->ops[job.op_off + k];
-            if (op.kind > OSMT_OP_STROKE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown kind %u", j, k, op.kind);
-            if (op.kind == OSMT_OP_NONE) continue;
-            if ((size_t)op.ring_off + op.n_rings > b->n_rings)
-                return fail(OSMT_INVALID_ARG, "job %zu op %u: ring range out of bounds", j, k);
-            for (uint32_t r = 0; r < op.n_rings; ++r) {
-                const osmt_ring& ring = b->rings[op.ring_off + r];
-                if (ring.first_pt < job.pt_off || (size_t)ring.first_pt + ring.n_pts > (size_t)job.pt_off + job.n_pts)
-                    return fail(OSMT_INVALID_ARG, "job %zu op %u ring %u: points outside the job's pool range", j, k, r);
+    /* Every op of the pool is pre-processed on the device (k_opinfo runs over [0, n_ops)), so every op must be
+     * reachable through exactly one job: the jobs' op ranges partition the op pool and their point ranges do not
+     * overlap (a point is projected against the tile of the job that owns it). */
+    std::vector<uint32_t> op_job(b->n_ops, 0xFFFFFFFFu);
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> pr; /* non-empty point ranges, for the overlap test */
+        pr.reserve(b->n_jobs);
+        for (size_t j = 0; j < b->n_jobs; ++j) {
+            const osmt_tile_job& job = b->jobs[j];
+            if (job.zoom > OSMT_MAX_ZOOM) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u > MAX_ZOOM (src/tile.rs:5)", j, job.zoom);
+            if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
+            if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
+            for (uint32_t k = 0; k < job.n_ops; ++k) {
+                uint32_t& owner = op_job[job.op_off + k];
+                if (owner != 0xFFFFFFFFu)
+                    return fail(OSMT_INVALID_ARG, "job %zu: op %u also belongs to job %u (op ranges must not overlap)", j, job.op_off + k, owner);
+                owner = (uint32_t)j;
             }
-            if (!(op.opacity >= 0.0) || !(op.opacity <= 4503599627370496.0))
-                return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be in [0, 2^52]", j, k);
-            if (op.kind == OSMT_OP_STROKE) {
-                if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
-                if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
-                if (op.has_dashes) {
-                    /* Some([]) panics in the reference (opacity_calculator.rs:109 indexes dashes[0]) */
-                    if (op.n_dashes == 0) return fail(OSMT_INVALID_ARG, "job %zu op %u: empty dash list", j, k);
-                    if (op.n_dashes > OSMT_MAX_DASHES)
-                        return fail(OSMT_UNSUPPORTED, "job %zu op %u: more than %u dashes", j, k, OSMT_MAX_DASHES);
-                    if ((size_t)op.dashes_off + op.n_dashes > b->n_dashes)
-                        return fail(OSMT_INVALID_ARG, "job %zu op %u: dash range out of bounds", j, k);
-                }
+            if (job.n_pts) pr.emplace_back((uint64_t)job.pt_off, (uint64_t)job.pt_off + job.n_pts);
+        }
+        std::sort(pr.begin(), pr.end());
+        for (size_t i = 1; i < pr.size(); ++i)
+            if (pr[i].first < pr[i - 1].second) return fail(OSMT_INVALID_ARG, "the point ranges of two jobs overlap at point %llu", (unsigned long long)pr[i].first);
+    }
+    for (size_t o = 0; o < b->n_ops; ++o) {
+        const osmt_op& op = b->ops[o];
+        const size_t j = op_job[o];
+        if (j == 0xFFFFFFFFu) return fail(OSMT_INVALID_ARG, "op %zu is not covered by any job (the jobs' op ranges must partition the op pool)", o);
+        const osmt_tile_job& job = b->jobs[j];
+        const uint32_t k = (uint32_t)(o - job.op_off);
+        if (op.kind > OSMT_OP_STROKE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown kind %u", j, k, op.kind);
+        if (op.kind == OSMT_OP_NONE) continue;
+        if ((size_t)op.ring_off + op.n_rings > b->n_rings) return fail(OSMT_INVALID_ARG, "job %zu op %u: ring range out of bounds", j, k);
+        for (uint32_t r = 0; r < op.n_rings; ++r) {
+            const osmt_ring& ring = b->rings[op.ring_off + r];
+            if (ring.first_pt < job.pt_off || (size_t)ring.first_pt + ring.n_pts > (size_t)job.pt_off + job.n_pts)
+                return fail(OSMT_INVALID_ARG, "job %zu op %u ring %u: points outside the job's pool range", j, k, r);
+        }
+        if (!(op.opacity >= 0.0) || !(op.opacity <= 4503599627370496.0))
+            return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be in [0, 2^52]", j, k);
+        if (op.kind == OSMT_OP_STROKE) {
+            if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
+            if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
+            if (op.has_dashes) {
+                /* Some([]) panics in the reference (opacity_calculator.rs:109 indexes dashes[0]) */
+                if (op.n_dashes == 0) return fail(OSMT_INVALID_ARG, "job %zu op %u: empty dash list", j, k);
+                if (op.n_dashes > OSMT_MAX_DASHES) return fail(OSMT_UNSUPPORTED, "job %zu op %u: more than %u dashes", j, k, OSMT_MAX_DASHES);
+                if ((size_t)op.dashes_off + op.n_dashes > b->n_dashes) return fail(OSMT_INVALID_ARG, "job %zu op %u: dash range out of bounds", j, k);
             }
         }
     }
@@ -309,6 +435,18 @@ int validate_batch(const osmt_batch* b) {
         for (size_t i = 0; i < 2 * b->n_pts; ++i)
             if (b->points[i] > OSMT_COORD_LIMIT || b->points[i] < -OSMT_COORD_LIMIT)
                 return fail(OSMT_UNSUPPORTED, "point %zu: |coordinate| > 2^28", i / 2);
+    } else {
+        /* The closed forms and the Bresenham state of the kernels need |pixel coordinate| <= 2^28 (osmt_geom.h); with
+         * zoom <= 18 and scale <= 4 that holds for every (lat, lon) of the Web-Mercator square.  Outside it (or for a
+         * NaN / infinity) Point::from_node saturates (point.rs:11-19) and the integer walks would overflow. */
+        const double* ll = b->coord_kind == OSMT_COORD_NODE_REF ? b->nodes : b->latlon;
+        const size_t n = b->coord_kind == OSMT_COORD_NODE_REF ? b->n_nodes : b->n_pts;
+        for (size_t i = 0; i < n; ++i) {
+            const double lat = ll[2 * i], lon = ll[2 * i + 1];
+            if (!(std::fabs(lat) <= OSMT_MAX_ABS_LAT) || !(std::fabs(lon) <= 180.0))
+                return fail(OSMT_UNSUPPORTED, "point %zu: (lat, lon) = (%g, %g) outside the Web-Mercator square (|lat| <= %g, |lon| <= 180)", i, lat,
+                            lon, OSMT_MAX_ABS_LAT);
+        }
     }
     return OSMT_OK;
 }
@@ -334,7 +472,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     if (want_labels && ((stages & 8u) || ((stages & 4u) && !(stages & 16u)))) {
         /* the label pass does not read the area canvas: coverage + collisions first, then
          * k_raster blends the survivors right before to_rgb_triples */
-        int rc = sync_images(ctx);
+        int rc = sync_images(ctx, nullptr);
         if (rc != OSMT_OK) return rc;
         osmt_label_launch ll;
         memset(&ll, 0, sizeof ll);
@@ -356,7 +494,8 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         HIP_TRY(osmt_launch_labels(ll, st));
     }
     if (stages & 4u) {
-        int rc = sync_images(ctx);
+        image_snapshot img;
+        int rc = sync_images(ctx, &img);
         if (rc != OSMT_OK) return rc;
         if (first_job > sc->n_jobs || n_range > sc->n_jobs - first_job) return fail(OSMT_INVALID_ARG, "tile range out of bounds");
         const uint32_t n_render = n_range ? n_range : sc->n_jobs - first_job;
@@ -378,9 +517,9 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.blk = sc->d_blk;
         a.has_blocks = sc->n_blk > 0 ? 1u : 0u;
         a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
-        a.images = ctx->d_images;
-        a.image_pool = ctx->d_image_pool;
-        a.n_images = (uint32_t)ctx->images.size();
+        a.images = img.desc;
+        a.image_pool = img.pool;
+        a.n_images = img.n;
         a.out = d_out;
         a.out_tile_stride = stride;
         if (want_labels) {
@@ -393,6 +532,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         }
         HIP_TRY(osmt_launch_raster(a, f64, st));
     }
+    HIP_TRY(scene_mark_use(sc, st));
     return OSMT_OK;
 }
 
@@ -428,13 +568,7 @@ int osmt_create(const osmt_config* cfg, osmt_ctx** out_ctx) {
 
 void osmt_destroy(osmt_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->d_images) (void)hipFree(ctx->d_images);
-    if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
-    for (auto& c : ctx->cache) (void)hipFree(c.p); /* scenes must be freed before their context */
-    for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
-    for (auto& c : ctx->host_cache) (void)hipHostFree(c.p);
-    delete ctx;
+    ctx_release(ctx); /* scenes still alive keep the context (and the device buffers they use) until they are freed */
 }
 
 static int osmt_register_image_body(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t* out_id) {
@@ -507,6 +641,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     }
 
     s->ctx = ctx;
+    ctx->refs.fetch_add(1);
     s->n_jobs = (uint32_t)b->n_jobs;
     s->n_ops = (uint32_t)b->n_ops;
     s->n_rings = (uint32_t)b->n_rings;
@@ -547,7 +682,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
-        delete s;
+        scene_delete(s);
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
                     hipGetErrorString(e));
     }
@@ -597,7 +732,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         if (err != hipSuccess) {
             stage_release(ctx, stage);
             dev_free(ctx, s->d_base);
-            delete s;
+            scene_delete(s);
             return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
         }
         *out_scene = s;
@@ -616,11 +751,15 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err != hipSuccess) {
         dev_free(ctx, s->d_base);
-        delete s;
+        scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
     *out_scene = s;
     return OSMT_OK;
+}
+
+int osmt_validate_batch(const osmt_batch* b) {
+    return guarded([&] { return validate_batch(b); });
 }
 
 int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
@@ -631,15 +770,13 @@ void osmt_scene_free(osmt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     /* in-flight kernels may still read the scene and a cached buffer can be handed to the next upload at once:
-     * wait for the scene's own stream (internal per-call scenes) or for the device (hipFree used to do that) */
-    if (s->own_stream)
-        (void)hipStreamSynchronize(s->own_stream);
-    else
-        (void)hipDeviceSynchronize();
+     * wait for the scene's own stream (internal per-call scenes) or for the last launch on every stream the scene
+     * was rendered on (public scenes) — not for the device: other workers' streams keep running */
+    (void)scene_wait_idle(s);
     dev_free(s->ctx, s->d_base);
     dev_free(s->ctx, s->d_lab_base);
     stage_release(s->ctx, s->h_stage);
-    delete s;
+    scene_delete(s);
 }
 
 /* Drawer::draw_labels (drawer.rs:221-262) as data: validates, sizes each label's coverage window and
@@ -650,10 +787,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = sc->own_stream;
-    if (st)
-        HIP_TRY(hipStreamSynchronize(st));
-    else
-        HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(scene_wait_idle(sc)); /* the previous label pass of THIS scene may still be in flight; nobody else is waited for */
     dev_free(ctx, sc->d_lab_base);
     sc->d_lab_base = nullptr;
     sc->n_labels = sc->n_label_segs = 0;
@@ -781,8 +915,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     if (e == hipSuccess) e = up(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4);
     if (e == hipSuccess) e = up(sc->d_lab_segs, lb->segs, lb->n_segs * 32);
     if (e == hipSuccess) e = up(sc->d_lab_wide, wide.data(), wide.size() * 4);
-    if (e == hipSuccess) e = st ? hipMemsetAsync(sc->d_lab_ok, 0, lb->n_labels, st) : hipMemset(sc->d_lab_ok, 0, lb->n_labels);
-    if (e == hipSuccess) e = st ? hipMemsetAsync(sc->d_lab_err, 0, 4, st) : hipMemset(sc->d_lab_err, 0, 4);
+    /* the verdicts and the error word are cleared by the label stage itself, on the render stream (osmt_launch_labels) */
     if (e != hipSuccess) {
         dev_free(ctx, sc->d_lab_base);
         sc->d_lab_base = nullptr;
@@ -802,11 +935,11 @@ static int osmt_scene_read_label_status_body(osmt_ctx* ctx, osmt_scene* sc, uint
     if (sc->n_labels == 0) return OSMT_OK;
     if (!ok) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(scene_wait_idle(sc));
     uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, sc->d_lab_err, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_back(ctx, &err, sc->d_lab_err, 4));
     if (err) return fail(OSMT_HIP_ERROR, "label coverage window overflow (internal error %u)", err);
-    HIP_TRY(hipMemcpy(ok, sc->d_lab_ok, sc->n_labels, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_back(ctx, ok, sc->d_lab_ok, sc->n_labels));
     return OSMT_OK;
 }
 
@@ -843,8 +976,8 @@ int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_ma
 static int osmt_scene_read_points_body(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
     if (!ctx || !sc || !xy) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
-    if (sc->n_pts) HIP_TRY(hipMemcpy(xy, sc->d_pts, (size_t)sc->n_pts * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(scene_wait_idle(sc));
+    if (sc->n_pts) HIP_TRY(copy_back(ctx, xy, sc->d_pts, (size_t)sc->n_pts * 8));
     return OSMT_OK;
 }
 
@@ -927,6 +1060,7 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "pipelined readback failed: %s", hipGetErrorString(e));
         }
         if (s_k) (void)hipStreamSynchronize(s_k);
+        if (rc == OSMT_OK) rc = label_error_check(sc, s_k);
         if (s_c) {
             e = hipStreamSynchronize(s_c);
             if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "pipelined readback failed: %s", hipGetErrorString(e));
@@ -960,6 +1094,7 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
+    if (rc == OSMT_OK) rc = label_error_check(sc, st);
     osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d_out);
     stream_release(ctx, st);
@@ -1063,6 +1198,7 @@ static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, co
         }
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
+    if (rc == OSMT_OK) rc = label_error_check(sc, st);
     osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d);
     stream_release(ctx, st);
@@ -1098,17 +1234,21 @@ static int osmt_project_body(osmt_ctx* ctx, const double* latlon, size_t n, uint
     if (n >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "too many points");
     if (n == 0) return OSMT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    double* d_in = nullptr;
-    int32_t* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_in, n * 16));
-    hipError_t e = hipMalloc((void**)&d_out, n * 8);
-    if (e == hipSuccess) e = hipMemcpy(d_in, latlon, n * 16, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = osmt_launch_project_single(d_in, (uint32_t)n, zoom, tx, ty, scale, d_out, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(xy, d_out, n * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(OSMT_HIP_ERROR, "osmt_project: %s", hipGetErrorString(e));
+    /* device buffers from the per-context cache, the whole call on a pooled private stream: concurrent worker threads
+     * neither pay hipMalloc/hipFree per call nor wait for each other's work */
+    char* d = nullptr;
+    hipStream_t st = nullptr;
+    HIP_TRY(stream_acquire(ctx, &st));
+    const size_t in_bytes = align_up(n * 16, 256);
+    hipError_t e = dev_alloc(ctx, (void**)&d, in_bytes + n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, latlon, n * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = osmt_launch_project_single((const double*)d, (uint32_t)n, zoom, tx, ty, scale, (int32_t*)(d + in_bytes), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(xy, d + in_bytes, n * 8, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st); /* also on the error path: the buffer goes back to the cache */
+    if (e == hipSuccess) e = es;
+    dev_free(ctx, d);
+    stream_release(ctx, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "osmt_project: %s", hipGetErrorString(e));
     return OSMT_OK;
 }
 
@@ -1140,18 +1280,20 @@ static int osmt_composite_body(osmt_ctx* ctx, const double* planes, const double
     if (npx == 0) return OSMT_OK;
     if (!planes || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    void *d_in = nullptr, *d_out = nullptr;
-    const size_t in_bytes = npx * L * 32;
-    if (in_bytes) HIP_TRY(hipMalloc(&d_in, in_bytes));
-    hipError_t e = hipMalloc(&d_out, npx * 4);
-    if (e == hipSuccess && in_bytes) e = hipMemcpy(d_in, planes, in_bytes, hipMemcpyHostToDevice);
+    char* d = nullptr;
+    hipStream_t st = nullptr;
+    HIP_TRY(stream_acquire(ctx, &st));
+    const size_t in_bytes = align_up(npx * L * 32, 256);
+    hipError_t e = dev_alloc(ctx, (void**)&d, in_bytes + npx * 4);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(d, planes, npx * L * 32, hipMemcpyHostToDevice, st);
     int rc = OSMT_OK;
-    if (e == hipSuccess) rc = osmt_composite_device(ctx, d_in ? d_in : (void*)1, canvas, n, L, W, H, d_out, nullptr);
-    if (e == hipSuccess && rc == OSMT_OK) e = hipDeviceSynchronize();
-    if (e == hipSuccess && rc == OSMT_OK) e = hipMemcpy(out_rgba, d_out, npx * 4, hipMemcpyDeviceToHost);
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(OSMT_HIP_ERROR, "osmt_composite: %s", hipGetErrorString(e));
+    if (e == hipSuccess) rc = osmt_composite_device(ctx, d, canvas, n, L, W, H, d + in_bytes, st);
+    if (e == hipSuccess && rc == OSMT_OK) e = hipMemcpyAsync(out_rgba, d + in_bytes, npx * 4, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
+    dev_free(ctx, d);
+    stream_release(ctx, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "osmt_composite: %s", hipGetErrorString(e));
     return rc;
 }
 

@@ -444,6 +444,11 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
 hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
     if (a.n_labels == 0 || a.n_jobs == 0) return hipSuccess;
     const double4* segs = reinterpret_cast<const double4*>(a.segs);
+    /* verdicts and the error word start from zero on THIS stream, ordered before the kernels that set them (a clear
+     * issued at upload time on another stream could land after them) */
+    hipError_t ce = hipMemsetAsync(a.ok, 0, a.n_labels, st);
+    if (ce == hipSuccess) ce = hipMemsetAsync(a.err, 0, 4, st);
+    if (ce != hipSuccess) return ce;
     hipLaunchKernelGGL(k_label_cover, dim3(a.n_labels), dim3(64), 0, st, a.info, a.n_labels, segs, a.plane_a, a.err);
     if (a.n_wide)
         hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,

@@ -22,6 +22,7 @@ EXPORTS = [
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_scene_set_labels", "osmt_scene_read_label_status",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
+    "osmt_validate_batch",
 ]
 
 
@@ -51,6 +52,7 @@ def load():
     L.osmt_destroy.restype = None
     L.osmt_register_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.osmt_render_batch.argtypes = [vp, C.POINTER(abi.Batch), u8p, C.c_size_t]
+    L.osmt_validate_batch.argtypes = [C.POINTER(abi.Batch)]
     L.osmt_scene_upload.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(vp)]
     L.osmt_scene_free.argtypes = [vp]
     L.osmt_scene_free.restype = None

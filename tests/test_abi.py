@@ -81,3 +81,60 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_py" not in text and "liboracle" not in text and "osm_oracle" not in text, f
+
+
+def _validate(dl):
+    L = lib.load()
+    b = dl.as_batch()
+    rc = L.osmt_validate_batch(C.byref(b))
+    return rc, L.osmt_last_error().decode()
+
+
+def test_validate_batch_rejects_ops_no_job_covers():
+    """k_opinfo pre-processes EVERY op of the pool, so an op outside every job's range (or inside two) must not reach
+    the device: orphan ops, n_jobs == 0 with ops, overlapping op / point ranges, bad fields of an orphan op."""
+    import numpy as np
+
+    from osm_renderer_amd import synth
+
+    good = synth.config2(3)
+    assert _validate(good)[0] == abi.OK
+    # an orphan op between two jobs' ranges
+    dl = synth.config2(3)
+    dl.jobs["n_ops"][1] -= 1
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "not covered by any job" in msg
+    # no jobs at all, ops present
+    dl = synth.config2(2)
+    dl.jobs = dl.jobs[:0]
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "not covered by any job" in msg
+    # overlapping op ranges
+    dl = synth.config2(3)
+    dl.jobs["op_off"][2] -= 1
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "overlap" in msg
+    # overlapping point ranges (a shared point would be projected against the wrong tile)
+    dl = synth.config2(3)
+    dl.jobs["pt_off"][2] -= 4
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "point ranges" in msg
+    # an orphan op with a wild ring range is reported as orphan, a covered one as a ring error
+    dl = synth.config2(2)
+    dl.ops["ring_off"][5] = 10**7
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "ring range" in msg
+    # coordinates outside the Web-Mercator square / not finite
+    for bad in (np.nan, np.inf, 89.9, -90.0):
+        dl = synth.config2(1)
+        dl.coords[7, 0] = bad
+        rc, msg = _validate(dl)
+        assert rc == abi.UNSUPPORTED and "Web-Mercator" in msg, (bad, msg)
+    dl = synth.config2(1)
+    dl.coords[7, 1] = 181.0
+    assert _validate(dl)[0] == abi.UNSUPPORTED
+    # empty batches stay valid
+    dl = synth.config2(1)
+    dl.jobs = dl.jobs[:0]
+    dl.ops = dl.ops[:0]
+    assert _validate(dl)[0] == abi.OK
