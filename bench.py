@@ -1,23 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — tiles/sec of the MI355X tile hot path on BASELINE.json configs[1].
+"""bench.py — tiles/sec of the MI355X tile hot path (BASELINE.json), one JSON line on rank 0.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--total-tiles T]
 
-A "step" is one pass of the hot path (project -> per-op pre-pass -> fused
-fill/stroke/blend raster -> RGBA8 framebuffer) over one batch of 1024 synthetic
-z=15 256x256 tiles (50 polygons + 200 stroke segments each) PER GPU, display
-lists already resident in HBM, framebuffers written to HBM.  With N > 1 (launched
-by torch.distributed.run, one rank per GPU) tile i of the global batch belongs to
-rank i mod N (weak scaling: 1024 tiles per GPU), no data-path collective; one
-RCCL all-reduce of the tile count per step is the only communication.
+A "step" is one pass of the hot path (project -> per-op pre-pass -> fused fill/stroke/blend raster -> RGBA8
+framebuffer) over one batch of synthetic tiles, display lists already resident in HBM, framebuffers written to HBM.
 
-Rank 0 prints ONE JSON line with the whole-job tiles/s plus
-  roofline            the dominant kernel (k_raster): algorithmic bytes / kernel time vs 8 TB/s
-  roofline_composite  the 8-layer @2x composite pass (the kernel the >= 40 % HBM target is on)
-  cpu_baseline        the C++ oracle (restatement of the reference's Rust CPU path, NOT the
-                      Rust binary) on the host cores, bounded sample of the same workload
-  png_encode          SURVEY.md 8(f) N3: the framebuffers of the step turned into PNG files on the GPU
-  label_pass          SURVEY.md 8(f) N1: the same tiles with 24 synthetic labels per tile on top
+Headline (`value`): BASELINE configs[1] — 1024 z=15 256x256 tiles (50 polygons + 200 stroke segments each) PER GPU;
+with N > 1 (launched by torch.distributed.run, one rank per GPU) tile i of the global batch belongs to rank i mod N
+(weak scaling), no data-path collective, one RCCL all-reduce of the tile count per step.
+`--total-tiles T` switches the headline to STRONG scaling on a fixed global batch (configs[3]: T = 10000, tile i ->
+rank i mod N, x = 19000 + i mod 100, y = 10000 + i / 100; N = 1 renders the same T tiles).  The same 10000-tile
+strong-scaling batch is ALSO timed in every default run, at every N, as the `config4_strong` object, so a 1/2/4/8-GPU
+sweep of the default command carries the north_star's ">= 6x at 8 GPUs on the 10k-tile batch" numbers.
+
+Objects on the line (N = 1 unless said otherwise):
+  roofline            k_raster, the dominant kernel: algorithmic bytes / HIP-event kernel time vs 8 TB/s (+ measured copy ceiling)
+  roofline_issue      k_raster's real bound: VALU/SALU wave-instructions and VALU-busy cycles from an SQ counter pass of this run
+  roofline_composite  the 8-layer @2x composite pass (the kernel the >= 40 % HBM target is defined on)
+  hbm_copy_ceiling    a float4 device copy timed in this run (what "HBM speed" is on this box)
+  config4_strong      (every N) the 10000-tile z=15 batch sharded round-robin
+  raster_2x           configs[2] geometry: the same lists at @2x (512x512)
+  config5             configs[4]: dense city, 5000 polygons + 20000 segments per tile, z=17
+  sustained           >= 2 s of back-to-back steps (what the driver's GPU-busy sampler can see)
+  end_to_end          PCIe-inclusive: osmt_render_batch into pinned memory, osmt_render_batch_png
+  png_encode, label_pass  SURVEY.md 8(f) N3 / N1 on the same tiles
+  cpu_baseline        the C++ oracle (restatement of the reference's Rust CPU path, NOT the Rust binary) on the host
+                      cores: persistent worker pool (one canvas per worker, allocated before the timer), thread sweep
 """
 import argparse
 import json
@@ -30,24 +39,84 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 256 * 4       # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # max shader clock (same guide)
 
 
-def main():
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU per step")
+    ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU per step (weak scaling, the default headline)")
+    ap.add_argument("--total-tiles", type=int, default=0, help="strong scaling: a fixed global batch, tile i -> rank i mod N (configs[3]: 10000)")
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--composite-tiles", type=int, default=64)
     ap.add_argument("--n-poly", type=int, default=50, help="diagnostic: polygons per tile (default = the named config)")
     ap.add_argument("--n-line", type=int, default=40, help="diagnostic: polylines per tile (default = the named config)")
+    ap.add_argument("--config4-tiles", type=int, default=10000)
+    ap.add_argument("--config5-tiles", type=int, default=64)
+    ap.add_argument("--sustained-seconds", type=float, default=2.0)
+    ap.add_argument("--label-tiles", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     ap.add_argument("--no-labels", action="store_true")
     ap.add_argument("--no-png", action="store_true")
-    ap.add_argument("--label-tiles", type=int, default=1024)
-    args = ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (child processes)")
+    ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (no config4/5, 2x, sustained, end-to-end legs)")
+    ap.add_argument("--keep-pmc", default="", help="directory to keep the rocpd databases of the counter passes in")
+    ap.add_argument("--pmc-child", default="", help="internal: render a few steps of the named workload and exit (run under rocprofv3)")
+    return ap.parse_args()
+
+
+def pmc_child(name):
+    """Run under rocprofv3 by tools/pmc_pass.py: 1 warm-up + 3 steps of one workload, nothing else."""
+    import torch
+
+    from osm_renderer_amd import abi, synth
+    from osm_renderer_amd.renderer import Context
+
+    ctx = Context(0)
+    if name in ("composite", "all"):
+        planes = synth.composite_planes(64, L=8, dim=512, device=ctx.device)
+        cout = torch.empty((64, 512, 512, 4), dtype=torch.uint8, device=ctx.device)
+        for _ in range(4):
+            ctx.composite(planes, [0xFC / 255.0, 0xF8 / 255.0, 0xE4 / 255.0, 1.0], out=cout)
+        torch.cuda.synchronize()
+        del planes, cout
+        if name == "composite":
+            return
+    if name == "config5":
+        dl = synth.config5(16)
+    elif name == "raster_2x":
+        dl = synth.config3(256)
+    else:
+        dl = synth.config2(1024)
+    scene = ctx.upload(dl)
+    out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=ctx.device)
+    for _ in range(4):
+        ctx.render_stages(scene, abi.STAGE_PROJECT | abi.STAGE_OPINFO)
+        ctx.render_stages(scene, abi.STAGE_RASTER, out)
+    torch.cuda.synchronize()
+    scene.free()
+
+
+def main():
+    args = parse_args()
+    if args.pmc_child:
+        pmc_child(args.pmc_child)
+        return
 
     import numpy as np
     import torch
@@ -55,9 +124,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -67,87 +135,99 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from osm_renderer_amd import abi, synth
+    from osm_renderer_amd import abi, shard, synth
     from osm_renderer_amd.renderer import Context
 
     ctx = Context(local_rank)
     dev = ctx.device
-
-    # ---- workload: tile i of the global batch -> rank i mod world --------------------
-    global_tiles = synth.config_tiles(args.tiles * world)
-    mine = global_tiles[rank::world]
-    dl = synth.make_tiles(mine, zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
-    scene = ctx.upload(dl)
-    out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev)
+    solo = rank == 0 and world == 1
     count = torch.zeros(1, dtype=torch.int64, device=dev)
-    alg_bytes = dl.algorithmic_bytes()  # 16*N_pts + 64*N_ops + 8*N_dashes + 4*W*H per tile
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        ctx.render_stages(scene, abi.STAGE_PROJECT | abi.STAGE_OPINFO)
-        if i is not None:
-            ev[i][0].record()
-        ctx.render_stages(scene, abi.STAGE_RASTER, out)
-        if i is not None:
-            ev[i][1].record()
+    def sync_all():
+        torch.cuda.synchronize()
         if dist is not None:
-            count.fill_(dl.n_jobs)
-            dist.all_reduce(count)  # RCCL sum of tile counts (the path's only collective)
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def run_sharded(global_tiles_xy, zoom, scale, n_poly, n_line, steps, warmup, maker=None):
+        """Tile i of the global batch -> rank i mod N.  W untimed + K timed steps bracketed by barrier + synchronize on
+        both sides, MAX over ranks; returns the whole-job figures and this rank's objects."""
+        mine = global_tiles_xy[shard.shard_indices(len(global_tiles_xy), rank, world)]
+        dl = maker(mine) if maker else synth.make_tiles(mine, zoom=zoom, scale=scale, n_poly=n_poly, n_line=n_line)
+        scene = ctx.upload(dl)
+        out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        total_tiles_per_step = int(count.item())
-        assert total_tiles_per_step == args.tiles * world, (total_tiles_per_step, args.tiles, world)
+        def step(i=None):
+            ctx.render_stages(scene, abi.STAGE_PROJECT | abi.STAGE_OPINFO)
+            if i is not None:
+                ev[i][0].record()
+            ctx.render_stages(scene, abi.STAGE_RASTER, out)
+            if i is not None:
+                ev[i][1].record()
+            if dist is not None:
+                count.fill_(dl.n_jobs)
+                dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
+
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        total = dl.n_jobs
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            total = int(count.item())
+            assert total == len(global_tiles_xy), (total, len(global_tiles_xy))
+        raster_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        return {"elapsed": elapsed, "total_tiles": total, "raster_ms": raster_ms, "dl": dl, "scene": scene, "out": out, "step": step}
+
+    # ---- headline ----------------------------------------------------------------------------------
+    strong = args.total_tiles > 0
+    n_global = args.total_tiles if strong else args.tiles * world
+    head = run_sharded(synth.config_tiles(n_global), 15, args.scale, args.n_poly, args.n_line, args.steps, args.warmup)
+    dl, scene, out = head["dl"], head["scene"], head["out"]
+    alg_bytes = dl.algorithmic_bytes()  # SURVEY.md 8(d): 16*N_pts + 64*N_ops + 8*N_dashes + 4*W*H per tile
+    raster_s = head["raster_ms"] / 1e3
+    achieved = alg_bytes / raster_s / 1e9
+    named = args.n_poly == 50 and args.n_line == 40
+    if strong:
+        workload = (f"BASELINE.json configs[3]: fixed global batch of {n_global} z=15 {dl.dim}x{dl.dim} tiles (x = 19000 + i mod 100, "
+                    f"y = 10000 + i / 100), tile i -> rank i mod {world}, RCCL sum of tile counts per step; synthetic 50-poly/200-segment geometry")
     else:
-        total_tiles_per_step = dl.n_jobs
-
-    raster_ms = [a.elapsed_time(b) for a, b in ev]
-    raster_avg_s = sum(raster_ms) / len(raster_ms) / 1e3
-    achieved = alg_bytes / raster_avg_s / 1e9
-
+        workload = (f"BASELINE.json configs[1]: batch of {args.tiles} z=15 {dl.dim}x{dl.dim} tiles per GPU, synthetic 50-poly/200-segment "
+                    "geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input resident in HBM, RGBA8 framebuffers written to HBM")
     result = {
         "metric": "tiles/sec (256x256 z=15)",
-        "value": total_tiles_per_step * args.steps / elapsed,
+        "value": head["total_tiles"] * args.steps / head["elapsed"],
         "unit": "tiles/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": head["elapsed"] / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE.json configs[1]: batch of {args.tiles} z=15 {dl.dim}x{dl.dim} tiles per GPU, "
-            "synthetic 50-poly/200-segment geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input "
-            "resident in HBM, RGBA8 framebuffers written to HBM",
-            "tiles_per_gpu": args.tiles,
+            "workload": workload,
+            "tiles_per_step_all_gpus": head["total_tiles"],
+            "tiles_this_rank": dl.n_jobs,
             "polygons_per_tile": args.n_poly,
             "polylines_per_tile": args.n_line,
             "scale": args.scale,
+            "named_config": bool(named),
             "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
         },
         "roofline": {
-            "kernel": "k_raster (fused fill/stroke/blend/to_rgb; LDS/ALU-bound by construction, see DESIGN.md)",
+            "kernel": "k_raster (fused fill/stroke/blend/to_rgb) — instruction-issue bound by construction, see roofline_issue; "
+                      "the HBM fraction is reported because the metric asks for it, it is not this kernel's ceiling",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -155,12 +235,117 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "avg_launch_ms": raster_avg_s * 1e3,
+            "avg_launch_ms": raster_s * 1e3,
+            "timing": "HIP events around the raster stage on the launch stream, averaged over the timed steps",
         },
     }
 
+    # ---- configs[3]: the 10000-tile strong-scaling batch, at every N ---------------------------------
+    if not args.no_extra and not strong and args.config4_tiles > 0:
+        c4 = run_sharded(synth.config_tiles(args.config4_tiles), 15, 1, 50, 40, steps=max(3, min(args.steps, 10)), warmup=2)
+        k4 = max(3, min(args.steps, 10))
+        result["config4_strong"] = {
+            "workload": f"BASELINE.json configs[3]: {args.config4_tiles} z=15 tiles, tile i -> rank i mod {world} "
+                        "(x = 19000 + i mod 100, y = 10000 + i / 100), RCCL sum of tile counts per step",
+            "value": c4["total_tiles"] * k4 / c4["elapsed"], "unit": "tiles/s", "scaling": "strong", "n_gpus": world,
+            "steps": k4, "ms_per_step": c4["elapsed"] / k4 * 1e3, "tiles_this_rank": c4["dl"].n_jobs,
+            "raster_ms_this_rank": c4["raster_ms"],
+        }
+        c4["scene"].free()
+        del c4
+
+    if solo and not args.no_extra:
+        # ---- measured HBM copy ceiling (float4 device copy, 1 GiB in + 1 GiB out) -------------------
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9
+            result["hbm_copy_ceiling"] = {
+                "value": copy_gbs, "unit": "GB/s", "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
+                "how": "torch vectorised (16 B/lane) elementwise device copy, 1 GiB read + 1 GiB written per launch, 20 launches, HIP events",
+            }
+            result["roofline"]["frac_of_copy_ceiling"] = achieved / copy_gbs
+            del src, dst
+        except Exception as e:  # noqa: BLE001
+            result["hbm_copy_ceiling"] = {"error": str(e)}
+
+        # ---- sustained: >= 2 s of back-to-back steps ---------------------------------------------------
+        n_sus = max(10, int(args.sustained_seconds / max(head["elapsed"] / args.steps, 1e-5)) + 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            head["step"]()
+        torch.cuda.synchronize()
+        t_sus = time.perf_counter() - t0
+        result["sustained"] = {"steps": n_sus, "seconds": t_sus, "tiles_per_s": n_sus * dl.n_jobs / t_sus, "ms_per_step": t_sus / n_sus * 1e3}
+
+        # ---- configs[2] geometry: the same display lists at @2x --------------------------------------
+        r2 = run_sharded(synth.config_tiles(256), 15, 2, 50, 40, steps=10, warmup=2)
+        b2 = r2["dl"].algorithmic_bytes()
+        result["raster_2x"] = {
+            "workload": "BASELINE.json configs[2] geometry: 256 z=15 tiles at @2x (512x512), same 50-poly/200-segment lists",
+            "tiles_per_s": 256 * 10 / r2["elapsed"], "ms_per_step": r2["elapsed"] / 10 * 1e3, "k_raster_ms": r2["raster_ms"],
+            "algorithmic_bytes_per_launch": b2, "achieved": b2 / (r2["raster_ms"] / 1e3) / 1e9, "unit": "GB/s",
+            "frac": b2 / (r2["raster_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+        }
+        r2["scene"].free()
+        del r2
+
+        # ---- configs[4]: dense city -------------------------------------------------------------------
+        n5 = args.config5_tiles
+        if n5 > 0:
+            r5 = run_sharded(synth.config_tiles(n5, x0=79000, y0=40000), 17, 1, 5000, 4000, steps=5, warmup=1,
+                             maker=lambda xy: synth.make_tiles(xy, zoom=17, scale=1, n_poly=5000, n_line=4000, radius=(2.0, 12.0), step=12.0))
+            b5 = r5["dl"].algorithmic_bytes()
+            result["config5"] = {
+                "workload": f"BASELINE.json configs[4]: dense city, {n5} z=17 tiles, 5000 polygons + 4000 polylines (20000 segments) per tile",
+                "tiles_per_s": n5 * 5 / r5["elapsed"], "ms_per_step": r5["elapsed"] / 5 * 1e3, "k_raster_ms": r5["raster_ms"],
+                "ops_per_tile": 9000, "algorithmic_bytes_per_tile": b5 / n5, "algorithmic_bytes_per_launch": b5,
+                "achieved": b5 / (r5["raster_ms"] / 1e3) / 1e9, "unit": "GB/s", "frac": b5 / (r5["raster_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+            }
+            r5["scene"].free()
+            del r5
+
+        # ---- end to end through the host-buffer ABI (upload + kernels + readback per call) -----------
+        try:
+            pin = ctx.host_alloc((dl.n_jobs, dl.dim, dl.dim, 4))
+            ctx.render_batch_host(dl, out=pin)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.render_batch_host(dl, out=pin)
+                ts.append(time.perf_counter() - t0)
+            raw_s = min(ts)
+            pbuf = ctx.host_alloc((dl.n_jobs * 96 * 1024,))
+            _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
+                ts.append(time.perf_counter() - t0)
+            png_s = min(ts)
+            result["end_to_end"] = {
+                "what": "wall clock around one osmt_render_batch / osmt_render_batch_png call (validation + H2D of the display lists + all "
+                        "kernels + D2H into pinned host memory), best of 3; never `value`",
+                "tiles": dl.n_jobs,
+                "raw_rgba8_pinned_tiles_per_s": dl.n_jobs / raw_s, "raw_rgba8_ms": raw_s * 1e3,
+                "png_files_pinned_tiles_per_s": dl.n_jobs / png_s, "png_ms": png_s * 1e3, "png_bytes_per_tile": float(off[-1]) / dl.n_jobs,
+            }
+            ctx.host_free(pin)
+            ctx.host_free(pbuf)
+        except Exception as e:  # noqa: BLE001
+            result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- composite pass (configs[2]: @2x 512x512, 8 layers) — rank 0, N = 1 only ------
-    if rank == 0 and world == 1 and not args.no_composite:
+    if solo and not args.no_composite:
         n, L, dim = args.composite_tiles, 8, 512
         planes = synth.composite_planes(n, L=L, dim=dim, device=dev)
         cout = torch.empty((n, dim, dim, 4), dtype=torch.uint8, device=dev)
@@ -175,7 +360,7 @@ def main():
             b.record()
         torch.cuda.synchronize()
         c_s = sum(a.elapsed_time(b) for a, b in cev) / reps / 1e3
-        c_bytes = n * (L * dim * dim * 32 + dim * dim * 4)  # B_comp, SURVEY.md §8(d)
+        c_bytes = n * (L * dim * dim * 32 + dim * dim * 4)  # B_comp, SURVEY.md 8(d)
         result["roofline_composite"] = {
             "kernel": "k_composite<8> (8-layer premultiplied f64 over + to_rgb, 512x512)",
             "bound": "hbm",
@@ -189,10 +374,12 @@ def main():
             "tiles_per_s": n / c_s,
             "tiles_per_launch": n,
         }
+        if "hbm_copy_ceiling" in result and "value" in result["hbm_copy_ceiling"]:
+            result["roofline_composite"]["frac_of_copy_ceiling"] = c_bytes / c_s / 1e9 / result["hbm_copy_ceiling"]["value"]
         del planes, cout
 
     # ---- PNG files written by the GPU from the framebuffers of the timed steps — rank 0, N = 1 only ----
-    if rank == 0 and world == 1 and not args.no_png:
+    if solo and not args.no_png:
         slots, lens = ctx.encode_png_device(out)
         torch.cuda.synchronize()
         reps = 10
@@ -206,7 +393,7 @@ def main():
         png_bytes = int(lens.sum().item())
         p_alg = out.numel() + png_bytes  # RGBA8 read once + files written once
         result["png_encode"] = {
-            "kernel": "k_png_encode_fast (Paeth + fixed-Huffman run-length deflate + Adler-32/CRC-32, one workgroup per tile)",
+            "kernel": "k_png_encode (Paeth + deflate + Adler-32/CRC-32 on the device, one workgroup per tile)",
             "tiles": int(out.shape[0]),
             "avg_launch_ms": p_s * 1e3,
             "tiles_per_s": out.shape[0] / p_s,
@@ -218,7 +405,7 @@ def main():
         del slots, lens
 
     # ---- label pass on top of the same area workload — rank 0, N = 1 only ----
-    if rank == 0 and world == 1 and not args.no_labels:
+    if solo and not args.no_labels:
         from osm_renderer_amd import labels as labels_mod
 
         n = args.label_tiles
@@ -274,6 +461,9 @@ def main():
             nt = min(16, os.cpu_count() or 1)
             n_cpu = min(n, 256)  # enough work for the difference of the two timings to stand clear of the noise
             sub_dl, sub_ll = ldl.subset(range(n_cpu)), ll.subset(range(n_cpu))
+            lpool = oracle_py.Pool(nt, args.scale)
+            lbuf = np.empty((n_cpu, ldl.dim, ldl.dim, 4), dtype=np.uint8)
+            lstat = np.zeros(len(sub_ll.labels), dtype=np.uint8)
 
             def best(fn, reps=3):
                 ts = []
@@ -283,79 +473,125 @@ def main():
                     ts.append(time.perf_counter() - t0)
                 return min(ts)
 
-            t_plain = best(lambda: oracle_py.render_batch(sub_dl, threads=nt))
-            t_lab = best(lambda: oracle_py.render_batch(sub_dl, threads=nt, labels=sub_ll))
+            t_plain = best(lambda: lpool.render(sub_dl, lbuf))
+            t_lab = best(lambda: lpool.render(sub_dl, lbuf, labels=sub_ll, status=lstat))
+            lpool.close()
             cpu_s = max(t_lab - t_plain, 1e-9)
             result["label_pass"]["cpu_baseline"] = {
                 "value": len(sub_ll.labels) / cpu_s, "unit": "labels/s", "cores": nt, "kind": "port",
-                "sample": f"{n_cpu} tiles, {len(sub_ll.labels)} labels: oracle render with labels ({t_lab:.3f} s) minus "
+                "sample": f"{n_cpu} tiles, {len(sub_ll.labels)} labels: pooled oracle render with labels ({t_lab:.3f} s) minus "
                           f"without ({t_plain:.3f} s), best of 3 each",
             }
         lscene.free()
         del lout
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N = 1 only) ---------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         from oracle import oracle_py
 
+        oracle_py.build()
         cores = os.cpu_count() or 1
+        # Persistent worker pool = the reference's server: one TilePixels per worker, created at start-up
+        # (http_server.rs:69-72), tiles dealt round-robin (:105-108).  Pool, canvases and the output array exist
+        # BEFORE the timer starts.  Thread sweep: the path rewrites a 47 MB canvas per tile, so it can turn
+        # memory-bound before all cores are used; every point of the sweep is reported.
         probe = dl.subset(range(min(8, dl.n_jobs)))
+        p1 = oracle_py.Pool(1, args.scale)
+        pbuf = np.empty((probe.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
+        p1.render(probe, pbuf)
         t = time.perf_counter()
-        oracle_py.render_batch(probe, threads=1)
+        p1.render(probe, pbuf)
         per_tile = (time.perf_counter() - t) / probe.n_jobs
-        # bounded sample (~10-30 s of CPU work in total): at least 8 tiles per thread so the per-thread
-        # canvas allocation is amortised, at most 4096 tiles; tiles beyond the step's own batch continue
-        # the same generator.  The reference's path is memory-bound (a 47 MB canvas is rewritten per
-        # tile), so more threads is not always faster: a few thread counts are timed, the best is reported.
-        tried = {}
-        cpu_out = None
-        n_sample = 0
-        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}):
-            n_th = int(min(8192, 32 * th))  # 32 tiles per thread: steady state, not canvas allocation
-            sample = synth.make_tiles(synth.config_tiles(n_th * world)[rank::world], zoom=15, scale=args.scale,
-                                      n_poly=args.n_poly, n_line=args.n_line)
+        p1.close()
+        tried, cpu_out, n_first = {}, None, 0
+        budget_s = 3.0  # per sweep point; ~6 points -> ~20 s of wall clock
+        for th in sorted({1, max(1, cores // 16), max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
+            n_th = int(min(8192, max(2 * th, min(64 * th, budget_s * th / per_tile))))
+            sample = synth.make_tiles(synth.config_tiles(n_th), zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
+            pool_t = oracle_py.Pool(th, args.scale)
+            buf = np.empty((n_th, dl.dim, dl.dim, 4), dtype=np.uint8)
+            buf[:] = 0  # touch the pages before the timer
             t = time.perf_counter()
-            o = oracle_py.render_batch(sample, threads=th)
-            tried[th] = n_th / (time.perf_counter() - t)
+            pool_t.render(sample, buf)
+            dt = time.perf_counter() - t
+            tried[th] = {"tiles": n_th, "seconds": dt, "tiles_per_s": n_th / dt}
+            pool_t.close()
             if cpu_out is None:
-                cpu_out, n_sample = o, n_th
-        best_threads = max(tried, key=tried.get)
-        cpu_s = 1.0 / tried[best_threads]  # seconds per tile at the best thread count
-        n_cmp = min(n_sample, dl.n_jobs)
-        cpu_out = cpu_out[:n_cmp]
-        n_sample_cmp = n_cmp
-        gpu_out = out[:n_sample_cmp].cpu().numpy()
+                cpu_out, n_first = buf.copy(), n_th
+            del buf
+        best_threads = max(tried, key=lambda k: tried[k]["tiles_per_s"])
+        n_cmp = min(n_first, dl.n_jobs) if not strong and world == 1 else 0
+        match = bool(np.array_equal(out[:n_cmp].cpu().numpy(), cpu_out[:n_cmp])) if n_cmp else None
         result["cpu_baseline"] = {
-            "value": 1.0 / cpu_s,
+            "value": tried[best_threads]["tiles_per_s"],
             "unit": "tiles/s",
             "cores": best_threads,
             "host_logical_cpus": cores,
-            "tiles_per_s_by_threads": {str(k): v for k, v in tried.items()},
+            "cpu_model": cpu_model(),
+            "sweep": {str(k): v for k, v in tried.items()},
             "kind": "port",
-            "sample": f"32 tiles per thread (max 8192) of the same workload (the batch's own tiles first), C++ oracle (restatement of the reference's Rust "
-            f"CPU path incl. its 3x3-tile canvas), best of {sorted(tried)} threads, one canvas per thread, tiles round-robin; "
-            f"single-thread probe {1.0 / per_tile:.1f} tiles/s",
+            "sample": "per sweep point ~3 s of the same workload (the batch's own tiles first): C++ oracle = restatement of the reference's "
+                      "Rust CPU path incl. its 3x3-tile canvas, NOT the Rust binary; persistent pool, one canvas per worker allocated before "
+                      "the timer, output pre-allocated, tiles round-robin; best point reported as value",
             "single_thread_tiles_per_s": 1.0 / per_tile,
-            "gpu_matches_oracle_on_sample": bool(np.array_equal(gpu_out, cpu_out)),
+            "gpu_matches_oracle_on_sample": match,
         }
 
-    # HBM bytes per launch from the PMC counters cannot be read in-process: they are collected by
-    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command and
-    # committed as profiles/r01_hbm_traffic.json (with the gfx950 FETCH_SIZE correction noted there).
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            tr = json.load(f)
-        if args.tiles == 1024 and args.scale == 1 and args.n_poly == 50 and args.n_line == 40:
-            result["roofline"]["traffic"] = tr["k_raster"]["traffic_bytes_per_launch_fetch_x2"]
-            result["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC pass of an earlier run of this command"
-        if "png_encode" in result and "k_png_encode_fast" in tr and args.tiles == 1024 and args.scale == 1:
-            result["png_encode"]["traffic"] = tr["k_png_encode_fast"]["traffic_bytes_per_launch_fetch_x2"]
-        if "label_pass" in result and "k_label_cover" in tr and args.label_tiles == 1024 and args.scale == 1:
-            result["label_pass"]["traffic_k_label_cover"] = tr["k_label_cover"]["traffic_bytes_per_launch_fetch_x2"]
-        if "roofline_composite" in result and args.composite_tiles == 64:
-            result["roofline_composite"]["traffic"] = tr["k_composite"]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # ---- counters of THIS run: child rocprofv3 passes over the same step (N = 1 only) ------------------
+    if solo and not args.no_pmc and named and args.tiles == 1024 and args.scale == 1 and not strong:
+        from tools import pmc_pass
+
+        keep = args.keep_pmc or None
+        pm = {"how": "child processes: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --pmc-child all (4 composite launches, then 4 config-2 steps), "
+                     "per-dispatch averages; FETCH_SIZE / WRITE_SIZE in separate passes, unit KB; FETCH_SIZE x2 = the gfx950 correction "
+                     "of MI355X_MICROARCH.md for wide coalesced reads (uncalibrated for k_raster's small scattered reads: both given)"}
+        child = ["all" if "roofline_composite" in result else "config2"]
+        sq = pmc_pass.run_pass(pmc_pass.SQ_PASS_1, child, keep_dir=keep)
+        hit = pmc_pass.pick(sq, "k_raster") if "error" not in sq else None
+        if hit:
+            v = hit[1]
+            valu, salu = v.get("SQ_INSTS_VALU", 0.0), v.get("SQ_INSTS_SALU", 0.0)
+            act = v.get("SQ_ACTIVE_INST_VALU", 0.0)  # quad-cycles summed over waves
+            busy_ms = act * 4.0 / N_SIMD / CLOCK_HZ * 1e3
+            floor4 = valu * 4.0 / N_SIMD / CLOCK_HZ * 1e3
+            result["roofline_issue"] = {
+                "kernel": "k_raster", "bound": "valu-issue",
+                "valu_wave_instr": valu, "salu_wave_instr": salu,
+                "valu_busy_quad_cycles": act, "wave_quad_cycles": v.get("SQ_WAVE_CYCLES"), "wait_any_quad_cycles": v.get("SQ_WAIT_ANY"),
+                "wait_inst_any_quad_cycles": v.get("SQ_WAIT_INST_ANY"), "busy_cycles": v.get("SQ_BUSY_CYCLES"),
+                "floor_ms": busy_ms,
+                "floor_ms_at_4_cycles_per_valu": floor4,
+                "floor_ms_at_2_cycles_per_valu": floor4 / 2.0,
+                "measured_ms": raster_s * 1e3, "profiled_ms": v.get("avg_us", 0.0) / 1e3,
+                "frac": busy_ms / (raster_s * 1e3) if raster_s > 0 else None,
+                "note": "floor_ms = SQ_ACTIVE_INST_VALU (quad-cycles the SIMDs spent issuing VALU) x 4 / (1024 SIMDs x 2.4 GHz): the time "
+                        "the kernel's own VALU stream needs with perfect overlap of everything else; frac = floor_ms / HIP-event kernel time. "
+                        "f64 VALU issues at 4 cycles per wave-instruction (16 lanes/cycle), f32/int at 2; both uniform-rate floors are given too",
+            }
+        else:
+            result["roofline_issue"] = {"error": sq.get("error", "k_raster not found in the SQ pass")}
+        fe = pmc_pass.run_pass(["FETCH_SIZE"], child, keep_dir=keep)
+        wr = pmc_pass.run_pass(["WRITE_SIZE"], child, keep_dir=keep)
+        hf = pmc_pass.pick(fe, "k_raster") if "error" not in fe else None
+        hw = pmc_pass.pick(wr, "k_raster") if "error" not in wr else None
+        if hf and hw and "FETCH_SIZE" in hf[1] and "WRITE_SIZE" in hw[1]:
+            f_b, w_b = hf[1]["FETCH_SIZE"] * 1024.0, hw[1]["WRITE_SIZE"] * 1024.0
+            result["roofline"]["traffic"] = f_b * 2.0 + w_b
+            result["roofline"]["traffic_raw_fetch"] = f_b + w_b
+            result["roofline"]["traffic_note"] = "bytes per launch measured in THIS run (child rocprofv3 passes): 2 x FETCH_SIZE + WRITE_SIZE"
+            pm["all_kernels"] = {k: {"fetch_kb": fe.get(k, {}).get("FETCH_SIZE"), "write_kb": wr.get(k, {}).get("WRITE_SIZE"),
+                                     "avg_us": fe.get(k, {}).get("avg_us")} for k in fe if "osmt" in k or "k_" in k}
+        else:
+            result["roofline"]["traffic_note"] = "counter pass failed: " + str(fe.get("error") or wr.get("error") or "k_raster not found")
+        if "roofline_composite" in result:
+            hfc = pmc_pass.pick(fe, "k_composite") if "error" not in fe else None
+            hwc = pmc_pass.pick(wr, "k_composite") if "error" not in wr else None
+            if hfc and hwc and "FETCH_SIZE" in hfc[1] and "WRITE_SIZE" in hwc[1]:
+                result["roofline_composite"]["traffic"] = hfc[1]["FETCH_SIZE"] * 2048.0 + hwc[1]["WRITE_SIZE"] * 1024.0
+                result["roofline_composite"]["traffic_note"] = "measured in THIS run: 2 x FETCH_SIZE + WRITE_SIZE (wide coalesced 16 B/lane stream)"
+        result["pmc"] = pm
+    elif solo and not args.no_pmc:
+        result["roofline"]["traffic_note"] = "counter passes only run for the named config (1024 tiles, scale 1, weak mode)"
 
     if rank == 0:
         print(json.dumps(result))

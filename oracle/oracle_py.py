@@ -73,6 +73,13 @@ def lib():
             C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), C.c_size_t, C.c_size_t, C.POINTER(Icon), C.c_size_t, u8p,
             C.c_size_t, C.c_int, u8p,
         ]
+        L.orc_pool_create.restype = C.c_void_p
+        L.orc_pool_create.argtypes = [C.c_int, C.c_uint32]
+        L.orc_pool_free.argtypes = [C.c_void_p]
+        L.orc_pool_render.argtypes = [
+            C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), C.c_size_t, C.c_size_t, C.POINTER(Icon), C.c_size_t,
+            u8p, C.c_size_t, u8p,
+        ]
         L.orc_rasterizer_pixels.argtypes = [dp, C.c_size_t, ip, dp, C.c_size_t]
         L.orc_rasterizer_pixels.restype = C.c_size_t
         L.orc_flatten_quad.argtypes = [dp, dp, C.c_size_t]
@@ -260,6 +267,35 @@ def render_batch(dl, first=0, count=None, images=(), threads=1, labels=None, wan
                                        dl.dim * dl.dim * 4, threads, _u8p(status) if len(status) else None)
     assert rc == 0
     return (out, status) if want_status else out
+
+
+class Pool:
+    """Persistent worker pool of the oracle: `threads` TilePixels allocated once, like the reference's server
+    (http_server.rs:69-72).  render() writes into a caller-provided array and allocates nothing."""
+
+    def __init__(self, threads, scale=1):
+        self.threads = int(threads)
+        self.scale = int(scale)
+        self._p = lib().orc_pool_create(self.threads, self.scale)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().orc_pool_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
+
+    def render(self, dl, out, first=0, count=None, labels=None, status=None, images=()):
+        count = dl.n_jobs - first if count is None else count
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.shape[0] >= count
+        b = dl.as_batch()
+        arr, n, keep = make_icons(list(images))
+        lb = labels.as_batch() if labels is not None else None
+        rc = lib().orc_pool_render(self._p, C.byref(b), C.byref(lb) if lb is not None else None, first, count, arr, n,
+                                   _u8p(out), dl.dim * dl.dim * 4, _u8p(status) if status is not None else None)
+        assert rc == 0, rc
+        return out
 
 
 def rasterizer_pixels(segs):

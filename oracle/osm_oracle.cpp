@@ -1027,6 +1027,56 @@ int orc_render_batch_labels(const osmt_batch* batch, const osmt_label_batch* lab
     return 0;
 }
 
+/* A persistent worker pool: `threads` TilePixels allocated ONCE, like the reference's server, which builds one
+ * TilePixels per worker thread at start-up (http_server.rs:69-72) and reuses it for every request.  The cpu_baseline
+ * leg of bench.py creates the pool (and the output array) before its timer starts. */
+struct orc_pool {
+    std::vector<orc_pixels*> px;
+};
+
+orc_pool* orc_pool_create(int threads, uint32_t scale) {
+    if (threads < 1) threads = 1;
+    orc_pool* p = new orc_pool();
+    p->px.assign((size_t)threads, nullptr);
+    /* each worker builds (and first-touches) its own canvas, as the server's worker threads do */
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back([p, t, scale] { p->px[(size_t)t] = new orc_pixels(scale); });
+    for (auto& t : th) t.join();
+    return p;
+}
+
+void orc_pool_free(orc_pool* p) {
+    if (!p) return;
+    for (orc_pixels* q : p->px) delete q;
+    delete p;
+}
+
+int orc_pool_threads(const orc_pool* p) { return p ? (int)p->px.size() : 0; }
+
+int orc_pool_render(orc_pool* pool, const osmt_batch* batch, const osmt_label_batch* labels, size_t first, size_t count,
+                    const orc_icon* icons, size_t n_icons, uint8_t* out_rgba, size_t out_tile_stride, uint8_t* out_status) {
+    if (!pool || !batch || first + count > batch->n_jobs) return -1;
+    const int threads = (int)pool->px.size();
+    for (orc_pixels* q : pool->px)
+        if (q->scaled_tile_size != (size_t)TILE_SIZE * batch->scale) return -2;
+    auto worker = [&](int tid) {
+        orc_pixels& px = *pool->px[(size_t)tid];
+        for (size_t i = (size_t)tid; i < count; i += (size_t)threads) { /* tiles dealt round-robin (http_server.rs:105-108) */
+            render_job_into(batch, first + i, icons, n_icons, px);
+            label_job_into(labels, first + i, icons, n_icons, px, out_status);
+            px.to_rgb(out_rgba + i * out_tile_stride, true);
+        }
+    };
+    if (threads == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t) th.emplace_back(worker, t);
+        for (auto& t : th) t.join();
+    }
+    return 0;
+}
+
 void orc_job_points(const osmt_batch* batch, size_t job_idx, int32_t* xy) {
     const osmt_tile_job& job = batch->jobs[job_idx];
     for (uint32_t i = 0; i < job.n_pts; ++i) {

@@ -77,6 +77,14 @@ int orc_render_job_labels(const osmt_batch* batch, const osmt_label_batch* label
 int orc_render_batch_labels(const osmt_batch* batch, const osmt_label_batch* labels, size_t first, size_t count,
                             const orc_icon* icons, size_t n_icons, uint8_t* out_rgba, size_t out_tile_stride, int threads,
                             uint8_t* out_status);
+/* Persistent worker pool: one TilePixels per worker allocated once (http_server.rs:69-72), tiles dealt round-robin
+ * (:105-108); orc_pool_render allocates nothing.  Returns 0, -1 (bad range) or -2 (pool scale != batch scale). */
+typedef struct orc_pool orc_pool;
+orc_pool* orc_pool_create(int threads, uint32_t scale);
+void orc_pool_free(orc_pool* pool);
+int orc_pool_threads(const orc_pool* pool);
+int orc_pool_render(orc_pool* pool, const osmt_batch* batch, const osmt_label_batch* labels, size_t first, size_t count,
+                    const orc_icon* icons, size_t n_icons, uint8_t* out_rgba, size_t out_tile_stride, uint8_t* out_status);
 /* font/rasterizer.rs:27-88 + :115-147 on a fresh Rasterizer: the (x, y, total) triples save_to_figure would pass
  * to set_label_pixel, in its order.  Returns the count (may exceed cap; only cap are written). */
 size_t orc_rasterizer_pixels(const double* segs, size_t n_segs, int32_t* out_xy, double* out_total, size_t cap);

@@ -30,7 +30,14 @@ def _worker(rank, world, port, n_tiles, q):
     dl = synth.make_tiles(tiles[idx])
     out = oracle_py.render_batch(dl)
     total = shard.reduce_tile_count(dl.n_jobs, dist)
-    q.put((rank, idx.tolist(), total, [int(o.astype(np.uint64).sum()) for o in out]))
+    # BASELINE configs[3]: the 10000-tile batch, tile i -> rank i mod world (bench.py --total-tiles 10000 and the
+    # config4_strong leg use exactly these two functions); nothing is rendered here, only the partition is checked
+    big = synth.config_tiles(10000)
+    big_idx = shard.shard_indices(10000, rank, world)
+    big_total = shard.reduce_tile_count(len(big_idx), dist)
+    big_xy = big[big_idx]
+    q.put((rank, idx.tolist(), total, [int(o.astype(np.uint64).sum()) for o in out],
+           (big_total, len(big_idx), int(big_idx[0]), int(big_idx[-1]), big_xy[:2].tolist(), int(big_xy[:, 0].astype(np.int64).sum()))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +58,12 @@ def test_two_rank_sharding_covers_the_batch(oracle):
         assert p.exitcode == 0
     full = oracle.render_batch(synth.config2(n_tiles))
     seen = {}
-    for rank, idx, total, sums in res:
+    xsum = 0
+    for rank, idx, total, sums, big in res:
+        big_total, n_mine, first, last, xy2, xs = big
+        assert big_total == 10000 and n_mine == 5000 and first == rank and last == 9998 + rank
+        assert xy2 == [[19000 + rank, 10000], [19000 + rank + 2, 10000]]  # x = 19000 + i mod 100, y = 10000 + i / 100
+        xsum += xs
         assert total == n_tiles  # all-reduce(sum) of the per-rank counts
         assert idx == list(range(rank, n_tiles, world))
         for i, s in zip(idx, sums):
@@ -59,3 +71,4 @@ def test_two_rank_sharding_covers_the_batch(oracle):
     assert sorted(seen) == list(range(n_tiles))
     for i in range(n_tiles):
         assert seen[i] == int(full[i].astype(np.uint64).sum())
+    assert xsum == int(synth.config_tiles(10000)[:, 0].sum())  # the two shards tile the 10000-tile batch exactly

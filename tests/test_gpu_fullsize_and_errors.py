@@ -120,3 +120,102 @@ def test_pinned_output_takes_the_overlapped_chunk_pipeline(gpu_ctx, oracle):
         assert np.array_equal(c[idx], want)
     finally:
         gpu_ctx.host_free(pin)
+
+
+def test_config5_dense_city_at_stated_density(gpu_ctx, oracle):
+    """BASELINE configs[4] as stated: 5000 polygons + 4000 polylines (20000 segments) per z=17 tile.  Two tiles
+    bit-exact (RGBA8 and f64 canvas) against the oracle, determinism and permutation equivariance on 16 tiles, and
+    one tile whose dense multipolygon puts > 16 crossings on a row (the overflow path of the fill)."""
+    import torch
+
+    from osm_renderer_amd.display_list import TileBuilder, concat
+    from tests._parity import assert_parity
+
+    dl = synth.config5(16)
+    assert int(dl.jobs["n_ops"][0]) == 9000 and int(dl.jobs["n_pts"][0]) == 5000 * 9 + 4000 * 6
+    scene = gpu_ctx.upload(dl)
+    a = gpu_ctx.render(scene)
+    b = gpu_ctx.render(scene)
+    assert torch.equal(a, b)
+    a = a.cpu().numpy()
+    scene.free()
+    pick = [3, 12]
+    assert_parity(gpu_ctx, oracle, dl.subset(pick), msg="config5")  # RGBA8 + f64 canvas, rendered alone
+    want = oracle.render_batch(dl.subset(pick), threads=2)
+    np.testing.assert_array_equal(a[pick], want)  # ... and inside the 16-tile batch
+    perm = np.random.default_rng(5).permutation(16)
+    permuted = gpu_ctx.render_batch_host(dl.subset(perm.tolist()))
+    np.testing.assert_array_equal(permuted, a[perm])
+    # a config-5 tile followed by a comb multipolygon (160 crossings per row inside one 32-px column band)
+    tb = TileBuilder(zoom=17, x=79001, y=40001, scale=1, canvas=synth.CANVAS_OSMOSNIMKI)
+    rnd = np.random.default_rng(17)
+    for _ in range(300):
+        c = rnd.integers(0, 256, size=2)
+        r = rnd.integers(2, 12, size=8)
+        ang = 2 * np.pi * np.arange(8) / 8
+        ring = [(int(c[0] + r[k] * np.cos(ang[k])), int(c[1] + r[k] * np.sin(ang[k]))) for k in range(8)]
+        tb.fill(ring + ring[:1], tuple(int(v) for v in rnd.integers(0, 256, size=3)), float(rnd.choice([1.0, 0.7, 0.5])))
+    dense = []
+    for i in range(80):
+        x = 96 + (i * 31) % 32
+        dense += [(x, 20 + (i % 7)), (x + (i % 3) - 1, 230 - (i % 11))]
+    dense.append(dense[0])
+    hole = [(100, 60), (120, 60), (120, 180), (100, 180), (100, 60)]
+    tb.fill([dense, hole], (200, 10, 10), 0.6)
+    for _ in range(300):
+        p = rnd.integers(-8, 264, size=2).astype(np.int64)
+        pts = [tuple(int(v) for v in p)]
+        for _ in range(5):
+            p = p + rnd.integers(-12, 13, size=2)
+            pts.append(tuple(int(v) for v in p))
+        tb.stroke(pts, float(rnd.choice([0.5, 1.0, 2.0, 4.0])), tuple(int(v) for v in rnd.integers(0, 256, size=3)), 0.6,
+                  dashes=[3.0, 3.0] if rnd.random() < 0.25 else None, cap=int(rnd.choice([abi.CAP_NONE, abi.CAP_ROUND, abi.CAP_SQUARE])))
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="dense tile with a comb multipolygon")
+
+
+def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx):
+    """osmt_scene_set_labels / osmt_scene_read_label_status / osmt_scene_free of one worker's scene wait for THAT
+    scene's launches only (events), not for the device: while one thread keeps a long queue of renders in flight
+    on its stream, another thread's label round trips on a small scene finish long before that queue drains."""
+    import threading
+    import time
+
+    import torch
+
+    from osm_renderer_amd import labels
+
+    big = gpu_ctx.upload(synth.config2(1024))
+    big_out = torch.empty((1024, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
+    s_big = torch.cuda.Stream(device=gpu_ctx.device)
+    gpu_ctx.render(big, big_out, stream=s_big)
+    torch.cuda.synchronize()
+    small_dl = synth.config2(2)
+    small_ll = labels.make_labels(2, labels_per_tile=6, seed=9)
+    small_out = torch.empty((2, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
+    lat = []
+
+    def worker():
+        s = torch.cuda.Stream(device=gpu_ctx.device)
+        sc = gpu_ctx.upload(small_dl)
+        for _ in range(5):
+            t0 = time.perf_counter()
+            sc.set_labels(small_ll)
+            gpu_ctx.render(sc, small_out, stream=s)
+            sc.label_status()
+            lat.append(time.perf_counter() - t0)
+        sc.free()
+
+    n_queue = 150  # ~1.9 ms each: ~0.3 s of queued work on s_big
+    t0 = time.perf_counter()
+    for _ in range(n_queue):
+        gpu_ctx.render(big, big_out, stream=s_big)
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    t_worker_done = time.perf_counter() - t0
+    s_big.synchronize()
+    t_queue_done = time.perf_counter() - t0
+    big.free()
+    assert len(lat) == 5
+    # with a device-wide synchronisation inside the calls the worker could not finish before the big queue did
+    assert t_worker_done < 0.6 * t_queue_done, (t_worker_done, t_queue_done, lat)

@@ -144,3 +144,27 @@ def test_push_away_from(oracle):
     assert oracle.push_away_from((10, 10), (0, 10), 3.0) == (13, 10)
     assert oracle.push_away_from((0, 0), (3, 4), 5.0) == (-3, -4)
     assert oracle.push_away_from((0, 0), (1, 1), 1.0) == (-1, -1)  # round(0.7071) = 1 on both axes
+
+
+def test_persistent_pool_equals_the_one_shot_renderer(oracle):
+    """oracle_py.Pool (canvases allocated once per worker, http_server.rs:69-72) reuses its TilePixels across calls:
+    same pixels as the allocate-per-call path, also on the second call and with labels."""
+    import numpy as np
+
+    from osm_renderer_amd import labels, synth
+
+    dl = synth.config2(6)
+    ll = labels.make_labels(6, labels_per_tile=4, seed=3)
+    want = oracle.render_batch(dl, threads=2)
+    want_l, st = oracle.render_batch(dl, threads=2, labels=ll, want_status=True)
+    pool = oracle.Pool(3)
+    out = np.zeros_like(want)
+    for _ in range(2):
+        pool.render(dl, out)
+        assert np.array_equal(out, want)
+    got_st = np.zeros_like(st)
+    pool.render(dl, out, labels=ll, status=got_st)
+    assert np.array_equal(out, want_l) and np.array_equal(got_st, st)
+    pool.render(dl, out)  # labels of the previous call leave nothing behind
+    assert np.array_equal(out, want)
+    pool.close()
