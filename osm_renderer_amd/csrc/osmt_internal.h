@@ -52,25 +52,50 @@ struct osmt_stroke_aux {
     osmt_dash_table caps;
 };
 
-/* Everything k_raster needs to start on an op, in ONE 64-byte record (one s_load_dwordx16):
- * the op header fields, the pre-pass results and the first ring (the only ring of every way),
- * so the dependent-load chain per op is oplist -> opinfo -> points. */
+/* Everything k_raster needs to start on an op, in ONE 64-byte record (one s_load_dwordx16): the op header fields it
+ * uses and the results of the pre-pass — k_raster never touches ops, rings or points. */
 struct osmt_opinfo {
-    int32_t x0, y0, x1, y1; /* inclusive extent of pixels the op can touch (empty: x0 > x1) */
-    uint32_t aux;           /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
+    int32_t x0, y0, x1, y1; /* inclusive extent of the op's points (empty: x0 > x1) */
+    uint32_t aux;           /* STROKE: index into the stroke_aux table */
     uint32_t n_edges;       /* total edges over all rings */
     int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its Bresenham centre */
     int32_t reach_major;    /* STROKE: the same along the segment's major axis only (tighter) */
     uint8_t kind, cap, color[3], _pad[3]; /* osmt_op.kind / cap / color */
-    uint32_t n_rings, ring_off;           /* osmt_op.n_rings / ring_off */
-    osmt_ring ring0;                      /* rings[ring_off] when n_rings >= 1 */
-    double opacity;                       /* osmt_op.opacity */
+    /* FILL: first 64-byte group (16 row words of one sub-tile) of the op's coverage masks in the fill arena;
+     * STROKE: first record of the op in the stroke-record arena */
+    uint32_t arena_off;
+    uint32_t rec_cap;   /* STROKE: records reserved for the op (sum of candidate sub-tiles over its virtual segments) */
+    /* FILL: sub-tile window the masks cover: sr0 | c0 << 8 | ncols << 16 | nsr << 24 (nsr == 0: no covered row inside the tile) */
+    uint32_t fill_geom;
+    uint32_t image_id;  /* FILL_IMAGE: osmt_op.image_id */
+    double opacity;     /* osmt_op.opacity */
 };
 static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record");
 
+/* ---- pre-pass products (implementation traffic, not algorithmic bytes) --------------------------
+ * Fill arena: for every FILL op, for every sub-tile (sr, c) of its window, 16 words = the coverage of rows
+ * 16*sr .. 16*sr+15 restricted to columns 32*c .. 32*c+31 (bit x of the word of row y = fill_contour sets pixel (x, y),
+ * fill.rs:23-45).  Group index = arena_off + (sr - sr0) * ncols + (c - c0).  Written by k_fill_rows once per op — the
+ * rows of an op are evaluated ONCE per tile, not once per sub-tile column.
+ *
+ * Stroke arena: one record per (virtual segment, sub-tile it can draw into), written by k_stroke_bin with the step
+ * ranges of the segment's perpendicular runs for that sub-tile.  Records of one op are contiguous (arena_off .. +rec_n),
+ * in no particular order; `key` = the sub-tile a record belongs to, kept in its own array so that a wave filters 64
+ * records with one coalesced load. */
+struct osmt_srec {
+    int32_t p1x, p1y, p2x, p2y;
+    double traveled;      /* line.rs:31, before this edge (0 for a cap stub) */
+    double denom;         /* center_dist_denom (line.rs:104) */
+    double rdenom;        /* 1 / denom, correctly rounded (exact-division shortcut of the walk) */
+    int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
+    int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
+    uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
+    uint32_t count;       /* items = k_n0 + k_n1 + n_x0 + n_x1 */
+};
+static_assert(sizeof(osmt_srec) == 80, "osmt_srec layout");
+
 /* Ops with more than 64 edges get one bounding box per block of 64 consecutive edges (running
- * edge index over all rings): k_raster skips whole blocks that cannot touch its sub-tile, so a
- * 2000-vertex way costs a sub-tile a few blocks, not 2000 edge tests. */
+ * edge index over all rings): k_fill_rows skips the blocks whose rows miss the rows it is working on. */
 struct osmt_blk_bbox {
     int32_t x0, y0, x1, y1; /* over the end points of the block's edges (empty block: x0 > x1) */
 };
@@ -150,20 +175,14 @@ struct osmt_raster_args {
     const osmt_tile_job* jobs;
     uint32_t n_jobs;
     uint32_t scale;
-    const osmt_op* ops;
     const osmt_opinfo* info;
-    const osmt_ring* rings;
-    const int2* pts;
-    const double* trav;
-    const double* den; /* per edge (indexed by its first point): center_dist_denom = |p2 - p1| */
     const osmt_stroke_aux* aux;
-    const uint32_t* op_blk;  /* per op: first entry in `blk` (0xFFFFFFFF: op has <= 64 edges, no blocks) */
-    const osmt_blk_bbox* blk;
-    const uint8_t* opnv;     /* per op: 0 = not a stroke; 1..64 = stroke with that many virtual segments
-                              * (edges + cap stubs, single ring); 255 = stroke that needs its own passes */
-    const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = op may touch sub-tile (sx, sy) */
+    const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = the op draws into sub-tile (sx, sy) (exact) */
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
-    uint32_t has_blocks;     /* some op has more than 64 edges: use the block-culling instantiation */
+    const uint32_t* fmask;   /* fill arena (words) */
+    const osmt_srec* srec;   /* stroke arena */
+    const uint32_t* skey;    /* per stroke record: its sub-tile (sy * subs_per_row + sx) */
+    const uint32_t* rec_n;   /* per op: records written by k_stroke_bin */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -173,14 +192,45 @@ struct osmt_raster_args {
     osmt_label_args labels;  /* info == NULL: no label pass */
 };
 
+/* The per-op pre-pass and the two binning kernels (stage 2). */
+struct osmt_prepass_args {
+    const osmt_tile_job* jobs;
+    uint32_t n_jobs;
+    const osmt_op* ops;
+    uint32_t n_ops;
+    const osmt_ring* rings;
+    const int2* pts;
+    const double* dashes;
+    const uint32_t* op_aux;   /* op -> stroke slot */
+    const uint32_t* op_job;   /* op -> job */
+    const uint32_t* op_blk;   /* op -> first 64-edge block bbox (0xFFFFFFFF: none) */
+    const uint32_t* vseg_base; /* [n_strokes + 1]: first virtual segment (edges + cap stubs) of every stroke slot */
+    const uint32_t* stroke_op; /* [n_strokes]: stroke slot -> op */
+    uint32_t n_strokes;
+    uint32_t n_vsegs;
+    uint32_t scale;
+    uint32_t sub_rows;
+    osmt_opinfo* info;
+    double* trav;
+    double* den;
+    double* rden;
+    osmt_stroke_aux* aux;
+    osmt_blk_bbox* blk;
+    uint32_t* submask;
+    uint32_t* rec_n;
+    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records); zeroed by the launcher */
+    uint32_t* fmask;
+    osmt_srec* srec;
+    uint32_t* skey;
+    unsigned long long fmask_cap, srec_cap; /* arena capacities (groups / records); 0 = sizing pass: only the cursors are produced */
+};
+
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
                                uint32_t n_pts, double scale, int32_t* pts, hipStream_t st);
 hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
                                       double scale, int32_t* pts, hipStream_t st);
-hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
-                              const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
-                              uint32_t* submask, uint32_t sub_rows, hipStream_t st);
+/* k_opinfo -> k_fill_rows -> k_stroke_bin on `st` (sizing pass: k_opinfo only) */
+hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 /* label pass: cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
 hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st);

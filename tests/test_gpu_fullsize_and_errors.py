@@ -92,6 +92,10 @@ def test_error_codes(gpu_ctx):
 def test_empty_batch(gpu_ctx):
     dl = synth.config2(1).subset([0])
     dl.jobs = dl.jobs[:0]
+    with pytest.raises(OsmtError) as e:  # ops no job covers would still reach the per-op pre-pass: rejected
+        gpu_ctx.render_batch_host(dl)
+    assert e.value.code == abi.INVALID_ARG and "not covered by any job" in str(e.value)
+    dl.ops = dl.ops[:0]
     out = gpu_ctx.render_batch_host(dl)
     assert out.shape[0] == 0
 
