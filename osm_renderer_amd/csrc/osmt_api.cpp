@@ -115,11 +115,23 @@ struct osmt_scene {
     double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     uint32_t* d_submask = nullptr;
-    uint8_t* d_opnv = nullptr;
     uint32_t* d_op_blk = nullptr;
     osmt_blk_bbox* d_blk = nullptr;
+    double* d_rden = nullptr;
+    uint32_t* d_op_job = nullptr;
+    uint32_t* d_vseg_base = nullptr;
+    uint32_t* d_stroke_op = nullptr;
+    uint32_t* d_rec_n = nullptr;
+    unsigned long long* d_cursors = nullptr;
+    uint32_t n_vsegs = 0;
+    /* the two arenas of the pre-pass (fill coverage words, stroke records + keys): one allocation, sized at upload */
+    char* d_arena = nullptr;
+    uint32_t* d_fmask = nullptr;
+    osmt_srec* d_srec = nullptr;
+    uint32_t* d_skey = nullptr;
+    unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
-    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_lab_wide;
+    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_job, h_vseg_base, h_stroke_op, h_lab_wide;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
     /* public scenes: one event per stream the scene was rendered on, recorded behind the last launch that reads it.
@@ -451,6 +463,43 @@ int validate_batch(const osmt_batch* b) {
     return OSMT_OK;
 }
 
+/* Arguments of stage 2 (k_opinfo -> k_fill_rows -> k_stroke_bin); sizing: only the arena cursors are produced. */
+osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
+    osmt_prepass_args a;
+    memset(&a, 0, sizeof a);
+    a.jobs = sc->d_jobs;
+    a.n_jobs = sc->n_jobs;
+    a.ops = sc->d_ops;
+    a.n_ops = sc->n_ops;
+    a.rings = sc->d_rings;
+    a.pts = reinterpret_cast<const int2*>(sc->d_pts);
+    a.dashes = sc->d_dashes;
+    a.op_aux = sc->d_op_aux;
+    a.op_job = sc->d_op_job;
+    a.op_blk = sc->d_op_blk;
+    a.vseg_base = sc->d_vseg_base;
+    a.stroke_op = sc->d_stroke_op;
+    a.n_strokes = sc->n_strokes;
+    a.n_vsegs = sc->n_vsegs;
+    a.scale = sc->scale;
+    a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
+    a.info = sc->d_info;
+    a.trav = sc->d_trav;
+    a.den = sc->d_den;
+    a.rden = sc->d_rden;
+    a.aux = sc->d_aux;
+    a.blk = sc->d_blk;
+    a.submask = sc->d_submask;
+    a.rec_n = sc->d_rec_n;
+    a.cursors = sc->d_cursors;
+    a.fmask = sc->d_fmask;
+    a.srec = sc->d_srec;
+    a.skey = sc->d_skey;
+    a.fmask_cap = sizing ? 0ull : sc->fmask_cap;
+    a.srec_cap = sizing ? 0ull : sc->srec_cap;
+    return a;
+}
+
 /* stages: 1 = project, 2 = per-op pre-pass, 4 = raster (with the label kernels first when the scene has labels),
  * 8 = label kernels only (cover + resolve), 16 = with 4: the label kernels already ran for this scene.
  * [first_job, first_job + n_range) = tiles the raster stage renders into d_out (n_range 0: all). */
@@ -465,9 +514,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     if ((stages & 1u) && sc->coord_kind != OSMT_COORD_POINT_I32)
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->coord_kind == OSMT_COORD_NODE_REF ? sc->d_node_refs : nullptr,
                                     sc->n_pts, (double)sc->scale, sc->d_pts, st));
-    if (stages & 2u)
-        HIP_TRY(osmt_launch_opinfo(sc->d_ops, sc->n_ops, sc->d_rings, sc->d_pts, sc->d_dashes, sc->d_op_aux, sc->d_info,
-                                   sc->d_trav, sc->d_den, sc->d_aux, sc->d_opnv, sc->d_op_blk, sc->d_blk, sc->d_submask, OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H, st));
+    if (stages & 2u) HIP_TRY(osmt_launch_prepass(prepass_args(sc, false), st));
     const bool want_labels = sc->n_labels && !f64;
     if (want_labels && ((stages & 8u) || ((stages & 4u) && !(stages & 16u)))) {
         /* the label pass does not read the area canvas: coverage + collisions first, then
@@ -504,19 +551,14 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.jobs = sc->d_jobs + first_job;
         a.n_jobs = n_render;
         a.scale = sc->scale;
-        a.ops = sc->d_ops;
         a.info = sc->d_info;
-        a.rings = sc->d_rings;
-        a.pts = reinterpret_cast<const int2*>(sc->d_pts);
-        a.trav = sc->d_trav;
-        a.den = sc->d_den;
         a.aux = sc->d_aux;
         a.submask = sc->d_submask;
-        a.opnv = sc->d_opnv;
-        a.op_blk = sc->d_op_blk;
-        a.blk = sc->d_blk;
-        a.has_blocks = sc->n_blk > 0 ? 1u : 0u;
         a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
+        a.fmask = sc->d_fmask;
+        a.srec = sc->d_srec;
+        a.skey = sc->d_skey;
+        a.rec_n = sc->d_rec_n;
         a.images = img.desc;
         a.image_pool = img.pool;
         a.n_images = img.n;
@@ -599,6 +641,52 @@ int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uin
     return guarded([&] { return osmt_register_image_body(ctx, rgba8, width, height, out_id); });
 }
 
+/* The pre-pass writes into two arenas whose sizes depend on the PROJECTED geometry (how many sub-tiles every op
+ * reaches).  Small scenes take the worst case — every fill covers the whole tile, every stroke segment reaches every
+ * sub-tile — without asking the device (a single-tile request must not pay a round trip); larger ones run the
+ * projection and the sizing half of k_opinfo once, read the two totals back and allocate exactly.  Either way the
+ * reservation logic of k_opinfo is the same code at render time, so the arenas cannot overflow. */
+static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
+    const size_t W = (size_t)OSMT_TILE_SIZE * s->scale;
+    const size_t nsub = (W / OSMT_SUB_W) * (W / OSMT_SUB_H);
+    unsigned long long groups = (unsigned long long)n_fills * nsub, recs = (unsigned long long)s->n_vsegs * nsub;
+    const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 4ull);
+    if (worst_bytes > ((unsigned long long)32 << 20)) {
+        hipStream_t st = s->own_stream;
+        if (s->coord_kind != OSMT_COORD_POINT_I32)
+            HIP_TRY(osmt_launch_project(s->d_jobs, s->d_pt_job, s->d_latlon, s->coord_kind == OSMT_COORD_NODE_REF ? s->d_node_refs : nullptr,
+                                        s->n_pts, (double)s->scale, s->d_pts, st));
+        HIP_TRY(osmt_launch_prepass(prepass_args(s, true), st));
+        unsigned long long totals[2] = {0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(totals, s->d_cursors, sizeof totals, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        groups = totals[0];
+        recs = totals[1];
+    }
+    if (groups >= 0xFFFFFFFFull || recs >= 0xFFFFFFFFull)
+        return fail(OSMT_UNSUPPORTED, "scene needs %llu fill groups / %llu stroke records (> 2^32): split the batch", groups, recs);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t o_f = carve((size_t)(groups + 1) * 64);
+    const size_t o_r = carve((size_t)(recs + 1) * sizeof(osmt_srec));
+    const size_t o_k = carve((size_t)(recs + 1) * 4);
+    hipError_t e = dev_alloc(ctx, (void**)&s->d_arena, off + 256);
+    if (e != hipSuccess) {
+        s->d_arena = nullptr;
+        return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) for the pre-pass arenas failed: %s", off, hipGetErrorString(e));
+    }
+    s->d_fmask = (uint32_t*)(s->d_arena + o_f);
+    s->d_srec = (osmt_srec*)(s->d_arena + o_r);
+    s->d_skey = (uint32_t*)(s->d_arena + o_k);
+    s->fmask_cap = groups + 1; /* never 0: 0 means "sizing pass" to the kernels */
+    s->srec_cap = recs + 1;
+    return OSMT_OK;
+}
+
 /* st == nullptr: blocking copies (the public osmt_scene_upload); otherwise stream-ordered on `st`, the caller
  * synchronises the stream before the batch's host arrays go away */
 static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st) {
@@ -618,27 +706,48 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     pt_job.assign(b->n_pts, 0xFFFFFFFFu);
     op_aux.assign(b->n_ops, 0u);
     op_blk.assign(b->n_ops, 0xFFFFFFFFu);
+    /* op -> job; stroke slot -> op; first virtual segment (edges + the two cap stubs of Round/Square caps,
+     * line.rs:33-57) of every stroke slot: k_stroke_bin runs one thread per virtual segment of the scene */
+    std::vector<uint32_t>& op_job = s->h_op_job;
+    std::vector<uint32_t>& vseg_base = s->h_vseg_base;
+    std::vector<uint32_t>& stroke_op = s->h_stroke_op;
+    op_job.assign(b->n_ops, 0u);
+    vseg_base.clear();
+    stroke_op.clear();
     uint32_t n_strokes = 0;
     size_t n_blk = 0; /* 64-edge blocks of the ops with more than 64 edges */
+    size_t n_vsegs = 0, n_fills = 0;
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
         for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
         for (uint32_t k = 0; k < job.n_ops; ++k) {
             const osmt_op& op = b->ops[job.op_off + k];
-            if (op.kind == OSMT_OP_STROKE) op_aux[job.op_off + k] = n_strokes++;
-            if (op.kind != OSMT_OP_NONE) {
-                size_t ne = 0;
-                for (uint32_t r = 0; r < op.n_rings; ++r) {
-                    const uint32_t np = b->rings[op.ring_off + r].n_pts;
-                    if (np >= 2) ne += np - 1;
-                }
-                if (ne > 64 && n_blk + (ne + 63) / 64 < 0xFFFFFFFFull) {
-                    op_blk[job.op_off + k] = (uint32_t)n_blk;
-                    n_blk += (ne + 63) / 64;
-                }
+            op_job[job.op_off + k] = (uint32_t)j;
+            if (op.kind == OSMT_OP_NONE) continue;
+            size_t ne = 0;
+            for (uint32_t r = 0; r < op.n_rings; ++r) {
+                const uint32_t np = b->rings[op.ring_off + r].n_pts;
+                if (np >= 2) ne += np - 1;
+            }
+            if (ne > 64 && n_blk + (ne + 63) / 64 < 0xFFFFFFFFull) {
+                op_blk[job.op_off + k] = (uint32_t)n_blk;
+                n_blk += (ne + 63) / 64;
+            }
+            if (op.kind == OSMT_OP_STROKE) {
+                op_aux[job.op_off + k] = n_strokes++;
+                stroke_op.push_back(job.op_off + k);
+                vseg_base.push_back((uint32_t)n_vsegs);
+                n_vsegs += ne + ((op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE) ? 2u : 0u);
+            } else {
+                ++n_fills;
             }
         }
     }
+    if (n_vsegs >= 0xFFFFFFFFull) {
+        delete s;
+        return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices (stroke segments)");
+    }
+    vseg_base.push_back((uint32_t)n_vsegs);
 
     s->ctx = ctx;
     ctx->refs.fetch_add(1);
@@ -649,6 +758,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->n_dashes = (uint32_t)b->n_dashes;
     s->n_strokes = n_strokes;
     s->n_blk = (uint32_t)n_blk;
+    s->n_vsegs = (uint32_t)n_vsegs;
     s->scale = b->scale;
     s->coord_kind = b->coord_kind;
 
@@ -670,6 +780,9 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_ptjob = carve(b->n_pts * 4);
     const size_t o_opaux = carve(b->n_ops * 4);
     const size_t o_opblk = carve(b->n_ops * 4);
+    const size_t o_opjob = carve(b->n_ops * 4);
+    const size_t o_vsegbase = carve(vseg_base.size() * 4);
+    const size_t o_strokeop = carve(((size_t)n_strokes + 1) * 4);
     const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
@@ -677,8 +790,10 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
-    const size_t o_opnv = carve(b->n_ops + 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
+    const size_t o_rden = carve(b->n_pts * 8);
+    const size_t o_recn = carve(((size_t)b->n_ops + 1) * 4);
+    const size_t o_cursors = carve(16);
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
@@ -700,9 +815,14 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
-    s->d_opnv = (uint8_t*)(s->d_base + o_opnv);
     s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
     s->d_blk = (osmt_blk_bbox*)(s->d_base + o_blk);
+    s->d_rden = (double*)(s->d_base + o_rden);
+    s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
+    s->d_vseg_base = (uint32_t*)(s->d_base + o_vsegbase);
+    s->d_stroke_op = (uint32_t*)(s->d_base + o_strokeop);
+    s->d_rec_n = (uint32_t*)(s->d_base + o_recn);
+    s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
@@ -727,6 +847,9 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         put(o_ptjob, pt_job.data(), b->n_pts * 4);
         put(o_opaux, op_aux.data(), b->n_ops * 4);
         put(o_opblk, op_blk.data(), b->n_ops * 4);
+        put(o_opjob, op_job.data(), b->n_ops * 4);
+        put(o_vsegbase, vseg_base.data(), vseg_base.size() * 4);
+        put(o_strokeop, stroke_op.data(), stroke_op.size() * 4);
         s->h_stage = stage;
         err = hipMemcpyAsync(s->d_base, stage, front_bytes, hipMemcpyHostToDevice, st);
         if (err != hipSuccess) {
@@ -734,6 +857,11 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             dev_free(ctx, s->d_base);
             scene_delete(s);
             return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
+        }
+        rc = scene_size_arenas(ctx, s, n_fills);
+        if (rc != OSMT_OK) {
+            osmt_scene_free(s);
+            return rc;
         }
         *out_scene = s;
         return OSMT_OK;
@@ -749,10 +877,18 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
+    if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
+    if (err == hipSuccess) err = up(s->d_vseg_base, vseg_base.data(), vseg_base.size() * 4);
+    if (err == hipSuccess) err = up(s->d_stroke_op, stroke_op.data(), stroke_op.size() * 4);
     if (err != hipSuccess) {
         dev_free(ctx, s->d_base);
         scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
+    }
+    rc = scene_size_arenas(ctx, s, n_fills);
+    if (rc != OSMT_OK) {
+        osmt_scene_free(s);
+        return rc;
     }
     *out_scene = s;
     return OSMT_OK;
@@ -774,6 +910,7 @@ void osmt_scene_free(osmt_scene* s) {
      * was rendered on (public scenes) — not for the device: other workers' streams keep running */
     (void)scene_wait_idle(s);
     dev_free(s->ctx, s->d_base);
+    dev_free(s->ctx, s->d_arena);
     dev_free(s->ctx, s->d_lab_base);
     stage_release(s->ctx, s->h_stage);
     scene_delete(s);

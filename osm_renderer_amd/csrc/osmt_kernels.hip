@@ -135,62 +135,71 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
     t->total_len = len_before;
 }
 
-/* Marks the sub-tiles whose rectangle grown by g pixels intersects the segment a-b
- * (separating axes: x, y and the segment's normal; exact in int64). */
-__device__ void mark_segment(uint32_t* __restrict__ sm, int32_t n_sub_x, int32_t n_sub_y, int32_t ax, int32_t ay,
-                             int32_t bx, int32_t by, int32_t g) {
-    const int32_t sx0 = max((min(ax, bx) - g) >> 5, 0), sx1 = min((max(ax, bx) + g) >> 5, n_sub_x - 1);
-    const int32_t sy0 = max((min(ay, by) - g) >> OSMT_SUB_H_LOG2, 0);
-    const int32_t sy1 = min((max(ay, by) + g) >> OSMT_SUB_H_LOG2, n_sub_y - 1);
-    if (sx0 > sx1 || sy0 > sy1) return;
-    const int64_t dx = (int64_t)bx - ax, dy = (int64_t)by - ay;
-    for (int32_t sy = sy0; sy <= sy1; ++sy) {
-        const int64_t y0 = (int64_t)sy * OSMT_SUB_H - g - ay, y1 = (int64_t)sy * OSMT_SUB_H + (OSMT_SUB_H - 1) + g - ay;
-        uint32_t bits = 0u;
-        for (int32_t sx = sx0; sx <= sx1; ++sx) {
-            const int64_t x0 = (int64_t)sx * 32 - g - ax, x1 = (int64_t)sx * 32 + 31 + g - ax;
-            /* cross(d, corner - a) for the four corners */
-            const int64_t c00 = dx * y0 - dy * x0, c10 = dx * y0 - dy * x1;
-            const int64_t c01 = dx * y1 - dy * x0, c11 = dx * y1 - dy * x1;
-            const bool all_pos = c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0;
-            const bool all_neg = c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0;
-            if (!(all_pos || all_neg)) bits |= 1u << sx;
-        }
-        sm[sy] |= bits;
-    }
+/* Sub-tiles a virtual segment (an edge or a cap stub) can draw into: every pixel it sets lies within `reach` (per
+ * axis) of the segment's box — the first cull of seg_ranges.  k_opinfo counts these candidates to reserve the op's
+ * records, k_stroke_bin walks exactly the same window, so the reservation can never be exceeded. */
+struct SubWindow {
+    int32_t sx0, sx1, sy0, sy1; /* inclusive; empty when sx0 > sx1 or sy0 > sy1 */
+};
+__device__ __forceinline__ SubWindow vseg_window(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
+                                                 int32_t n_sub_x, int32_t n_sub_y) {
+    SubWindow w;
+    w.sx0 = max((min(p1x, p2x) - reach) >> 5, 0);
+    w.sx1 = min((max(p1x, p2x) + reach) >> 5, n_sub_x - 1);
+    w.sy0 = max((min(p1y, p2y) - reach) >> OSMT_SUB_H_LOG2, 0);
+    w.sy1 = min((max(p1y, p2y) + reach) >> OSMT_SUB_H_LOG2, n_sub_y - 1);
+    return w;
+}
+__device__ __forceinline__ uint32_t window_count(const SubWindow& w) {
+    if (w.sx0 > w.sx1 || w.sy0 > w.sy1) return 0u;
+    return (uint32_t)(w.sx1 - w.sx0 + 1) * (uint32_t)(w.sy1 - w.sy0 + 1);
 }
 
-/* Per-op pre-pass: pixel extents (for sub-tile culling), traveled distance before every
- * edge of a stroke (line.rs:31: add_traveled_distance, summed in edge order), and the two
- * dash tables of draw_lines (line.rs:21-22). One thread per op. */
-__global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, uint32_t n_ops,
-                                               const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
-                                               const double* __restrict__ dashes, const uint32_t* __restrict__ op_aux,
-                                               osmt_opinfo* __restrict__ info, double* __restrict__ trav,
-                                               double* __restrict__ den, osmt_stroke_aux* __restrict__ aux,
-                                               uint8_t* __restrict__ opnv, const uint32_t* __restrict__ op_blk,
-                                               osmt_blk_bbox* __restrict__ blk, uint32_t* __restrict__ submask,
-                                               uint32_t sub_rows) {
+/* Per-op pre-pass, one thread per op: everything k_raster needs in one 64-byte osmt_opinfo; the traveled distance
+ * before every edge of a stroke (line.rs:31: add_traveled_distance, summed in edge order) and every edge's length
+ * (= center_dist_denom, line.rs:104) with its reciprocal; the two dash tables and the cap stubs of draw_lines
+ * (line.rs:21-22,33-57); 64-edge block boxes of long ops; and the RESERVATIONS in the two arenas: a fill op gets
+ * 16 row words per sub-tile of its clipped window, a stroke op one record per (virtual segment, candidate sub-tile).
+ * Offsets come from two global cursors (atomicAdd: the order of the ops in the arenas does not matter, k_raster
+ * finds everything through osmt_opinfo).  With fmask_cap == srec_cap == 0 the kernel only sizes (upload-time pass). */
+__global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     const uint32_t o = blockIdx.x * 64u + threadIdx.x;
-    if (o >= n_ops) return;
-    const osmt_op op = ops[o];
-    uint32_t* __restrict__ sm = submask + (size_t)o * sub_rows;
+    if (o >= a.n_ops) return;
+    const osmt_op op = a.ops[o];
+    const osmt_ring* __restrict__ rings = a.rings;
+    const int2* __restrict__ pts = a.pts;
+    const uint32_t sub_rows = a.sub_rows;
+    uint32_t* __restrict__ sm = a.submask + (size_t)o * sub_rows;
     for (uint32_t r = 0; r < sub_rows; ++r) sm[r] = 0u;
+    a.rec_n[o] = 0u;
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
     oi.x1 = oi.y1 = INT32_MIN;
-    oi.aux = op_aux[o];
+    oi.aux = a.op_aux[o];
     oi.n_edges = 0;
+    oi.reach = 0;
     oi.reach_major = 0;
-    opnv[o] = 0;
+    oi.kind = op.kind;
+    oi.cap = op.cap;
+    oi.color[0] = op.color[0];
+    oi.color[1] = op.color[1];
+    oi.color[2] = op.color[2];
+    oi._pad[0] = oi._pad[1] = oi._pad[2] = 0;
+    oi.arena_off = 0;
+    oi.rec_cap = 0;
+    oi.fill_geom = 0;
+    oi.image_id = op.image_id;
+    oi.opacity = op.opacity;
     if (op.kind == OSMT_OP_NONE) {
-        info[o] = oi;
+        a.info[o] = oi;
         return;
     }
+    const int32_t W = (int32_t)(OSMT_TILE_SIZE * a.scale);
+    const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = W / OSMT_SUB_W;
     double traveled = 0.0;
     uint32_t n_edges = 0;
     /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
-    const uint32_t blk_off = op_blk[o];
+    const uint32_t blk_off = a.op_blk[o];
     uint32_t cur_blk = 0xFFFFFFFFu;
     osmt_blk_bbox bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
     for (uint32_t r = 0; r < op.n_rings; ++r) {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
             if (blk_off != 0xFFFFFFFFu && i > 0) {
                 const uint32_t b_ = (n_edges + i - 1u) >> 6; /* running edge index / 64 */
                 if (b_ != cur_blk) {
-                    if (cur_blk != 0xFFFFFFFFu) blk[blk_off + cur_blk] = bb;
+                    if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
                     cur_blk = b_;
                     bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
                 }
@@ -219,16 +228,17 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
                     /* |p2 - p1| is both the traveled increment (line.rs:31) and center_dist_denom
                      * (line.rs:104: sqrt(dy*dy + dx*dx) of the absolute deltas — the same f64) */
                     const double len = point_dist(prev.x, prev.y, p.x, p.y);
-                    den[ring.first_pt + i - 1] = len;
+                    a.den[ring.first_pt + i - 1] = len;
+                    a.rden[ring.first_pt + i - 1] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
                     traveled += len;
                 }
-                trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
+                a.trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
             }
             prev = p;
         }
         if (ring.n_pts >= 2) n_edges += ring.n_pts - 1;
     }
-    if (cur_blk != 0xFFFFFFFFu) blk[blk_off + cur_blk] = bb;
+    if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
     oi.n_edges = n_edges;
     if (op.kind == OSMT_OP_STROKE) {
         const double hw = op.width / 2.0;
@@ -239,67 +249,42 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
          * |d0| <= 0.5 for a main perpendicular and <= 1.5 for the extra one of line.rs:152-154; it
          * is set only while that distance is < ft' <= ft.  Hence t < (ft + 2.21) * b/len <= ft + 2.21
          * and cc_t < (a/len)*(ft + 2.21) + 1 <= 0.7072*(ft + 2.21) + 1. */
-        int32_t reach = (int32_t)fmin(ceil(ft + 2.21), 1.0e6);
-        int32_t reach_major = (int32_t)fmin(ceil(0.7072 * (ft + 2.21)), 1.0e6) + 1;
-        oi.reach_major = reach_major;
-        const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
-        int32_t cap_reach = caps ? (int32_t)fmin(ceil(fabs(hw)), 1.0e6) + 1 : 0;
+        const int32_t reach = (int32_t)fmin(ceil(ft + 2.21), 1.0e6);
         oi.reach = reach;
-        if (oi.x0 <= oi.x1) {
-            oi.x0 -= reach + cap_reach;
-            oi.y0 -= reach + cap_reach;
-            oi.x1 += reach + cap_reach;
-            oi.y1 += reach + cap_reach;
-        }
-        /* sub-tile coverage: a sub-tile is marked when its rectangle grown by reach+1 (the
-         * Bresenham centre is within 0.5 px of the ideal segment) meets the segment; the cap
-         * stubs (length <= hw + 1) are covered by growing the first/last edge's test further */
-        {
-            const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = (int32_t)(sub_rows * OSMT_SUB_H / OSMT_SUB_W);
-            uint32_t e_seen = 0;
-            for (uint32_t r = 0; r < op.n_rings; ++r) {
-                const osmt_ring ring = rings[op.ring_off + r];
-                for (uint32_t i = 1; i < ring.n_pts; ++i) {
-                    const int2 a = pts[ring.first_pt + i - 1];
-                    const int2 b = pts[ring.first_pt + i];
-                    ++e_seen;
-                    const bool endcap = caps && (e_seen == 1 || e_seen == n_edges);
-                    const int32_t g = reach + 1 + (endcap ? cap_reach : 0);
-                    mark_segment(sm, n_sub_x, n_sub_y, a.x, a.y, b.x, b.y, g);
-                }
-            }
-        }
-        {
-            const uint32_t nv = n_edges + (caps ? 2u : 0u);
-            opnv[o] = (op.n_rings == 1u && nv <= 64u) ? (uint8_t)nv : (uint8_t)255;
-        }
-        osmt_stroke_aux* sa = &aux[oi.aux];
+        oi.reach_major = (int32_t)fmin(ceil(0.7072 * (ft + 2.21)), 1.0e6) + 1;
+        const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
+        osmt_stroke_aux* sa = &a.aux[oi.aux];
         sa->half_width = hw;
         /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
-         * degenerate (`first` is consumed by a degenerate first edge) */
+         * degenerate (`first` is consumed by a degenerate first edge); and the record reservation:
+         * one slot per (virtual segment, sub-tile of its window) */
+        unsigned long long cand = 0ull;
         {
             osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0, 1.0}, c1 = {0, 0, 0, 0, 0, 0, 1.0};
             uint32_t seen = 0;
-            for (uint32_t r = 0; r < op.n_rings && caps; ++r) {
+            for (uint32_t r = 0; r < op.n_rings; ++r) {
                 const osmt_ring ring = rings[op.ring_off + r];
                 for (uint32_t i = 1; i < ring.n_pts; ++i) {
                     ++seen;
-                    if (seen != 1 && seen != n_edges) continue;
-                    const int2 a = pts[ring.first_pt + i - 1];
-                    const int2 b = pts[ring.first_pt + i];
-                    if (a.x == b.x && a.y == b.y) continue;
+                    const int2 pa = pts[ring.first_pt + i - 1];
+                    const int2 pb = pts[ring.first_pt + i];
+                    if (pa.x == pb.x && pa.y == pb.y) continue; /* line.rs:73-75: draws nothing */
+                    cand += window_count(vseg_window(pa.x, pa.y, pb.x, pb.y, reach, n_sub_x, n_sub_y));
+                    if (!caps) continue;
                     if (seen == 1) {
-                        const int2 ce = push_away_from(a, b, hw);
-                        c0 = {a.x, a.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, a.x, a.y)};
+                        const int2 ce = push_away_from(pa, pb, hw);
+                        c0 = {pa.x, pa.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, pa.x, pa.y)};
                     }
                     if (seen == n_edges) {
-                        const int2 ce = push_away_from(b, a, hw);
-                        c1 = {b.x, b.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, b.x, b.y)};
+                        const int2 ce = push_away_from(pb, pa, hw);
+                        c1 = {pb.x, pb.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, pb.x, pb.y)};
                     }
                 }
             }
             sa->cap_seg[0] = c0;
             sa->cap_seg[1] = c1;
+            if (c0.valid) cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, reach, n_sub_x, n_sub_y));
+            if (c1.valid) cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, reach, n_sub_x, n_sub_y));
         }
         sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
@@ -308,7 +293,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         sa->mul0 = fmin(2.0 * sa->hlw0, 1.0);
         const int cap_for_dashes = op.use_caps_for_dashes ? op.cap : OSMT_CAP_NONE;
         if (op.has_dashes) {
-            compute_segments(hw, dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes, &sa->main);
+            compute_segments(hw, a.dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes, &sa->main);
         } else {
             sa->main.n_segs = 0;
             sa->main.has_orig = 0;
@@ -319,20 +304,27 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_op* __restrict__ ops, 
         /* the chained (0..1) pass pushes the same segment twice; max/min over two equal
          * entries equals one entry, keep one */
         sa->caps.n_segs = 1;
+        if (cand > 0xFFFFFFFFull) cand = 0xFFFFFFFFull; /* cannot happen below 2^32 records per scene (checked by the host) */
+        oi.rec_cap = (uint32_t)cand;
+        if (cand) {
+            const unsigned long long off = atomicAdd(&a.cursors[1], cand);
+            oi.arena_off = (uint32_t)off;
+            if (a.srec_cap && off + cand > a.srec_cap) oi.rec_cap = 0; /* never: the arena was sized by this same code */
+        }
     } else {
-        oi.reach = 0;
-        /* fills: every sub-tile of the extent (rows ytop+1..ybot only carry records) */
-        if (oi.x0 <= oi.x1) {
-            const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = (int32_t)(sub_rows * OSMT_SUB_H / OSMT_SUB_W);
-            const int32_t sx0 = max(oi.x0 >> 5, 0), sx1 = min(oi.x1 >> 5, n_sub_x - 1);
-            const int32_t sy0 = max((oi.y0 + 1) >> OSMT_SUB_H_LOG2, 0), sy1 = min(oi.y1 >> OSMT_SUB_H_LOG2, n_sub_y - 1);
-            if (sx0 <= sx1) {
-                const uint32_t bits = (uint32_t)((((uint64_t)1 << (sx1 - sx0 + 1)) - 1) << sx0);
-                for (int32_t sy = sy0; sy <= sy1; ++sy) sm[sy] |= bits;
-            }
+        /* fills: rows ytop+1 .. ybot carry records (fill.rs:66-72), spans lie inside the points' x range */
+        const int32_t ylo = max(oi.y0 + 1, 0), yhi = min(oi.y1, W - 1);
+        const int32_t xlo = max(oi.x0, 0), xhi = min(oi.x1, W - 1);
+        if (oi.x0 <= oi.x1 && ylo <= yhi && xlo <= xhi) {
+            const uint32_t sr0 = (uint32_t)(ylo >> OSMT_SUB_H_LOG2), nsr = (uint32_t)(yhi >> OSMT_SUB_H_LOG2) - sr0 + 1u;
+            const uint32_t c0 = (uint32_t)(xlo >> 5), ncols = (uint32_t)(xhi >> 5) - c0 + 1u;
+            const unsigned long long groups = (unsigned long long)nsr * ncols;
+            const unsigned long long off = atomicAdd(&a.cursors[0], groups);
+            oi.arena_off = (uint32_t)off;
+            if (!(a.fmask_cap && off + groups > a.fmask_cap)) oi.fill_geom = sr0 | (c0 << 8) | (ncols << 16) | (nsr << 24);
         }
     }
-    info[o] = oi;
+    a.info[o] = oi;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -419,52 +411,28 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
     return cdop > 0.0;
 }
 
-/* ---- the fused raster kernel ---------------------------------------------- */
+/* ---- the fused raster kernel and its two binning kernels ------------------------------------- */
 constexpr int SUB = OSMT_SUB_W;    /* sub-tile width in pixels (one 32-bit coverage word per row) */
 constexpr int SUBH = OSMT_SUB_H;   /* sub-tile height */
-#ifndef OSMT_V_NTHREADS
-#define OSMT_V_NTHREADS 64
-#endif
-constexpr int NTHREADS = OSMT_V_NTHREADS; /* 64 = one wave per sub-tile: no cross-wave barrier anywhere */
-static_assert(NTHREADS == 64, "the stroke path packs items with wave-level scans");
+constexpr int NTHREADS = 64;       /* one wave per sub-tile: no cross-wave barrier anywhere */
 constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
-constexpr int NBUF = NTHREADS > 64 ? 2 : 1; /* multi-wave groups double-buffer planes/masks to save a barrier */
-constexpr int ROWSTEP = NTHREADS / SUB;     /* rows between a thread's consecutive pixels */
+constexpr int ROWSTEP = NTHREADS / SUB;    /* rows between a thread's consecutive pixels */
+constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
+constexpr int SEGCAP = 64;         /* stroke records of one group held in LDS */
 #ifndef OSMT_V_ROWCAP
 #define OSMT_V_ROWCAP 16
 #endif
-constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path */
-
-constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
-
-struct RowRec {
-    int32_t x_min, x_max;
-    uint32_t edge;
-};
-
-/* One stroke segment (an edge or a cap stub) that survived the sub-tile cull, with the step
- * ranges of its two perpendicular sides; the items of all records of an op are walked together. */
-struct SegRec {
-    int32_t p1x, p1y, p2x, p2y;
-    double traveled;
-    double denom;         /* center_dist_denom (line.rs:104) */
-    int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
-    int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
-    uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
-    uint32_t count;
-};
-constexpr int SEGCAP = 64;
+constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path (k_fill_rows) */
 
 struct RasterShared {
-    SegRec seg[SEGCAP];
-    uint8_t opnv[OPCHUNK];          /* g_opnv of the compacted list entries */
-    uint32_t grp_base[OPCHUNK + 1]; /* first virtual-segment lane of every list entry of a group */
-    unsigned long long plane[NBUF][SUB * SUBH]; /* generation alpha planes (f64 bit patterns) */
-    uint32_t mask[NBUF][SUBH];                  /* fill coverage per row */
-    RowRec rec[SUBH][ROWCAP];
-    uint32_t rowcnt[SUBH];
-    uint32_t oplist[OPCHUNK];
-    uint32_t wcount[(NTHREADS + 63) / 64];
+    osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
+    uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
+    unsigned long long plane[SUB * SUBH]; /* generation alpha plane (f64 bit patterns) */
+    uint32_t oplist[OPCHUNK];       /* ops of the chunk that touch this sub-tile, in order */
+    uint32_t oparena[OPCHUNK];      /* their osmt_opinfo.arena_off */
+    uint8_t opnv[OPCHUNK];          /* their record counts: 0 = fill, 1..64, 255 = more than 64 (own passes) */
+    uint8_t grp_base[OPCHUNK + 1];  /* first record lane of every list entry of a group */
+    uint8_t s_ent[OPCHUNK];         /* group-local index of the k-th STROKE entry of the group */
 };
 
 struct SubRect {
@@ -556,7 +524,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
  * mul*mn_inc per step along the minor axis and -mul*mx_inc per correction along the major axis,
  * so the major-axis test is one-sided.  Every item is exactly ONE perpendicular run. */
 __device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
-                                               int32_t reach_major, const SubRect& rc, SegRec* q) {
+                                               int32_t reach_major, const SubRect& rc, osmt_srec* q) {
     q->k_lo0 = q->k_n0 = q->k_lo1 = q->k_n1 = 0;
     q->m_lo0 = q->n_x0 = q->m_lo1 = q->n_x1 = 0;
     if (p1x == p2x && p1y == p2y) return 0u; /* line.rs:73-75 */
@@ -607,7 +575,7 @@ __device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t
 /* One item of a segment record = one perpendicular run (line.rs:108-137): items [0, k_n0 + k_n1)
  * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
  * of line.rs:152-154, located directly by osmt_extra_event. */
-__device__ __forceinline__ void walk_item(const SegRec& r, uint32_t local, const bool plain_main,
+__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const bool plain_main,
                                           const osmt_stroke_aux* __restrict__ sa, double initial_opacity,
                                           int32_t reach, const SubRect& rc, unsigned long long* __restrict__ plane) {
     osmt_seg s;
@@ -695,7 +663,7 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 }
 
 #ifndef OSMT_V_WAVES
-#define OSMT_V_WAVES 3
+#define OSMT_V_WAVES 0
 #endif
 #if OSMT_V_WAVES > 0
 /* waves per SIMD the register allocator must leave room for */
@@ -709,30 +677,228 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 #define OSMT_R __restrict__
 #endif
 
-/* BLOCKS: the scene has ops with more than 64 edges (osmt_blk_bbox culling compiled in); scenes
- * made of short ways only (all named configs) run the leaner instantiation. */
-template <bool OUT_F64, bool BLOCKS, bool LABELS>
+/* ---- k_fill_rows: fill_contour's coverage, once per op and row (fill.rs:16-104) ------------------------------
+ * One wave per FILL op; a pass handles the 64 rows of four sub-tile rows, lane = row.  Every lane walks the op's
+ * edges (wave-uniform loop, points fetched once per wave) and evaluates the closed form of the Zingl-Bresenham walk
+ * for ITS row (osmt_fill_row_extent: the un-poisoned Edge{x_min, x_max} of fill.rs:79-87); records go to the lane's
+ * column of an LDS table in edge order, are ordered by x_min with a stable insertion sort (= sort_by_key of records
+ * inserted in edge order, fill.rs:24-25), paired (0,1),(2,3).. and the spans OR-ed into one 32-bit word per sub-tile
+ * column.  k_raster then reads 16 words per (op, sub-tile) instead of re-deriving the rows in every column it
+ * crosses.  The exact "draws something here" bits of the op's sub-tile mask fall out of the same words. */
+struct FillRowsShared {
+    int32_t xmin[ROWCAP][64];
+    int32_t xmax[ROWCAP][64];
+};
+
+__global__ __launch_bounds__(64) void k_fill_rows(const osmt_op* __restrict__ g_ops, uint32_t n_ops,
+                                                  const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
+                                                  const int2* __restrict__ g_pts, const uint32_t* __restrict__ g_op_blk,
+                                                  const osmt_blk_bbox* __restrict__ g_blk, uint32_t* __restrict__ g_submask,
+                                                  uint32_t sub_rows, uint32_t* __restrict__ g_fmask) {
+    __shared__ FillRowsShared sh;
+    const uint32_t o = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const osmt_opinfo* __restrict__ oi = &g_info[o];
+    const uint32_t kind = oi->kind;
+    if (kind != OSMT_OP_FILL_COLOR && kind != OSMT_OP_FILL_IMAGE) return;
+    const uint32_t geom = oi->fill_geom;
+    const uint32_t nsr = geom >> 24;
+    if (nsr == 0u) return;
+    const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
+    const uint32_t arena = oi->arena_off;
+    const osmt_op* __restrict__ op = &g_ops[o];
+    const uint32_t ring_off = op->ring_off, n_rings = op->n_rings;
+    const uint32_t blk_off = g_op_blk[o];
+    for (uint32_t pass = 0; pass * 4u < nsr; ++pass) {
+        const uint32_t srb = sr0 + pass * 4u;          /* first sub-tile row of the pass */
+        const int32_t ybase = (int32_t)(srb * SUBH);
+        const int32_t y = ybase + (int32_t)lane;
+        const uint32_t sr = srb + (lane >> OSMT_SUB_H_LOG2);
+        const bool row_valid = sr < sr0 + nsr;
+        uint32_t cnt = 0;
+        uint32_t e_base = 0;
+        for (uint32_t r = 0; r < n_rings; ++r) {
+            const osmt_ring ring = g_rings[ring_off + r];
+            if (ring.n_pts < 2u) continue;
+            const uint32_t ne = ring.n_pts - 1u;
+            for (uint32_t e = 0; e < ne; ++e) {
+                if (blk_off != 0xFFFFFFFFu && ((e_base + e) & 63u) == 0u) {
+                    /* long op: skip the 64-edge block when none of its edges has a record on this pass's rows
+                     * (rows carrying records of an edge: ytop < y <= ybot) */
+                    const osmt_blk_bbox bb = g_blk[blk_off + ((e_base + e) >> 6)];
+                    if (bb.y1 < ybase || bb.y0 >= ybase + 63) {
+                        const uint32_t skip = min(64u, ne - e);
+                        e += skip - 1u;
+                        continue;
+                    }
+                }
+                const int2 p1 = g_pts[ring.first_pt + e];
+                const int2 p2 = g_pts[ring.first_pt + e + 1];
+                if (max(p1.y, p2.y) < ybase || min(p1.y, p2.y) >= ybase + 63) continue; /* wave-uniform */
+                int32_t xmn, xmx;
+                if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, y, &xmn, &xmx)) {
+                    if (cnt < (uint32_t)ROWCAP) {
+                        sh.xmin[cnt][lane] = xmn;
+                        sh.xmax[cnt][lane] = xmx;
+                    }
+                    ++cnt;
+                }
+            }
+            e_base += ne;
+        }
+        if (cnt <= (uint32_t)ROWCAP) {
+            /* stable insertion sort by x_min: equal keys keep edge order (fill.rs:24-25) */
+            for (uint32_t i = 1; i < cnt; ++i) {
+                const int32_t kx = sh.xmin[i][lane], km = sh.xmax[i][lane];
+                int32_t j = (int32_t)i - 1;
+                while (j >= 0 && sh.xmin[j][lane] > kx) {
+                    sh.xmin[j + 1][lane] = sh.xmin[j][lane];
+                    sh.xmax[j + 1][lane] = sh.xmax[j][lane];
+                    --j;
+                }
+                sh.xmin[j + 1][lane] = kx;
+                sh.xmax[j + 1][lane] = km;
+            }
+        }
+        uint32_t hit0 = 0u, hit1 = 0u, hit2 = 0u, hit3 = 0u; /* per sub-tile row of the pass: columns with coverage */
+        for (uint32_t c = 0; c < ncols; ++c) {
+            const int32_t x0 = (int32_t)((c0 + c) * SUB), x1 = x0 + SUB - 1;
+            uint32_t m = 0u;
+            if (cnt <= (uint32_t)ROWCAP) {
+                for (uint32_t k = 0; k + 1u < cnt; k += 2u) { /* fill.rs:27-45: pairs; an odd trailing record is ignored */
+                    const int32_t from = max(sh.xmin[k][lane], x0);
+                    const int32_t to = min(sh.xmax[k + 1u][lane], x1);
+                    if (from <= to) {
+                        const uint32_t len = (uint32_t)(to - from + 1);
+                        const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                        m |= bits << (uint32_t)(from - x0);
+                    }
+                }
+            } else {
+                /* more than ROWCAP crossings on this row: storage-free streaming (cold, out of line) */
+                m = fill_row_streaming(g_rings, g_pts, ring_off, n_rings, y, x0, x1);
+            }
+            if (row_valid) g_fmask[((size_t)arena + (size_t)(sr - sr0) * ncols + c) * SUBH + (lane & (SUBH - 1u))] = m;
+            const unsigned long long bal = __ballot(row_valid && m != 0u);
+            const uint32_t bit = 1u << (c0 + c);
+            if (bal & 0x000000000000FFFFull) hit0 |= bit;
+            if (bal & 0x00000000FFFF0000ull) hit1 |= bit;
+            if (bal & 0x0000FFFF00000000ull) hit2 |= bit;
+            if (bal & 0xFFFF000000000000ull) hit3 |= bit;
+        }
+        if (lane == 0u) {
+            uint32_t* sm = g_submask + (size_t)o * sub_rows + srb;
+            sm[0] = hit0;
+            if (srb + 1u < sr0 + nsr) sm[1] = hit1;
+            if (srb + 2u < sr0 + nsr) sm[2] = hit2;
+            if (srb + 3u < sr0 + nsr) sm[3] = hit3;
+        }
+    }
+}
+
+/* ---- k_stroke_bin: which sub-tiles a stroke segment draws into, and with which runs ----------------------------
+ * One thread per VIRTUAL SEGMENT of the scene (an edge of a stroke op, or one of its two cap stubs, line.rs:33-57),
+ * found by bisection of the host-built prefix table.  For every sub-tile of the segment's window the thread derives
+ * the ranges of perpendicular runs that can reach it (seg_ranges) and, when there are any, appends a record to the
+ * op's slice of the stroke arena and sets the op's bit for that sub-tile.  k_raster's waves then only FILTER the
+ * records of the ops they meet (one coalesced key load per 64 records) instead of each re-deriving the ranges of
+ * every segment of every op that comes near: the work is done once per (segment, sub-tile), with full lanes. */
+__global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g_ops, const osmt_opinfo* __restrict__ g_info,
+                                                   const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
+                                                   const double* __restrict__ g_trav, const double* __restrict__ g_den,
+                                                   const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
+                                                   const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_stroke_op,
+                                                   uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale, uint32_t sub_rows,
+                                                   uint32_t* __restrict__ g_submask, uint32_t* __restrict__ g_rec_n,
+                                                   osmt_srec* __restrict__ g_srec, uint32_t* __restrict__ g_skey) {
+    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= n_vsegs) return;
+    uint32_t lo = 0u, hi = n_strokes; /* largest slot with vseg_base[slot] <= g */
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g_vseg_base[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t v = g - g_vseg_base[lo];
+    const uint32_t o = g_stroke_op[lo];
+    const osmt_opinfo oi = g_info[o];
+    osmt_srec rec;
+    rec.caps_table = 0u;
+    rec.traveled = 0.0;
+    if (v < oi.n_edges) {
+        /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
+        const osmt_op* __restrict__ op = &g_ops[o];
+        uint32_t r = 0, e = v;
+        osmt_ring ring = g_rings[op->ring_off];
+        while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < op->n_rings) {
+            if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
+            ring = g_rings[op->ring_off + ++r];
+        }
+        const int2 p1 = g_pts[ring.first_pt + e];
+        const int2 p2 = g_pts[ring.first_pt + e + 1];
+        rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
+        rec.traveled = g_trav[ring.first_pt + e];
+        rec.denom = g_den[ring.first_pt + e];
+        rec.rdenom = g_rden[ring.first_pt + e];
+    } else {
+        const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
+        if (!cs.valid) return;
+        rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
+        rec.denom = cs.denom;
+        rec.rdenom = 1.0 / cs.denom;
+        rec.caps_table = 1u;
+    }
+    if (rec.p1x == rec.p2x && rec.p1y == rec.p2y) return; /* line.rs:73-75 */
+    const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
+    const int32_t n_sub_x = W / SUB, n_sub_y = (int32_t)sub_rows;
+    const SubWindow w = vseg_window(rec.p1x, rec.p1y, rec.p2x, rec.p2y, oi.reach, n_sub_x, n_sub_y);
+    for (int32_t sy = w.sy0; sy <= w.sy1; ++sy) {
+        uint32_t rowbits = 0u;
+        for (int32_t sx = w.sx0; sx <= w.sx1; ++sx) {
+            SubRect rc;
+            rc.x0 = sx * SUB;
+            rc.y0 = sy * SUBH;
+            rc.x1 = rc.x0 + SUB - 1;
+            rc.y1 = rc.y0 + SUBH - 1;
+            const uint32_t cnt = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, oi.reach, oi.reach_major, rc, &rec);
+            if (cnt == 0u) continue;
+            const uint32_t slot = atomicAdd(&g_rec_n[o], 1u);
+            if (slot >= oi.rec_cap) continue; /* never: the reservation counts this very window */
+            rec.count = cnt;
+            g_srec[(size_t)oi.arena_off + slot] = rec;
+            g_skey[(size_t)oi.arena_off + slot] = (uint32_t)(sy * n_sub_x + sx);
+            rowbits |= 1u << sx;
+        }
+        if (rowbits) atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
+    }
+}
+
+/* Scenes are rendered by waves that each own one 32x16 sub-tile for the whole display list: the premultiplied f64
+ * accumulators of their pixels live in registers from reset() to to_rgb_triples().  The pre-pass has already decided
+ * what every op does where: fills arrive as 16 coverage words per (op, sub-tile) (k_fill_rows), strokes as records
+ * of perpendicular-run ranges per (segment, sub-tile) (k_stroke_bin).  What is left here is the part that needs the
+ * pixels: walking the runs of a generation into the LDS alpha plane (set_pixel keeps the larger alpha,
+ * tile_pixels.rs:114-118) and blending generation after generation in order (tile_pixels.rs:205-223). */
+template <bool OUT_F64, bool LABELS>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
-    /* separate __restrict__ const pointers (not a struct): lets the compiler prove the display
-     * list is read-only and fetch wave-uniform records with scalar loads */
-    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_op* OSMT_R g_ops,
-    const osmt_opinfo* OSMT_R g_info, const osmt_ring* OSMT_R g_rings, const int2* OSMT_R g_pts,
-    const double* OSMT_R g_trav, const double* OSMT_R g_den, const osmt_stroke_aux* OSMT_R g_aux,
-    const uint8_t* OSMT_R g_opnv, const uint32_t* OSMT_R g_op_blk, const osmt_blk_bbox* OSMT_R g_blk,
-    const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows, const osmt_image_desc* OSMT_R g_images,
-    const double4* OSMT_R g_image_pool, uint32_t g_n_images, void* OSMT_R g_out,
-    size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab, const uint32_t* OSMT_R g_job_label_off,
-    const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt, const double* OSMT_R g_lab_plane) {
+    /* separate __restrict__ const pointers (not a struct): lets the compiler prove the tables are
+     * read-only and fetch wave-uniform records with scalar loads */
+    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_opinfo* OSMT_R g_info,
+    const osmt_stroke_aux* OSMT_R g_aux, const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows,
+    const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint32_t* OSMT_R g_skey,
+    const uint32_t* OSMT_R g_rec_n, const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
+    uint32_t g_n_images, void* OSMT_R g_out, size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab,
+    const uint32_t* OSMT_R g_job_label_off, const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt,
+    const double* OSMT_R g_lab_plane) {
     __shared__ RasterShared sh;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lane = tid;
     const uint32_t W = OSMT_TILE_SIZE * g_scale;
     const uint32_t subs_per_row = W / SUB;
     const uint32_t nsub = subs_per_row * (W / SUBH);
 
     /* XCD-aware block -> (tile, sub-tile): blocks b, b+8, b+16.. land on one XCD, so give
-     * them the sub-tiles of the same tiles (they share that tile's display list in L2). */
+     * them the sub-tiles of the same tiles (they share that tile's tables in L2). */
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u;
     const uint32_t rest = b >> 3;
@@ -748,7 +914,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     rc.x1 = rc.x0 + SUB - 1;
     rc.y1 = rc.y0 + SUBH - 1;
 
-    /* thread -> pixels: column lx, rows ly0 + 8*j; a wave covers two full 128-byte rows */
+    /* thread -> pixels: column lx, rows ly0 + 2*j; a wave covers two full 128-byte rows */
     const uint32_t lx = tid & (SUB - 1);
     const uint32_t ly0 = tid / SUB;
 
@@ -772,49 +938,43 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
-    if (tid < SUBH) sh.rowcnt[tid] = 0u;
-    __syncthreads();
 
-    uint32_t buf = 0;
     for (uint32_t base = 0; base < job.n_ops; base += OPCHUNK) {
-        /* ---- ordered compaction of the ops whose extent touches this sub-tile ---- */
+        /* ---- ordered compaction of the ops that draw into this sub-tile (exact bits from the binning kernels) ---- */
         const uint32_t oi_idx = base + tid;
         bool hit = false;
-        uint32_t my_nv = 0;
+        uint32_t my_nv = 0, my_arena = 0;
         if (oi_idx < job.n_ops) {
             hit = (g_submask[(size_t)(job.op_off + oi_idx) * g_sub_rows + sub_y] >> sub_x) & 1u;
-            if (hit) my_nv = g_opnv[job.op_off + oi_idx];
+            if (hit) {
+                my_nv = min(g_rec_n[job.op_off + oi_idx], 255u); /* 0: a fill */
+                my_arena = g_info[job.op_off + oi_idx].arena_off;
+            }
         }
         const unsigned long long bal = __ballot(hit);
-        if (lane == 0) sh.wcount[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t off = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < (NTHREADS + 63) / 64; ++w) {
-            const uint32_t cnt = sh.wcount[w];
-            if (w < wave) off += cnt;
-            total += cnt;
-        }
+        const uint32_t total = (uint32_t)__popcll(bal);
+        if (total == 0u) continue;
+        __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
-            const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            const uint32_t pos = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             sh.oplist[pos] = oi_idx;
-            sh.opnv[pos] = (uint8_t)my_nv;
+            sh.opnv[pos] = (uint8_t)(my_nv > 64u ? 255u : my_nv);
+            sh.oparena[pos] = my_arena;
         }
         const bool any_stroke = __ballot(hit && my_nv != 0u) != 0ull;
         if (any_stroke && !plane_clean) {
-            for (uint32_t i = tid; i < NBUF * SUB * SUBH; i += NTHREADS) (&sh.plane[0][0])[i] = 0ull;
+            for (uint32_t i = tid; i < SUB * SUBH; i += NTHREADS) sh.plane[i] = 0ull;
             plane_clean = true;
         }
         __syncthreads();
-        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
 
         uint32_t g0 = 0;
         while (g0 < total) {
-        /* ---- group = consecutive list entries whose stroke segments (edges + cap stubs) fit in the
-         * 64 lanes of ONE record pass; a stroke op with more segments (or several rings) forms a
-         * group of its own and takes the chunked per-op path below ------------------------------ */
-        uint32_t gend = g0, V = 0;
+        /* ---- group = consecutive list entries whose stroke records fit in the 64 lanes of ONE filter pass;
+         * an op with more than 64 records forms a group of its own and is filtered 64 records at a time ---- */
+        uint32_t gend = g0, V = 0, n_str = 0;
         bool big = false;
+        unsigned long long starts = 0ull; /* bit V_j for every stroke entry j of the group */
         if (!any_stroke) {
             gend = total; /* fills only: one group, nothing to lay out */
         } else {
@@ -828,105 +988,67 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     break;
                 }
                 if (V + nv > 64u) break;
-                if (lane == 0) sh.grp_base[gend - g0] = V;
+                if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
+                if (nv) {
+                    starts |= 1ull << V;
+                    if (lane == 0) sh.s_ent[n_str] = (uint8_t)(gend - g0);
+                    ++n_str;
+                }
                 V += nv;
             }
-            if (lane == 0) sh.grp_base[gend - g0] = V;
+            if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
             __syncthreads();
         }
-        /* A normal group's records are produced by ONE pass (at its first stroke op) in which lane
-         * -> (list entry, virtual segment) through grp_base; a big op runs one pass per 64 of its
-         * own virtual segments.  Same code, one call site. */
         unsigned long long gbal = 0ull;
-        uint32_t gincl = 0;
         bool records_ready = false;
 
         for (uint32_t li = g0; li < gend; ++li) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
-            const osmt_op* __restrict__ op = &g_ops[o];
-            const uint32_t kind = op->kind;
+            const osmt_opinfo* __restrict__ oi = &g_info[o];
+            const uint32_t kind = oi->kind;
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
-                const osmt_opinfo* __restrict__ oi = &g_info[o];
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[oi->aux];
                 const bool plain_main = sa->main.n_segs == 0;
-                const double initial_opacity = op->opacity;
+                const double initial_opacity = oi->opacity;
                 const int32_t reach = oi->reach;
-                unsigned long long* plane = sh.plane[buf];
-                const bool has_caps = (op->cap == OSMT_CAP_ROUND || op->cap == OSMT_CAP_SQUARE);
-                const uint32_t nv_op = oi->n_edges + (has_caps ? 2u : 0u);
-                const uint32_t n_rounds = big ? (nv_op + 63u) / 64u : 1u;
-                const uint32_t blk_off = (BLOCKS && big) ? g_op_blk[o] : 0xFFFFFFFFu;
+                const uint32_t nrec_op = big ? g_rec_n[o] : 0u;
+                const uint32_t n_rounds = big ? (nrec_op + 63u) / 64u : 1u;
                 for (uint32_t round = 0; round < n_rounds; ++round) {
-                    if (blk_off != 0xFFFFFFFFu && (round + 1u) * 64u <= oi->n_edges) {
-                        /* a round made of edges only (the cap stubs live in the last round): skip it when
-                         * the block's box, grown by the reach of a run, misses the sub-tile */
-                        const osmt_blk_bbox bb = g_blk[blk_off + round];
-                        if (bb.x1 + reach < rc.x0 || bb.x0 - reach > rc.x1 || bb.y1 + reach < rc.y0 || bb.y0 - reach > rc.y1)
-                            continue;
-                    }
                     if (big || !records_ready) {
-                        /* ---- record pass: one lane per virtual segment (an edge, or one of the two cap
-                         * stubs precomputed by k_opinfo, line.rs:33-57): cull, item ranges, record ---- */
+                        /* ---- filter pass: lane -> (list entry, record of that op); keep the records of THIS
+                         * sub-tile, compact them in lane order (= op order) and prefix-sum their item counts ---- */
                         if (big) __syncthreads(); /* previous round's records are consumed */
-                        SegRec rec;
-                        rec.count = 0;
-                        rec.p1x = rec.p1y = rec.p2x = rec.p2y = 0;
-                        rec.traveled = 0.0;
-                        rec.denom = 1.0;
-                        rec.caps_table = 0u;
-                        uint32_t lo = o, v = round * 64u + lane; /* big: this op, its round-th 64 segments */
-                        bool valid = v < nv_op;
-                        if (!big) {
-                            valid = lane < V;
-                            uint32_t j = 0;
-                            const uint32_t gn = gend - g0;
-                            while (j + 1u < gn && sh.grp_base[j + 1u] <= lane) ++j; /* last entry with base <= lane */
-                            lo = job.op_off + sh.oplist[g0 + j];
-                            v = lane - sh.grp_base[j];
+                        uint32_t ridx = 0xFFFFFFFFu;
+                        if (big) {
+                            const uint32_t v = round * 64u + lane;
+                            if (v < nrec_op) ridx = oi->arena_off + v;
+                        } else if (lane < V) {
+                            /* entry = the k-th stroke of the group, k = strokes starting at or below this lane */
+                            const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
+                            const uint32_t k = (uint32_t)__popcll(starts & below) - 1u;
+                            const uint32_t j = sh.s_ent[k];
+                            ridx = sh.oparena[g0 + j] + (lane - sh.grp_base[j]);
                         }
-                        if (valid) {
-                            const osmt_opinfo loi = g_info[lo];
-                            const osmt_op* lop = &g_ops[lo];
-                            const uint32_t ne_all = loi.n_edges;
-                            bool live = false;
-                            if (v < ne_all) {
-                                /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
-                                uint32_t r = 0, e = v;
-                                osmt_ring ring = g_rings[lop->ring_off];
-                                while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < lop->n_rings) {
-                                    if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
-                                    ring = g_rings[lop->ring_off + ++r];
-                                }
-                                const int2 p1 = g_pts[ring.first_pt + e];
-                                const int2 p2 = g_pts[ring.first_pt + e + 1];
-                                rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
-                                rec.traveled = g_trav[ring.first_pt + e];
-                                rec.denom = g_den[ring.first_pt + e];
-                                live = true;
-                            } else {
-                                const osmt_cap_seg cs = g_aux[loi.aux].cap_seg[v - ne_all];
-                                rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
-                                rec.denom = cs.denom;
-                                rec.caps_table = 1u;
-                                live = cs.valid != 0;
-                            }
-                            if (live)
-                                rec.count = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, loi.reach, loi.reach_major, rc, &rec);
-                        }
-                        gbal = __ballot(rec.count > 0u);
-                        if (rec.count > 0u) sh.seg[__popcll(gbal & ((1ull << lane) - 1ull))] = rec;
-                        gincl = rec.count; /* inclusive prefix of the item counts over the lanes */
+                        uint32_t cnt = 0;
+                        if (ridx != 0xFFFFFFFFu && g_skey[ridx] == sub) cnt = g_srec[ridx].count;
+                        gbal = __ballot(cnt > 0u);
+                        uint32_t incl = cnt; /* inclusive prefix of the item counts over the lanes */
 #pragma unroll
                         for (uint32_t d = 1; d < 64u; d <<= 1) {
-                            const uint32_t y = __shfl_up(gincl, d);
-                            if (lane >= d) gincl += y;
+                            const uint32_t y = __shfl_up(incl, d);
+                            if (lane >= d) incl += y;
+                        }
+                        if (cnt > 0u) {
+                            const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << lane) - 1ull));
+                            sh.seg[slot] = g_srec[ridx];
+                            sh.pre[slot] = incl;
                         }
                         records_ready = true;
                         __syncthreads();
                     }
-                    /* the op's records are lanes [va, vb) of the record pass */
-                    uint32_t va = 0, vb = min(64u, nv_op - round * 64u);
+                    /* the op's records are lanes [va, vb) of the filter pass */
+                    uint32_t va = 0, vb = 64u;
                     if (!big) {
                         va = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0]);
                         vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0 + 1u]);
@@ -934,149 +1056,73 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     if (vb > va) {
                         const unsigned long long lanes_ab =
                             ((vb >= 64u) ? ~0ull : ((1ull << vb) - 1ull)) & ~((1ull << va) - 1ull);
-                        const unsigned long long mask = gbal & lanes_ab;
-                        const uint32_t item_lo = va ? (uint32_t)__builtin_amdgcn_readlane((int)gincl, (int)va - 1) : 0u;
-                        const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readlane((int)gincl, (int)vb - 1);
                         const uint32_t slot0 = (uint32_t)__popcll(gbal & ((1ull << va) - 1ull));
-                        /* all (record, item) pairs of this op, lanes packed */
-                        for (uint32_t it = item_lo + lane; it < item_hi; it += 64u) {
-                            /* record of item `it`: walk the (wave-uniform) record lanes of this op and
-                             * compare with each one's inclusive item prefix, read with v_readlane */
-                            uint32_t j = slot0, base_items = item_lo;
-                            for (unsigned long long rem = mask; rem != 0ull; rem &= rem - 1ull) {
-                                const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)gincl, __builtin_ctzll(rem));
-                                if (it >= pv) {
-                                    ++j;
-                                    base_items = pv;
+                        const uint32_t nslot = (uint32_t)__popcll(gbal & lanes_ab);
+                        if (nslot) {
+                            const uint32_t item_lo = slot0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 - 1u]) : 0u;
+                            const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + nslot - 1u]);
+                            /* all (record, item) pairs of this op, lanes packed: record of item `it` = first slot whose
+                             * inclusive prefix exceeds it (bisection over the LDS prefix) */
+                            for (uint32_t it = item_lo + lane; it < item_hi; it += 64u) {
+                                uint32_t lo_s = slot0, n = nslot;
+                                while (n > 1u) {
+                                    const uint32_t half = n >> 1;
+                                    const bool right = sh.pre[lo_s + half - 1u] <= it;
+                                    lo_s = right ? lo_s + half : lo_s;
+                                    n = right ? n - half : half;
                                 }
+                                const uint32_t base_items = (lo_s == slot0) ? item_lo : sh.pre[lo_s - 1u];
+                                walk_item(sh.seg[lo_s], it - base_items, plain_main, sa, initial_opacity, reach, rc, sh.plane);
                             }
-                            const SegRec q = sh.seg[j];
-                            walk_item(q, it - base_items, plain_main, sa, initial_opacity, reach, rc, plane);
                         }
                     }
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
-                const double cr = (double)op->color[0] / 255.0;
-                const double cg = (double)op->color[1] / 255.0;
-                const double cb = (double)op->color[2] / 255.0;
+                const double cr = (double)oi->color[0] / 255.0;
+                const double cg = (double)oi->color[1] / 255.0;
+                const double cb = (double)oi->color[2] / 255.0;
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) {
                     const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * SUB + lx;
-                    const unsigned long long bits = plane[idx];
+                    const unsigned long long bits = sh.plane[idx];
                     if (bits != 0ull) {
-                        plane[idx] = 0ull;
-                        const double a = __longlong_as_double((long long)bits);
-                        blend_rgb(acc[j], a * cr, a * cg, a * cb, a); /* from_color: o * (c/255) */
+                        sh.plane[idx] = 0ull;
+                        const double al = __longlong_as_double((long long)bits);
+                        blend_rgb(acc[j], al * cr, al * cg, al * cb, al); /* from_color: o * (c/255) */
                     }
                 }
-                if (NBUF == 1) __syncthreads(); /* plane/mask reused by the next op */
-                buf = (buf + 1u) % NBUF;
+                __syncthreads(); /* the plane is reused by the next op */
             } else {
-                /* ---------------- fill_contour (fill.rs:16-47) ---------------- */
-                /* A: every (edge, row) pair -> un-poisoned Edge{x_min,x_max} record of that row.  Ops
-                 * with more than 64 edges are walked block by block (64 running edge indices), skipping
-                 * the blocks whose rows cannot meet the sub-tile's rows (x does not matter: crossings
-                 * left or right of the sub-tile still decide the parity). */
-                /* only ops with more than 64 edges have blocks: do not even load the offset for a
-                 * single short ring (every polygon of the named configs) */
-                const bool maybe_long = BLOCKS && (op->n_rings > 1u || g_rings[op->ring_off].n_pts > 65u);
-                const uint32_t fblk_off = maybe_long ? g_op_blk[o] : 0xFFFFFFFFu;
-                uint32_t e_base = 0;
-                for (uint32_t r = 0; r < op->n_rings; ++r) {
-                    const osmt_ring ring = g_rings[op->ring_off + r];
-                    if (ring.n_pts < 2) continue;
-                    const uint32_t ne = ring.n_pts - 1;
-                    /* pieces of this ring: the whole ring (short ops), or its intersections with the
-                     * 64-edge blocks that can meet this sub-tile's rows (long ops) */
-                    uint32_t b_first = 0, b_last = 0;
-                    if (BLOCKS && fblk_off != 0xFFFFFFFFu) {
-                        b_first = e_base >> 6;
-                        b_last = (e_base + ne - 1u) >> 6;
-                    }
-                    for (uint32_t bk = b_first; bk <= b_last; ++bk) {
-                        uint32_t e_lo = 0, n_items = ne * SUBH; /* ring-local first edge, (edge,row) items */
-                        if (BLOCKS && fblk_off != 0xFFFFFFFFu) {
-                            const osmt_blk_bbox bb = g_blk[fblk_off + bk];
-                            /* rows carrying records of an edge: ytop < y <= ybot */
-                            if (bb.y1 < rc.y0 || bb.y0 >= rc.y1) continue;
-                            e_lo = max(bk << 6, e_base) - e_base;
-                            n_items = (min((bk + 1u) << 6, e_base + ne) - e_base - e_lo) * SUBH;
-                        }
-                        for (uint32_t it = tid; it < n_items; it += NTHREADS) {
-                            const uint32_t e = e_lo + it / SUBH, row = it % SUBH;
-                            const int2 p1 = g_pts[ring.first_pt + e];
-                            const int2 p2 = g_pts[ring.first_pt + e + 1];
-                            int32_t xmn, xmx;
-                            if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, rc.y0 + (int32_t)row, &xmn, &xmx)) {
-                                const uint32_t slot = atomicAdd(&sh.rowcnt[row], 1u);
-                                if (slot < ROWCAP) {
-                                    sh.rec[row][slot].x_min = xmn;
-                                    sh.rec[row][slot].x_max = xmx;
-                                    sh.rec[row][slot].edge = e_base + e;
-                                }
-                            }
-                        }
-                    }
-                    e_base += ne;
-                }
-                __syncthreads();
-                /* B: per row: order by (x_min, edge index) == stable sort_by_key(x_min) of records
-                 * inserted in edge order (fill.rs:24-25), pair (0,1),(2,3).., OR the spans */
-                if (tid < SUBH) {
-                    const uint32_t row = tid;
-                    const uint32_t n = sh.rowcnt[row];
-                    uint32_t m = 0u;
-                    if (n <= ROWCAP) {
-                        RowRec* rr = sh.rec[row];
-                        for (uint32_t i = 1; i < n; ++i) {
-                            const RowRec key = rr[i];
-                            int32_t j = (int32_t)i - 1;
-                            while (j >= 0 && (rr[j].x_min > key.x_min ||
-                                              (rr[j].x_min == key.x_min && rr[j].edge > key.edge))) {
-                                rr[j + 1] = rr[j];
-                                --j;
-                            }
-                            rr[j + 1] = key;
-                        }
-                        for (uint32_t k = 0; k + 1 < n; k += 2) {
-                            const int32_t from = max(rr[k].x_min, rc.x0);
-                            const int32_t to = min(rr[k + 1].x_max, rc.x1);
-                            if (from <= to) {
-                                const uint32_t len = (uint32_t)(to - from + 1);
-                                const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                                m |= bits << (uint32_t)(from - rc.x0);
-                            }
-                        }
-                    } else {
-                        /* slow path (more than ROWCAP crossings on a row): kept out of line — it is cold,
-                         * and inlined it would only add code and register pressure to the hot path */
-                        m = fill_row_streaming(g_rings, g_pts, op->ring_off, op->n_rings, rc.y0 + (int32_t)row, rc.x0, rc.x1);
-                    }
-                    sh.mask[buf][row] = m;
-                    sh.rowcnt[row] = 0u;
-                }
-                __syncthreads();
-                /* C: set_pixel + blend of the covered pixels */
-                if (kind == OSMT_OP_FILL_COLOR) {
-                    const double o_ = op->opacity;
-                    const double sr = o_ * ((double)op->color[0] / 255.0);
-                    const double sg = o_ * ((double)op->color[1] / 255.0);
-                    const double sb = o_ * ((double)op->color[2] / 255.0);
+                /* ---------------- fill_contour (fill.rs:16-47): coverage words from k_fill_rows ---------------- */
+                const uint32_t geom = oi->fill_geom;
+                const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
+                const uint32_t* __restrict__ mw = g_fmask + ((size_t)oi->arena_off + (size_t)(sub_y - sr0) * ncols + (sub_x - c0)) * SUBH;
+                uint32_t cov = 0u; /* bit j = this lane's pixel j is covered */
 #pragma unroll
-                    for (int j = 0; j < PXT; ++j) {
-                        const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
-                        if ((sh.mask[buf][row] >> lx) & 1u) blend_rgb(acc[j], sr, sg, sb, o_);
-                    }
+                for (int j = 0; j < PXT; ++j) {
+                    /* wave-uniform addresses (scalar loads); the lane picks the word of its row pair */
+                    const uint32_t w0 = mw[2 * j], w1 = mw[2 * j + 1];
+                    const uint32_t w = ly0 ? w1 : w0;
+                    cov |= ((w >> lx) & 1u) << j;
+                }
+                if (kind == OSMT_OP_FILL_COLOR) {
+                    const double o_ = oi->opacity;
+                    const double sr = o_ * ((double)oi->color[0] / 255.0);
+                    const double sg = o_ * ((double)oi->color[1] / 255.0);
+                    const double sb = o_ * ((double)oi->color[2] / 255.0);
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j)
+                        if ((cov >> j) & 1u) blend_rgb(acc[j], sr, sg, sb, o_);
                 } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
-                    const uint32_t img = op->image_id;
+                    const uint32_t img = oi->image_id;
                     if (img < g_n_images) {
                         const osmt_image_desc im = g_images[img];
                         const double4* __restrict__ ipx = g_image_pool + im.offset;
 #pragma unroll
                         for (int j = 0; j < PXT; ++j) {
-                            const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
-                            if ((sh.mask[buf][row] >> lx) & 1u) {
+                            if ((cov >> j) & 1u) {
+                                const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
                                 const uint32_t ix = (uint32_t)(rc.x0 + (int32_t)lx) % im.width;
                                 const uint32_t iy = (uint32_t)(rc.y0 + (int32_t)row) % im.height;
                                 const double4 c = ipx[(size_t)iy * im.width + ix];
@@ -1085,14 +1131,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         }
                     }
                 }
-                if (NBUF == 1) __syncthreads(); /* plane/mask reused by the next op */
-                buf = (buf + 1u) % NBUF;
             }
         }
         __syncthreads(); /* the group's records / bases are rewritten by the next group */
         g0 = gend;
         }
-        __syncthreads(); /* oplist is rewritten by the next chunk */
     }
 
     /* ---- label pass, blend_unfinished_pixels(true) (tile_pixels.rs:154-158,205-223) ----------
@@ -1250,13 +1293,17 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
     return hipGetLastError();
 }
 
-hipError_t osmt_launch_opinfo(const osmt_op* ops, uint32_t n_ops, const osmt_ring* rings, const int32_t* pts,
-                              const double* dashes, const uint32_t* op_aux, osmt_opinfo* info, double* trav,
-                              double* den, osmt_stroke_aux* aux, uint8_t* opnv, const uint32_t* op_blk, osmt_blk_bbox* blk,
-                              uint32_t* submask, uint32_t sub_rows, hipStream_t st) {
-    if (n_ops == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_opinfo, dim3((n_ops + 63u) / 64u), dim3(64), 0, st, ops, n_ops, rings,
-                       reinterpret_cast<const int2*>(pts), dashes, op_aux, info, trav, den, aux, opnv, op_blk, blk, submask, sub_rows);
+hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(a.cursors, 0, 2 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    if (a.n_ops == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
+    if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
+    hipLaunchKernelGGL(k_fill_rows, dim3(a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.op_blk, a.blk, a.submask,
+                       a.sub_rows, a.fmask);
+    if (a.n_vsegs)
+        hipLaunchKernelGGL(k_stroke_bin, dim3((a.n_vsegs + 63u) / 64u), dim3(64), 0, st, a.ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden,
+                           a.aux, a.vseg_base, a.stroke_op, a.n_strokes, a.n_vsegs, a.scale, a.sub_rows, a.submask, a.rec_n, a.srec, a.skey);
     return hipGetLastError();
 }
 
@@ -1266,18 +1313,17 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
-#define OSMT_LAUNCH_RASTER(F64, BLK, LAB)                                                                             \
-    hipLaunchKernelGGL((k_raster<F64, BLK, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.ops, a.info, \
-                       a.rings, a.pts, a.trav, a.den, a.aux, a.opnv, a.op_blk, a.blk, a.submask, a.sub_rows, a.images,    \
-                       a.image_pool, a.n_images, a.out, a.out_tile_stride, a.labels.info, a.labels.job_label_off,         \
-                       a.labels.tile_labels, a.labels.tile_label_cnt, a.labels.plane)
-    if (out_f64) { /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
-        if (a.has_blocks) OSMT_LAUNCH_RASTER(true, true, false); else OSMT_LAUNCH_RASTER(true, false, false);
-    } else if (a.labels.info) {
-        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true, true); else OSMT_LAUNCH_RASTER(false, false, true);
-    } else {
-        if (a.has_blocks) OSMT_LAUNCH_RASTER(false, true, false); else OSMT_LAUNCH_RASTER(false, false, false);
-    }
+#define OSMT_LAUNCH_RASTER(F64, LAB)                                                                                   \
+    hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.info, a.aux, a.submask, \
+                       a.sub_rows, a.fmask, a.srec, a.skey, a.rec_n, a.images, a.image_pool, a.n_images, a.out,          \
+                       a.out_tile_stride, a.labels.info, a.labels.job_label_off, a.labels.tile_labels,                    \
+                       a.labels.tile_label_cnt, a.labels.plane)
+    if (out_f64) /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
+        OSMT_LAUNCH_RASTER(true, false);
+    else if (a.labels.info)
+        OSMT_LAUNCH_RASTER(false, true);
+    else
+        OSMT_LAUNCH_RASTER(false, false);
 #undef OSMT_LAUNCH_RASTER
     return hipGetLastError();
 }

