@@ -898,8 +898,33 @@ int osmt_validate_batch(const osmt_batch* b) {
     return guarded([&] { return validate_batch(b); });
 }
 
+/* Public scenes: the upload runs on a pooled private stream (never the NULL stream, whose copies order themselves
+ * against other workers' streams) and is complete when the call returns; the scene is then free to be rendered on any
+ * stream of the caller. */
+static int osmt_scene_upload_body(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
+    if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    HIP_TRY(stream_acquire(ctx, &st));
+    int rc = scene_upload_impl(ctx, b, out_scene, st);
+    if (rc == OSMT_OK) {
+        osmt_scene* s = *out_scene;
+        const hipError_t e = hipStreamSynchronize(st);
+        s->own_stream = nullptr; /* from here on a public scene: waits go through its last-use events */
+        stage_release(ctx, s->h_stage);
+        s->h_stage = nullptr;
+        if (e != hipSuccess) {
+            osmt_scene_free(s);
+            *out_scene = nullptr;
+            rc = fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    stream_release(ctx, st);
+    return rc;
+}
+
 int osmt_scene_upload(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene) {
-    return guarded([&] { return scene_upload_impl(ctx, b, out_scene, nullptr); });
+    return guarded([&] { return osmt_scene_upload_body(ctx, b, out_scene); });
 }
 
 void osmt_scene_free(osmt_scene* s) {
@@ -924,6 +949,21 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = sc->own_stream;
+    hipStream_t pooled = nullptr; /* public scene: copies on a private stream, complete on return (never the NULL stream) */
+    if (!st) {
+        HIP_TRY(stream_acquire(ctx, &pooled));
+        st = pooled;
+    }
+    struct release_pooled {
+        osmt_ctx* c;
+        hipStream_t s;
+        ~release_pooled() {
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                stream_release(c, s);
+            }
+        }
+    } pooled_guard{ctx, pooled};
     HIP_TRY(scene_wait_idle(sc)); /* the previous label pass of THIS scene may still be in flight; nobody else is waited for */
     dev_free(ctx, sc->d_lab_base);
     sc->d_lab_base = nullptr;

@@ -178,9 +178,11 @@ def test_config5_dense_city_at_stated_density(gpu_ctx, oracle):
 
 
 def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx):
-    """osmt_scene_set_labels / osmt_scene_read_label_status / osmt_scene_free of one worker's scene wait for THAT
-    scene's launches only (events), not for the device: while one thread keeps a long queue of renders in flight
-    on its stream, another thread's label round trips on a small scene finish long before that queue drains."""
+    """osmt_scene_upload / osmt_scene_set_labels / osmt_scene_read_label_status / osmt_scene_read_points /
+    osmt_scene_free of one worker's scene wait for THAT scene's launches only (per-stream events, private copy
+    streams), never for the device: while the main thread keeps ~0.3 s of renders queued on its stream, another
+    thread's calls on its own scenes return in milliseconds.  (Kernels of two streams may still share a hardware
+    queue — that is the GPU's scheduling, not a synchronisation inside the library — so the worker launches none.)"""
     import threading
     import time
 
@@ -192,27 +194,29 @@ def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx
     big_out = torch.empty((1024, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
     s_big = torch.cuda.Stream(device=gpu_ctx.device)
     gpu_ctx.render(big, big_out, stream=s_big)
-    torch.cuda.synchronize()
     small_dl = synth.config2(2)
     small_ll = labels.make_labels(2, labels_per_tile=6, seed=9)
     small_out = torch.empty((2, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
-    lat = []
-
     s = torch.cuda.Stream(device=gpu_ctx.device)
     sc = gpu_ctx.upload(small_dl)
-    # one warm-up round trip: first-use costs of the runtime (hipMalloc of the label buffers, kernel attributes) are
-    # not what this test is about — a server pays them once at start-up
+    # one complete round trip before the clock starts: first-use costs of the runtime (hipMalloc of the label buffers,
+    # kernel attributes) are paid once at start-up by a server too, and the scene now has finished launches to wait for
     sc.set_labels(small_ll)
     gpu_ctx.render(sc, small_out, stream=s)
-    sc.label_status()
+    want_status = sc.label_status()
+    torch.cuda.synchronize()
+    lat = []
 
     def worker():
         for _ in range(5):
             t0 = time.perf_counter()
-            sc.set_labels(small_ll)
-            gpu_ctx.render(sc, small_out, stream=s)
-            sc.label_status()
-            lat.append(time.perf_counter() - t0)
+            sc.set_labels(small_ll)            # waits for sc's own last launches (finished), copies on a private stream
+            st = sc.label_status()             # verdicts of the last render of THIS scene
+            pts = gpu_ctx.read_points(sc)
+            tmp = gpu_ctx.upload(small_dl)     # a fresh scene: upload, sizing, free
+            tmp.free()
+            lat.append(round(time.perf_counter() - t0, 5))
+            assert len(st) == len(want_status) and pts.shape[0] == len(small_dl.coords)
 
     n_queue = 150  # ~1.9 ms each: ~0.3 s of queued work on s_big
     t0 = time.perf_counter()
@@ -227,5 +231,5 @@ def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx
     sc.free()
     big.free()
     assert len(lat) == 5
-    # with a device-wide synchronisation inside the calls the worker could not finish before the big queue did
-    assert t_worker_done < 0.6 * t_queue_done, (t_worker_done, t_queue_done, lat)
+    # with a device-wide synchronisation inside any of the calls the worker could not finish before the big queue did
+    assert t_worker_done < 0.5 * t_queue_done, (t_worker_done, t_queue_done, lat)
