@@ -121,7 +121,7 @@ struct osmt_scene {
     uint32_t* d_op_job = nullptr;
     uint32_t* d_vseg_base = nullptr;
     uint32_t* d_stroke_op = nullptr;
-    uint32_t* d_rec_n = nullptr;
+    uint32_t* d_cand_off = nullptr;
     unsigned long long* d_cursors = nullptr;
     uint32_t n_vsegs = 0;
     /* the two arenas of the pre-pass (fill coverage words, stroke records + keys): one allocation, sized at upload */
@@ -434,6 +434,8 @@ int validate_batch(const osmt_batch* b) {
             return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be in [0, 2^52]", j, k);
         if (op.kind == OSMT_OP_STROKE) {
             if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
+            /* the per-segment reach bounds of the stroke cull are kept in 16 bits (osmt_reach_of); 4x the largest tile */
+            if (std::fabs(op.width) > 65536.0) return fail(OSMT_UNSUPPORTED, "job %zu op %u: |width| > 65536 px", j, k);
             if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
             if (op.has_dashes) {
                 /* Some([]) panics in the reference (opacity_calculator.rs:109 indexes dashes[0]) */
@@ -490,7 +492,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.aux = sc->d_aux;
     a.blk = sc->d_blk;
     a.submask = sc->d_submask;
-    a.rec_n = sc->d_rec_n;
+    a.cand_off = sc->d_cand_off;
     a.cursors = sc->d_cursors;
     a.fmask = sc->d_fmask;
     a.srec = sc->d_srec;
@@ -558,7 +560,6 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
-        a.rec_n = sc->d_rec_n;
         a.images = img.desc;
         a.image_pool = img.pool;
         a.n_images = img.n;
@@ -792,7 +793,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     const size_t o_rden = carve(b->n_pts * 8);
-    const size_t o_recn = carve(((size_t)b->n_ops + 1) * 4);
+    const size_t o_candoff = carve(((size_t)b->n_pts + 1) * 4);
     const size_t o_cursors = carve(16);
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
@@ -821,7 +822,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
     s->d_vseg_base = (uint32_t*)(s->d_base + o_vsegbase);
     s->d_stroke_op = (uint32_t*)(s->d_base + o_strokeop);
-    s->d_rec_n = (uint32_t*)(s->d_base + o_recn);
+    s->d_cand_off = (uint32_t*)(s->d_base + o_candoff);
     s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {

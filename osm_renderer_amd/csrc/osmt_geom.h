@@ -98,6 +98,25 @@ OSMT_HD double osmt_fmod_pos(double x, double y) {
     return r;
 }
 
+/* Correctly rounded n / d — bit-identical to the IEEE division the reference performs for center_distance
+ * (line.rs:116-118) — from the correctly rounded reciprocal r = RN(1 / d), which the pre-pass computes ONCE per
+ * segment with a real division: one multiply and two residual corrections, five full-rate instructions instead of
+ * the ~12 (one of them the quarter-rate v_rcp_f64) of the generic expansion, per visited pixel.
+ * Why it is exact (Markstein; Muller et al., Handbook of Floating-Point Arithmetic, "division with an FMA"): with
+ * r within half an ulp of 1/d, q0 = RN(n*r) is within 2 ulps of n/d; e0 = n - d*q0 comes out of the FMA with at
+ * most one rounding of a quantity 2^-52 smaller than n, so q1 = RN(q0 + e0*r) is a faithful rounding of n/d; for a
+ * faithful q1 the residual e1 = n - d*q1 is exactly representable and q2 = RN(q1 + e1*r) is RN(n/d).  Requires
+ * finite operands, d >= 1, n >= 0 and no overflow/underflow — here d = |p2 - p1| in [1, 2^30], n = |cross product|
+ * <= 2^60, and any nonzero quotient is >= 2^-30.  Brute-forced against the hardware division in
+ * tests/test_geom_closed_forms.py. */
+OSMT_HD double osmt_div_exact(double n, double d, double r) {
+    const double q0 = n * r;
+    const double e0 = fma(-d, q0, n);
+    const double q1 = fma(e0, r, q0);
+    const double e1 = fma(-d, q1, n);
+    return fma(e1, r, q1);
+}
+
 /* ---- fill.rs:51-104 ------------------------------------------------------
  * The walk from p1 to p2 visits, on the row reached after j y-steps (0 <= j <= DY),
  * the columns i_first(j) .. i_last(j) (counted in x-steps from p1).  With a = |dx|,
@@ -166,12 +185,13 @@ typedef struct osmt_seg {
     int32_t a, b;           /* mn_delta, mx_delta  (0 <= a <= b, b >= 1) */
     int32_t mn_inc, mx_inc; /* get_inc: from <= to ? 1 : -1 */
     int64_t numer_const;    /* p2.x*p1.y - p2.y*p1.x */
-    int64_t sdx, sdy;
+    int32_t sdx, sdy;       /* p2 - p1 (|.| <= 2^29: coordinates are limited to 2^28) */
     double denom;           /* sqrt(dy^2 + dx^2) */
+    double rdenom;          /* RN(1 / denom) */
 } osmt_seg;
 
 /* p1 != p2 required (line.rs:73-75 returns early otherwise). */
-OSMT_HD void osmt_seg_setup(osmt_seg* s, int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, double denom) {
+OSMT_HD void osmt_seg_setup(osmt_seg* s, int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, double denom, double rdenom) {
     const int32_t dx = p2x >= p1x ? p2x - p1x : p1x - p2x;
     const int32_t dy = p2y >= p1y ? p2y - p1y : p1y - p2y;
     const int32_t incx = p1x <= p2x ? 1 : -1;
@@ -188,9 +208,10 @@ OSMT_HD void osmt_seg_setup(osmt_seg* s, int32_t p1x, int32_t p1y, int32_t p2x, 
     s->mn_inc = s->swap ? incy : incx;
     s->mx_inc = s->swap ? incx : incy;
     s->numer_const = (int64_t)p2x * (int64_t)p1y - (int64_t)p2y * (int64_t)p1x;
-    s->sdx = (int64_t)p2x - (int64_t)p1x;
-    s->sdy = (int64_t)p2y - (int64_t)p1y;
+    s->sdx = p2x - p1x;
+    s->sdy = p2y - p1y;
     s->denom = denom;
+    s->rdenom = rdenom;
 }
 
 /* osmt_stroke_step for short segments (b < 2048): every intermediate is < 2^23, so the two
@@ -261,6 +282,43 @@ OSMT_HD void osmt_stroke_main(int32_t a, int32_t b, int32_t k, int32_t* c_out, i
     }
 }
 
+/* ---- how far a perpendicular run can draw (line.rs:108-137) -------------------------------------------------
+ * A run starts on a Bresenham centre (main run) or one minor step beside it (extra run, line.rs:152-154) and moves
+ * one pixel per step t along the segment's MINOR axis, with cc_t <= t*a/b + 1 corrections of one pixel along the
+ * major axis.  The pixel of step t lies at distance >= t*len/b - a/len - |d0| from the ideal line (both kinds of
+ * move increase the distance; the corrections lag the ideal perpendicular by less than one, which is the a/len),
+ * where |d0| <= 0.5 for a main run and <= 1.5 for an extra one, and it is set only while that distance is below
+ * feather_to <= ft (opacity_calculator.rs:171-185).  Hence
+ *     t < (ft + a/len + |d0|) * b/len,        cc_t <= t_max * a/b + 1.
+ * ft must be max(|half_width| + 0.5, 1.0): the calculator works with sqrt(h*h - cap_dist^2), i.e. with |h|. */
+typedef struct osmt_run_reach {
+    int32_t t_main, c_main;   /* main runs: steps 0 .. t_main, major offsets 0 .. c_main */
+    int32_t t_extra, c_extra; /* extra runs */
+} osmt_run_reach;
+
+#define OSMT_REACH_MAX 60000 /* widths are validated so that no bound comes near it */
+OSMT_HD osmt_run_reach osmt_reach_of(int32_t a, int32_t b, double len, double ft) {
+    osmt_run_reach r;
+    const double al = (double)a / len, bl = (double)b / len;
+    /* floor(x) >= the largest integer t with t < x; the 1e-9 absorbs the roundings of the few operations above */
+    const double xm = (ft + al + 0.5) * bl + 1e-9, xe = (ft + al + 1.5) * bl + 1e-9;
+    const double tm = floor(xm), te = floor(xe);
+    const double ab = (double)a / (double)b;
+    const double cm = floor(tm * ab + 1e-9) + 1.0, ce = floor(te * ab + 1e-9) + 1.0;
+    r.t_main = (int32_t)(tm < (double)OSMT_REACH_MAX ? tm : (double)OSMT_REACH_MAX);
+    r.t_extra = (int32_t)(te < (double)OSMT_REACH_MAX ? te : (double)OSMT_REACH_MAX);
+    r.c_main = (int32_t)(cm < (double)OSMT_REACH_MAX ? cm : (double)OSMT_REACH_MAX);
+    r.c_extra = (int32_t)(ce < (double)OSMT_REACH_MAX ? ce : (double)OSMT_REACH_MAX);
+    return r;
+}
+
+/* Smallest main-axis step k (0 <= k) whose correction count c_k = osmt_corrections(a, b, k) is >= c:
+ * c_k >= c  <=>  2ak > 2bc - b  <=>  k >= floor((2bc - b) / 2a) + 1   (c >= 1, a >= 1). */
+OSMT_HD int64_t osmt_first_step_with_corrections(int32_t a, int32_t b, int64_t c) {
+    if (c <= 0) return 0;
+    return osmt_udiv(2 * (int64_t)b * c - b, 2 * (int64_t)a) + 1;
+}
+
 /* ---- the extra perpendiculars of line.rs:152-154 as directly enumerable events -------------
  * An extra pair fires at step k < b exactly when both the main error and p_error are corrected
  * (c and d = corrections(c) both increment).  d grows by at most one per correction, hence:
@@ -293,6 +351,100 @@ OSMT_HD void osmt_extra_event(int32_t a, int32_t b, int32_t m, int32_t* c_out, i
         *k_out = (int32_t)osmt_udiv(2 * B * c - B, 2 * A);
         *pe_out = (int32_t)(2 * A * c - 2 * B * M);
     }
+}
+
+/* the item ranges of one (segment, sub-tile) pair, see osmt_seg_ranges */
+typedef struct osmt_item_ranges {
+    int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
+    int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
+} osmt_item_ranges;
+#define OSMT_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define OSMT_MIN(a, b) ((a) < (b) ? (a) : (b))
+
+/* Items of segment p1->p2 for this sub-tile: per side the main-axis steps [k_lo, k_lo + k_n) whose perpendicular
+ * run can reach the sub-tile, and the extra-perpendicular events (line.rs:152-154) that can; returns the total item
+ * count (0 when culled).  Every item is exactly ONE perpendicular run.
+ * The run of step k on side `mul` starts at (mn_k, mx_k) = (mn0 + c_k*mn_inc, mx0 + k*mx_inc), c_k = corrections
+ * after k steps, and its pixel of step t is (mn_k + mul*mn_inc*t, mx_k - mul*mx_inc*cc), 0 <= t <= T, 0 <= cc <= C
+ * (osmt_reach_of).  Both mx_k and mn_k are monotonic in k, so "the start lies within reach of the rectangle" is a
+ * range of k along the major axis AND a range of c_k — i.e. again a range of k — along the minor axis; the items
+ * are the intersection.  Extra event m sits at (c_m, k_m), both monotonic in m, and is clipped the same way. */
+OSMT_HD uint32_t osmt_seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, double len, double ft, int32_t rx0,
+                                 int32_t ry0, int32_t rx1, int32_t ry1, osmt_item_ranges* q) {
+    q->k_lo0 = q->k_n0 = q->k_lo1 = q->k_n1 = 0;
+    q->m_lo0 = q->n_x0 = q->m_lo1 = q->n_x1 = 0;
+    if (p1x == p2x && p1y == p2y) return 0u; /* line.rs:73-75 */
+    const int32_t dx = p2x >= p1x ? p2x - p1x : p1x - p2x, dy = p2y >= p1y ? p2y - p1y : p1y - p2y;
+    const bool swap = dx > dy;
+    const int32_t bmax = swap ? dx : dy, amin = swap ? dy : dx;
+    const osmt_run_reach rr = osmt_reach_of(amin, bmax, len, ft);
+    {
+        /* every set pixel lies within (t_extra, c_extra) of the segment's box along its (minor, major) axis */
+        const int32_t gx = swap ? rr.c_extra : rr.t_extra, gy = swap ? rr.t_extra : rr.c_extra;
+        if (OSMT_MAX(p1x, p2x) + gx < rx0 || OSMT_MIN(p1x, p2x) - gx > rx1 || OSMT_MAX(p1y, p2y) + gy < ry0 || OSMT_MIN(p1y, p2y) - gy > ry1)
+            return 0u;
+    }
+    const int32_t mx0 = swap ? p1x : p1y, mn0 = swap ? p1y : p1x;
+    const int32_t mx_inc = swap ? (p1x <= p2x ? 1 : -1) : (p1y <= p2y ? 1 : -1);
+    const int32_t mn_inc = swap ? (p1y <= p2y ? 1 : -1) : (p1x <= p2x ? 1 : -1);
+    const int32_t LO = swap ? rx0 : ry0, HI = swap ? rx1 : ry1;     /* rectangle along the major axis */
+    const int32_t mLO = swap ? ry0 : rx0, mHI = swap ? ry1 : rx1;   /* ... along the minor axis */
+    const int32_t c_end = (int32_t)osmt_corrections(amin, bmax, bmax);       /* c_k <= c_end */
+    uint32_t total = 0;
+    for (int side = 0; side < 2; ++side) {
+        const int32_t mul = side ? -1 : 1;
+        int32_t k_lo = 0, k_n = 0, m_lo = 0, n_x = 0;
+        for (int extra = 0; extra < 2; ++extra) {
+            const int32_t T = extra ? rr.t_extra : rr.t_main, C = extra ? rr.c_extra : rr.c_main;
+            /* major axis: pixel major = mx_k - mul*mx_inc*cc */
+            int32_t lo = LO, hi = HI;
+            if (mul * mx_inc > 0) hi += C; else lo -= C;
+            int32_t ka = (mx_inc > 0) ? lo - mx0 : mx0 - hi;
+            int32_t kb = (mx_inc > 0) ? hi - mx0 : mx0 - lo;
+            ka = OSMT_MAX(ka, 0);
+            kb = OSMT_MIN(kb, bmax);
+            /* minor axis: pixel minor = mn_k + mul*mn_inc*t  ->  start count c in [cl, ch] */
+            int32_t l2 = mLO, h2 = mHI;
+            if (mul * mn_inc > 0) l2 -= T; else h2 += T;
+            int32_t cl = (mn_inc > 0) ? l2 - mn0 : mn0 - h2;
+            int32_t ch = (mn_inc > 0) ? h2 - mn0 : mn0 - l2;
+            cl = OSMT_MAX(cl, 0);
+            ch = OSMT_MIN(ch, c_end + 1); /* an extra run starts one correction beyond its step's count */
+            if (ka > kb || cl > ch) continue;
+            if (!extra) {
+                /* steps with c_k in [cl, ch]: first k with c_k >= cl .. last k with c_k <= ch */
+                int64_t k1 = ka, k2 = kb;
+                if (amin > 0) {
+                    k1 = OSMT_MAX((int64_t)ka, osmt_first_step_with_corrections(amin, bmax, cl));
+                    k2 = OSMT_MIN((int64_t)kb, osmt_first_step_with_corrections(amin, bmax, (int64_t)ch + 1) - 1);
+                } else if (cl > 0) {
+                    continue; /* axis-parallel segment: c_k == 0 on every step */
+                }
+                if (k1 > k2) continue;
+                k_lo = (int32_t)k1;
+                k_n = (int32_t)(k2 - k1 + 1);
+            } else {
+                if (amin <= 0) continue; /* no extra perpendiculars without corrections */
+                /* events on steps ka .. OSMT_MIN(kb, bmax-1): E(OSMT_MIN(kb, bmax-1) + 1) - E(ka), numbered from 1 */
+                const int32_t e0 = osmt_extra_count(amin, bmax, ka);
+                const int32_t e1 = osmt_extra_count(amin, bmax, OSMT_MIN(kb, bmax - 1) + 1);
+                /* events with start count c_m in [cl, ch]: #events with c_m <= c is d(c) = corrections(a, b, c) */
+                const int32_t f0 = (cl > 0) ? (int32_t)osmt_corrections(amin, bmax, (int64_t)cl - 1) : 0;
+                const int32_t f1 = (int32_t)osmt_corrections(amin, bmax, ch);
+                const int32_t ma = OSMT_MAX(e0, f0) + 1, mb = OSMT_MIN(e1, f1);
+                if (ma > mb) continue;
+                m_lo = ma;
+                n_x = mb - ma + 1;
+            }
+        }
+        if (side == 0) {
+            q->k_lo0 = k_lo; q->k_n0 = k_n; q->m_lo0 = m_lo; q->n_x0 = n_x;
+        } else {
+            q->k_lo1 = k_lo; q->k_n1 = k_n; q->m_lo1 = m_lo; q->n_x1 = n_x;
+        }
+        total += (uint32_t)(k_n + n_x);
+    }
+    return total;
 }
 
 #endif /* OSMT_GEOM_H */

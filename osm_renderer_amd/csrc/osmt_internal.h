@@ -38,7 +38,7 @@ struct osmt_dash_table {
 struct osmt_cap_seg {
     int32_t p1x, p1y, p2x, p2y;
     int32_t valid; /* the edge is not degenerate and the cap is Round/Square */
-    int32_t _pad;
+    uint32_t cand_off; /* first slot of the stub's sub-tile window in the op's slice of the stroke arena */
     double denom;  /* center_dist_denom of the stub */
 };
 
@@ -64,7 +64,8 @@ struct osmt_opinfo {
     /* FILL: first 64-byte group (16 row words of one sub-tile) of the op's coverage masks in the fill arena;
      * STROKE: first record of the op in the stroke-record arena */
     uint32_t arena_off;
-    uint32_t rec_cap;   /* STROKE: records reserved for the op (sum of candidate sub-tiles over its virtual segments) */
+    uint32_t rec_cap;   /* STROKE: slots of the op in the stroke arena = sum over its virtual segments of the sub-tiles
+                         * in each one's window; slot order = segment order (edges, then the two cap stubs), window row-major */
     /* FILL: sub-tile window the masks cover: sr0 | c0 << 8 | ncols << 16 | nsr << 24 (nsr == 0: no covered row inside the tile) */
     uint32_t fill_geom;
     uint32_t image_id;  /* FILL_IMAGE: osmt_op.image_id */
@@ -78,10 +79,11 @@ static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record
  * fill.rs:23-45).  Group index = arena_off + (sr - sr0) * ncols + (c - c0).  Written by k_fill_rows once per op — the
  * rows of an op are evaluated ONCE per tile, not once per sub-tile column.
  *
- * Stroke arena: one record per (virtual segment, sub-tile it can draw into), written by k_stroke_bin with the step
- * ranges of the segment's perpendicular runs for that sub-tile.  Records of one op are contiguous (arena_off .. +rec_n),
- * in no particular order; `key` = the sub-tile a record belongs to, kept in its own array so that a wave filters 64
- * records with one coalesced load. */
+ * Stroke arena: one SLOT per (virtual segment, sub-tile of its window), written by k_stroke_bin: the step ranges of
+ * the segment's perpendicular runs for that sub-tile when it can draw there, a hole otherwise.  The slots of one op
+ * are contiguous (arena_off .. + rec_cap) and in segment order — no atomics, the layout is a pure function of the
+ * scene; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
+ * one coalesced load. */
 struct osmt_srec {
     int32_t p1x, p1y, p2x, p2y;
     double traveled;      /* line.rs:31, before this edge (0 for a cap stub) */
@@ -181,8 +183,7 @@ struct osmt_raster_args {
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
-    const uint32_t* skey;    /* per stroke record: its sub-tile (sy * subs_per_row + sx) */
-    const uint32_t* rec_n;   /* per op: records written by k_stroke_bin */
+    const uint32_t* skey;    /* per stroke slot: its sub-tile (sy * subs_per_row + sx), 0xFFFFFFFF = hole */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -217,7 +218,7 @@ struct osmt_prepass_args {
     osmt_stroke_aux* aux;
     osmt_blk_bbox* blk;
     uint32_t* submask;
-    uint32_t* rec_n;
+    uint32_t* cand_off; /* per point: first slot (relative to the op) of the window of the edge that starts there */
     unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records); zeroed by the launcher */
     uint32_t* fmask;
     osmt_srec* srec;

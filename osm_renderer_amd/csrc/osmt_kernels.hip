@@ -135,19 +135,25 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
     t->total_len = len_before;
 }
 
-/* Sub-tiles a virtual segment (an edge or a cap stub) can draw into: every pixel it sets lies within `reach` (per
- * axis) of the segment's box — the first cull of seg_ranges.  k_opinfo counts these candidates to reserve the op's
- * records, k_stroke_bin walks exactly the same window, so the reservation can never be exceeded. */
+/* Sub-tiles a virtual segment (an edge or a cap stub) can draw into: every pixel it sets lies within t_extra pixels
+ * of the segment's box along its minor axis and within c_extra along its major axis (osmt_reach_of) — the first
+ * cull of seg_ranges.  k_opinfo counts these candidates to reserve the op's slots, k_stroke_bin walks exactly the
+ * same window with the same inputs (the edge length comes from the same array), so the reservation is exact. */
 struct SubWindow {
     int32_t sx0, sx1, sy0, sy1; /* inclusive; empty when sx0 > sx1 or sy0 > sy1 */
 };
-__device__ __forceinline__ SubWindow vseg_window(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
+__device__ __forceinline__ double stroke_ft(double half_width) { return fmax(fabs(half_width) + 0.5, 1.0); }
+__device__ __forceinline__ SubWindow vseg_window(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, double len, double ft,
                                                  int32_t n_sub_x, int32_t n_sub_y) {
+    const int32_t dx = abs(p2x - p1x), dy = abs(p2y - p1y);
+    const bool swap = dx > dy; /* x is the major axis */
+    const osmt_run_reach rr = osmt_reach_of(swap ? dy : dx, swap ? dx : dy, len, ft);
+    const int32_t rx = swap ? rr.c_extra : rr.t_extra, ry = swap ? rr.t_extra : rr.c_extra;
     SubWindow w;
-    w.sx0 = max((min(p1x, p2x) - reach) >> 5, 0);
-    w.sx1 = min((max(p1x, p2x) + reach) >> 5, n_sub_x - 1);
-    w.sy0 = max((min(p1y, p2y) - reach) >> OSMT_SUB_H_LOG2, 0);
-    w.sy1 = min((max(p1y, p2y) + reach) >> OSMT_SUB_H_LOG2, n_sub_y - 1);
+    w.sx0 = max((min(p1x, p2x) - rx) >> 5, 0);
+    w.sx1 = min((max(p1x, p2x) + rx) >> 5, n_sub_x - 1);
+    w.sy0 = max((min(p1y, p2y) - ry) >> OSMT_SUB_H_LOG2, 0);
+    w.sy1 = min((max(p1y, p2y) + ry) >> OSMT_SUB_H_LOG2, n_sub_y - 1);
     return w;
 }
 __device__ __forceinline__ uint32_t window_count(const SubWindow& w) {
@@ -171,7 +177,6 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     const uint32_t sub_rows = a.sub_rows;
     uint32_t* __restrict__ sm = a.submask + (size_t)o * sub_rows;
     for (uint32_t r = 0; r < sub_rows; ++r) sm[r] = 0u;
-    a.rec_n[o] = 0u;
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
     oi.x1 = oi.y1 = INT32_MIN;
@@ -242,16 +247,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     oi.n_edges = n_edges;
     if (op.kind == OSMT_OP_STROKE) {
         const double hw = op.width / 2.0;
-        const double ft = fmax(hw + 0.5, 1.0);
-        /* How far a SET pixel can be from the Bresenham centre its perpendicular starts at.  At walk
-         * step t the pixel is t px along the minor axis and cc_t <= t*a/b + 1 px along the major
-         * axis from the centre; its distance from the ideal line is >= t*len/b - a/len - |d0|, with
-         * |d0| <= 0.5 for a main perpendicular and <= 1.5 for the extra one of line.rs:152-154; it
-         * is set only while that distance is < ft' <= ft.  Hence t < (ft + 2.21) * b/len <= ft + 2.21
-         * and cc_t < (a/len)*(ft + 2.21) + 1 <= 0.7072*(ft + 2.21) + 1. */
-        const int32_t reach = (int32_t)fmin(ceil(ft + 2.21), 1.0e6);
-        oi.reach = reach;
-        oi.reach_major = (int32_t)fmin(ceil(0.7072 * (ft + 2.21)), 1.0e6) + 1;
+        const double ft = stroke_ft(hw);
         const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
         osmt_stroke_aux* sa = &a.aux[oi.aux];
         sa->half_width = hw;
@@ -260,7 +256,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
          * one slot per (virtual segment, sub-tile of its window) */
         unsigned long long cand = 0ull;
         {
-            osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0, 1.0}, c1 = {0, 0, 0, 0, 0, 0, 1.0};
+            osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0u, 1.0}, c1 = {0, 0, 0, 0, 0, 0u, 1.0};
             uint32_t seen = 0;
             for (uint32_t r = 0; r < op.n_rings; ++r) {
                 const osmt_ring ring = rings[op.ring_off + r];
@@ -268,8 +264,9 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     ++seen;
                     const int2 pa = pts[ring.first_pt + i - 1];
                     const int2 pb = pts[ring.first_pt + i];
+                    a.cand_off[ring.first_pt + i - 1] = (uint32_t)min(cand, 0xFFFFFFFFull);
                     if (pa.x == pb.x && pa.y == pb.y) continue; /* line.rs:73-75: draws nothing */
-                    cand += window_count(vseg_window(pa.x, pa.y, pb.x, pb.y, reach, n_sub_x, n_sub_y));
+                    cand += window_count(vseg_window(pa.x, pa.y, pb.x, pb.y, a.den[ring.first_pt + i - 1], ft, n_sub_x, n_sub_y));
                     if (!caps) continue;
                     if (seen == 1) {
                         const int2 ce = push_away_from(pa, pb, hw);
@@ -281,10 +278,17 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     }
                 }
             }
+            /* a stub that push_away_from rounds back onto its own start draws nothing (line.rs:73-75) */
+            if (c0.valid && (c0.p1x != c0.p2x || c0.p1y != c0.p2y)) {
+                c0.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
+                cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
+            }
+            if (c1.valid && (c1.p1x != c1.p2x || c1.p1y != c1.p2y)) {
+                c1.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
+                cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
+            }
             sa->cap_seg[0] = c0;
             sa->cap_seg[1] = c1;
-            if (c0.valid) cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, reach, n_sub_x, n_sub_y));
-            if (c1.valid) cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, reach, n_sub_x, n_sub_y));
         }
         sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
@@ -411,6 +415,13 @@ __device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restr
     return cdop > 0.0;
 }
 
+/* f64::from(c) / 255.0 for every u8 (tile_pixels.rs:226-228): the compiler folds each entry with a correctly rounded
+ * IEEE division, so a lookup returns exactly what the reference computes — without three f64 divisions per op. */
+#define OSMT_C4(i) (double)(i) / 255.0, (double)((i) + 1) / 255.0, (double)((i) + 2) / 255.0, (double)((i) + 3) / 255.0
+#define OSMT_C16(i) OSMT_C4(i), OSMT_C4((i) + 4), OSMT_C4((i) + 8), OSMT_C4((i) + 12)
+#define OSMT_C64(i) OSMT_C16(i), OSMT_C16((i) + 16), OSMT_C16((i) + 32), OSMT_C16((i) + 48)
+__constant__ double k_u8_over_255[256] = {OSMT_C64(0), OSMT_C64(64), OSMT_C64(128), OSMT_C64(192)};
+
 /* ---- the fused raster kernel and its two binning kernels ------------------------------------- */
 constexpr int SUB = OSMT_SUB_W;    /* sub-tile width in pixels (one 32-bit coverage word per row) */
 constexpr int SUBH = OSMT_SUB_H;   /* sub-tile height */
@@ -419,15 +430,28 @@ constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int ROWSTEP = NTHREADS / SUB;    /* rows between a thread's consecutive pixels */
 constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
 constexpr int SEGCAP = 64;         /* stroke records of one group held in LDS */
+#ifndef OSMT_V_PLANE_STRIDE
+#define OSMT_V_PLANE_STRIDE 33
+#endif
+constexpr int PLANE_STRIDE = OSMT_V_PLANE_STRIDE;
 #ifndef OSMT_V_ROWCAP
 #define OSMT_V_ROWCAP 16
 #endif
 constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path (k_fill_rows) */
 
+#if defined(OSMT_ABL) && OSMT_ABL == 5
+#define OSMT_DBG(...) __VA_ARGS__
+#else
+#define OSMT_DBG(...)
+#endif
 struct RasterShared {
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] lane iterations [4] sum of per-pass max iterations [5] fill visits [6] set pixels */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
-    unsigned long long plane[SUB * SUBH]; /* generation alpha plane (f64 bit patterns) */
+    /* generation alpha plane (f64 bit patterns).  Row stride PLANE_STRIDE = 33 cells: the runs of one pass start on
+     * consecutive steps of the segment's major axis, so a steep segment sends its 64 atomics to one column of
+     * consecutive rows — with a 32-cell stride all of them on ONE bank pair, with 33 on 32 different ones */
+    unsigned long long plane[PLANE_STRIDE * SUBH];
     uint32_t oplist[OPCHUNK];       /* ops of the chunk that touch this sub-tile, in order */
     uint32_t oparena[OPCHUNK];      /* their osmt_opinfo.arena_off */
     uint8_t opnv[OPCHUNK];          /* their record counts: 0 = fill, 1..64, 255 = more than 64 (own passes) */
@@ -464,7 +488,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
                                                    const osmt_dash_table* __restrict__ tab, double traveled,
                                                    double initial_opacity, int32_t mn, int32_t mx, int32_t p_error,
                                                    int32_t mul, const SubRect& rc,
-                                                   unsigned long long* __restrict__ plane) {
+                                                   unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
     int32_t p_mn = mx;
     int32_t p_mx = mn;
     int32_t err = mul * p_error;
@@ -472,14 +496,15 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     int32_t px = s.swap ? p_mn : p_mx;
     int32_t py = s.swap ? p_mx : p_mn;
     /* center_dist_raw (line.rs:116-117) kept incrementally: exact int64 arithmetic */
-    int64_t raw = s.numer_const + (s.sdy * (int64_t)px - s.sdx * (int64_t)py);
+    int64_t raw = s.numer_const + ((int64_t)s.sdy * (int64_t)px - (int64_t)s.sdx * (int64_t)py);
     const int32_t step_mx = mul * s.mn_inc;  /* p_mx += */
     const int32_t step_mn = -mul * s.mx_inc; /* p_mn += (when corrected) */
-    const int64_t raw_step = s.swap ? -s.sdx * step_mx : s.sdy * step_mx;
-    const int64_t raw_corr = s.swap ? s.sdy * step_mn : -s.sdx * step_mn;
+    const int64_t raw_step = (int64_t)(s.swap ? -s.sdx * step_mx : s.sdy * step_mx); /* steps are +-1: 32-bit products */
+    const int64_t raw_corr = (int64_t)(s.swap ? s.sdy * step_mn : -s.sdx * step_mn);
     const double ff0 = sa->ff0, ft0 = sa->ft0, fd0 = sa->fd0, mul0 = sa->mul0;
     for (;;) {
-        const double cd = fabs((double)raw) / s.denom;
+        OSMT_DBG(++dbg_iters;)
+        const double cd = osmt_div_exact(fabs((double)raw), s.denom, s.rdenom); /* == fabs(raw) / denom (line.rs:116-118) */
         double op;
         bool in_line;
         if (PLAIN) {
@@ -504,7 +529,8 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
             const double alpha = initial_opacity * op;
             /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118);
              * alpha >= +0, so the u64 order of the bit pattern is the f64 order */
-            atomicMax(&plane[(py - rc.y0) * SUB + (px - rc.x0)], (unsigned long long)__double_as_longlong(alpha));
+            atomicMax(&plane[(py - rc.y0) * PLANE_STRIDE + (px - rc.x0)], (unsigned long long)__double_as_longlong(alpha));
+            OSMT_DBG(++dbg_set;)
         }
         /* update_error (line.rs:91-100) */
         if (err + two_a > s.b) {
@@ -518,68 +544,15 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     }
 }
 
-/* Items of segment p1->p2 for this sub-tile: per side the main-axis steps [k_lo, k_lo + k_n)
- * whose perpendicular run can reach the sub-tile, and the extra-perpendicular events that fire on
- * those steps; returns the total item count (0 when culled).  The run on side `mul` moves
- * mul*mn_inc per step along the minor axis and -mul*mx_inc per correction along the major axis,
- * so the major-axis test is one-sided.  Every item is exactly ONE perpendicular run. */
-__device__ __forceinline__ uint32_t seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t p2y, int32_t reach,
-                                               int32_t reach_major, const SubRect& rc, osmt_srec* q) {
-    q->k_lo0 = q->k_n0 = q->k_lo1 = q->k_n1 = 0;
-    q->m_lo0 = q->n_x0 = q->m_lo1 = q->n_x1 = 0;
-    if (p1x == p2x && p1y == p2y) return 0u; /* line.rs:73-75 */
-    /* every set pixel lies within `reach` (per axis) of the segment's box */
-    if (max(p1x, p2x) + reach < rc.x0 || min(p1x, p2x) - reach > rc.x1 || max(p1y, p2y) + reach < rc.y0 ||
-        min(p1y, p2y) - reach > rc.y1)
-        return 0u;
-    const int32_t dx = abs(p2x - p1x), dy = abs(p2y - p1y);
-    const bool swap = dx > dy;
-    const int32_t mx0 = swap ? p1x : p1y;
-    const int32_t bmax = swap ? dx : dy, amin = swap ? dy : dx;
-    const int32_t mx_inc = swap ? (p1x <= p2x ? 1 : -1) : (p1y <= p2y ? 1 : -1);
-    const int32_t LO = swap ? rc.x0 : rc.y0, HI = swap ? rc.x1 : rc.y1;
-    uint32_t total = 0;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const int32_t mul = side ? -1 : 1;
-        int32_t lo = LO, hi = HI; /* pixel major = mx_k - mul*mx_inc*cc, 0 <= cc <= reach_major */
-        if (mul * mx_inc > 0) hi += reach_major; else lo -= reach_major;
-        int32_t a, b;
-        if (mx_inc > 0) {
-            a = lo - mx0;
-            b = hi - mx0;
-        } else {
-            a = mx0 - hi;
-            b = mx0 - lo;
-        }
-        a = max(a, 0);
-        b = min(b, bmax);
-        const int32_t n = max(b - a + 1, 0);
-        int32_t m_lo = 0, n_x = 0;
-        if (n > 0) { /* events on steps a .. min(b, bmax-1): E(min(b, bmax-1) + 1) - E(a) */
-            const int32_t e0 = osmt_extra_count(amin, bmax, a);
-            const int32_t e1 = osmt_extra_count(amin, bmax, min(b, bmax - 1) + 1);
-            m_lo = e0 + 1;
-            n_x = max(e1 - e0, 0);
-        }
-        if (side == 0) {
-            q->k_lo0 = a; q->k_n0 = n; q->m_lo0 = m_lo; q->n_x0 = n_x;
-        } else {
-            q->k_lo1 = a; q->k_n1 = n; q->m_lo1 = m_lo; q->n_x1 = n_x;
-        }
-        total += (uint32_t)(n + n_x);
-    }
-    return total;
-}
-
 /* One item of a segment record = one perpendicular run (line.rs:108-137): items [0, k_n0 + k_n1)
  * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
  * of line.rs:152-154, located directly by osmt_extra_event. */
-__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const bool plain_main,
-                                          const osmt_stroke_aux* __restrict__ sa, double initial_opacity,
-                                          int32_t reach, const SubRect& rc, unsigned long long* __restrict__ plane) {
+template <bool PLAIN>
+__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const osmt_stroke_aux* __restrict__ sa,
+                                          double initial_opacity, const SubRect& rc,
+                                          unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
     osmt_seg s;
-    osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom);
+    osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom, r.rdenom);
     const uint32_t n_main = (uint32_t)(r.k_n0 + r.k_n1);
     int32_t k, c, pe, mul;
     if (local < n_main) {
@@ -596,13 +569,35 @@ __device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, co
     }
     const int32_t mx = s.mx0 + k * s.mx_inc;
     const int32_t mn = s.mn0 + c * s.mn_inc;
-    /* pixel minor = mn + mul*mn_inc*t, 0 <= t <= reach */
-    int32_t mlo = s.swap ? rc.y0 : rc.x0, mhi = s.swap ? rc.y1 : rc.x1;
-    if (mul * s.mn_inc > 0) mlo -= reach; else mhi += reach;
+    /* seg_ranges only lists runs whose start lies within reach of the sub-tile on both axes */
     const bool use_caps = r.caps_table != 0u;
-    if (mn >= mlo && mn <= mhi)
-        walk_perpendicular(plain_main && !use_caps, s, sa, use_caps ? &sa->caps : &sa->main, r.traveled,
-                           initial_opacity, mn, mx, pe, mul, rc, plane);
+    walk_perpendicular(PLAIN, s, sa, use_caps ? &sa->caps : &sa->main, r.traveled, initial_opacity, mn, mx, pe, mul, rc, plane OSMT_DBG(, dbg_iters, dbg_set));
+}
+
+/* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of one op, lanes packed: the record of item
+ * `it` is the first slot whose inclusive item prefix exceeds it (bisection over the LDS prefix).  PLAIN: every one
+ * of these records belongs to an un-dashed edge (no start-distance terms, per-op feather constants). */
+template <bool PLAIN, class Shared>
+__device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t slot0, uint32_t nslot, uint32_t item_base,
+                                           uint32_t it_lo, uint32_t it_hi, const osmt_stroke_aux* __restrict__ sa,
+                                           double initial_opacity, const SubRect& rc) {
+    for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
+        uint32_t lo_s = slot0, n = nslot;
+        while (n > 1u) {
+            const uint32_t half = n >> 1;
+            const bool right = sh.pre[lo_s + half - 1u] <= it;
+            lo_s = right ? lo_s + half : lo_s;
+            n = right ? n - half : half;
+        }
+        const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
+        OSMT_DBG(uint32_t dbg_iters = 0, dbg_set = 0;)
+        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
+        OSMT_DBG(atomicAdd(&sh.dbg[2], 1u); atomicAdd(&sh.dbg[3], dbg_iters); atomicAdd(&sh.dbg[6], dbg_set); atomicMax(&sh.dbg[7], dbg_iters);)
+    }
+    OSMT_DBG(for (uint32_t it0 = it_lo; it0 < it_hi; it0 += 64u) {
+        __syncthreads();
+        if (lane == 0) { sh.dbg[1] += 1u; }
+    })
 }
 
 /* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
@@ -809,7 +804,7 @@ __global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g
                                                    const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
                                                    const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_stroke_op,
                                                    uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale, uint32_t sub_rows,
-                                                   uint32_t* __restrict__ g_submask, uint32_t* __restrict__ g_rec_n,
+                                                   uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
                                                    osmt_srec* __restrict__ g_srec, uint32_t* __restrict__ g_skey) {
     const uint32_t g = blockIdx.x * 64u + threadIdx.x;
     if (g >= n_vsegs) return;
@@ -824,6 +819,7 @@ __global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g
     osmt_srec rec;
     rec.caps_table = 0u;
     rec.traveled = 0.0;
+    uint32_t cand_off;
     if (v < oi.n_edges) {
         /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
         const osmt_op* __restrict__ op = &g_ops[o];
@@ -839,6 +835,7 @@ __global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g
         rec.traveled = g_trav[ring.first_pt + e];
         rec.denom = g_den[ring.first_pt + e];
         rec.rdenom = g_rden[ring.first_pt + e];
+        cand_off = g_cand_off[ring.first_pt + e];
     } else {
         const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
         if (!cs.valid) return;
@@ -846,23 +843,32 @@ __global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g
         rec.denom = cs.denom;
         rec.rdenom = 1.0 / cs.denom;
         rec.caps_table = 1u;
+        cand_off = cs.cand_off;
     }
     if (rec.p1x == rec.p2x && rec.p1y == rec.p2y) return; /* line.rs:73-75 */
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
     const int32_t n_sub_x = W / SUB, n_sub_y = (int32_t)sub_rows;
-    const SubWindow w = vseg_window(rec.p1x, rec.p1y, rec.p2x, rec.p2y, oi.reach, n_sub_x, n_sub_y);
+    const double ft = stroke_ft(g_aux[oi.aux].half_width);
+    const SubWindow w = vseg_window(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, ft, n_sub_x, n_sub_y);
+    /* one slot per sub-tile of the window, row-major: the record, or a hole */
+    uint32_t slot = cand_off;
+    if ((unsigned long long)cand_off + window_count(w) > oi.rec_cap) return; /* never: k_opinfo reserved this very window */
     for (int32_t sy = w.sy0; sy <= w.sy1; ++sy) {
         uint32_t rowbits = 0u;
-        for (int32_t sx = w.sx0; sx <= w.sx1; ++sx) {
+        for (int32_t sx = w.sx0; sx <= w.sx1; ++sx, ++slot) {
             SubRect rc;
             rc.x0 = sx * SUB;
             rc.y0 = sy * SUBH;
             rc.x1 = rc.x0 + SUB - 1;
             rc.y1 = rc.y0 + SUBH - 1;
-            const uint32_t cnt = seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, oi.reach, oi.reach_major, rc, &rec);
-            if (cnt == 0u) continue;
-            const uint32_t slot = atomicAdd(&g_rec_n[o], 1u);
-            if (slot >= oi.rec_cap) continue; /* never: the reservation counts this very window */
+            osmt_item_ranges ir;
+            const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, ft, rc.x0, rc.y0, rc.x1, rc.y1, &ir);
+            if (cnt == 0u) {
+                g_skey[(size_t)oi.arena_off + slot] = 0xFFFFFFFFu;
+                continue;
+            }
+            rec.k_lo0 = ir.k_lo0; rec.k_n0 = ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = ir.k_n1;
+            rec.m_lo0 = ir.m_lo0; rec.n_x0 = ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = ir.n_x1;
             rec.count = cnt;
             g_srec[(size_t)oi.arena_off + slot] = rec;
             g_skey[(size_t)oi.arena_off + slot] = (uint32_t)(sy * n_sub_x + sx);
@@ -885,7 +891,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_opinfo* OSMT_R g_info,
     const osmt_stroke_aux* OSMT_R g_aux, const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows,
     const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint32_t* OSMT_R g_skey,
-    const uint32_t* OSMT_R g_rec_n, const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
+    const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
     uint32_t g_n_images, void* OSMT_R g_out, size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab,
     const uint32_t* OSMT_R g_job_label_off, const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt,
     const double* OSMT_R g_lab_plane) {
@@ -926,9 +932,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     {
         double r = 0.0, g = 0.0, bl = 0.0;
         if (job.has_canvas) {
-            r = 1.0 * ((double)job.canvas_rgb[0] / 255.0);
-            g = 1.0 * ((double)job.canvas_rgb[1] / 255.0);
-            bl = 1.0 * ((double)job.canvas_rgb[2] / 255.0);
+            r = 1.0 * k_u8_over_255[job.canvas_rgb[0]];
+            g = 1.0 * k_u8_over_255[job.canvas_rgb[1]];
+            bl = 1.0 * k_u8_over_255[job.canvas_rgb[2]];
         }
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
@@ -938,17 +944,23 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
+    OSMT_DBG(if (lane < 8) sh.dbg[lane] = 0u; __syncthreads();)
+    uint32_t job_n_ops_abl = job.n_ops; /* (diagnostic builds can zero it) */
 
-    for (uint32_t base = 0; base < job.n_ops; base += OPCHUNK) {
+#if defined(OSMT_ABL) && OSMT_ABL == 4
+    if (g_n_jobs) job_n_ops_abl = 0;
+#endif
+    for (uint32_t base = 0; base < job_n_ops_abl; base += OPCHUNK) {
         /* ---- ordered compaction of the ops that draw into this sub-tile (exact bits from the binning kernels) ---- */
         const uint32_t oi_idx = base + tid;
         bool hit = false;
         uint32_t my_nv = 0, my_arena = 0;
-        if (oi_idx < job.n_ops) {
+        if (oi_idx < job_n_ops_abl) {
             hit = (g_submask[(size_t)(job.op_off + oi_idx) * g_sub_rows + sub_y] >> sub_x) & 1u;
             if (hit) {
-                my_nv = min(g_rec_n[job.op_off + oi_idx], 255u); /* 0: a fill */
-                my_arena = g_info[job.op_off + oi_idx].arena_off;
+                const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + oi_idx];
+                my_nv = min(hi->rec_cap, 255u); /* slots of a stroke op; 0: a fill */
+                my_arena = hi->arena_off;
             }
         }
         const unsigned long long bal = __ballot(hit);
@@ -963,7 +975,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         const bool any_stroke = __ballot(hit && my_nv != 0u) != 0ull;
         if (any_stroke && !plane_clean) {
-            for (uint32_t i = tid; i < SUB * SUBH; i += NTHREADS) sh.plane[i] = 0ull;
+            for (uint32_t i = tid; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i] = 0ull;
             plane_clean = true;
         }
         __syncthreads();
@@ -999,20 +1011,26 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
             __syncthreads();
         }
-        unsigned long long gbal = 0ull;
+        unsigned long long gbal = 0ull, cbal = 0ull; /* lanes of the filter pass holding a record of this sub-tile / of a cap stub */
         bool records_ready = false;
 
         for (uint32_t li = g0; li < gend; ++li) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
             const osmt_opinfo* __restrict__ oi = &g_info[o];
             const uint32_t kind = oi->kind;
+#if defined(OSMT_ABL) && OSMT_ABL == 2
+            if (kind == OSMT_OP_STROKE) continue;
+#endif
+#if defined(OSMT_ABL) && OSMT_ABL == 3
+            if (kind != OSMT_OP_STROKE) continue;
+#endif
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[oi->aux];
+                OSMT_DBG(if (lane == 0) sh.dbg[0] += 1u;)
                 const bool plain_main = sa->main.n_segs == 0;
                 const double initial_opacity = oi->opacity;
-                const int32_t reach = oi->reach;
-                const uint32_t nrec_op = big ? g_rec_n[o] : 0u;
+                const uint32_t nrec_op = big ? oi->rec_cap : 0u;
                 const uint32_t n_rounds = big ? (nrec_op + 63u) / 64u : 1u;
                 for (uint32_t round = 0; round < n_rounds; ++round) {
                     if (big || !records_ready) {
@@ -1030,9 +1048,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             const uint32_t j = sh.s_ent[k];
                             ridx = sh.oparena[g0 + j] + (lane - sh.grp_base[j]);
                         }
-                        uint32_t cnt = 0;
-                        if (ridx != 0xFFFFFFFFu && g_skey[ridx] == sub) cnt = g_srec[ridx].count;
+                        uint32_t cnt = 0, is_cap = 0;
+                        if (ridx != 0xFFFFFFFFu && g_skey[ridx] == sub) {
+                            cnt = g_srec[ridx].count;
+                            is_cap = g_srec[ridx].caps_table;
+                        }
                         gbal = __ballot(cnt > 0u);
+                        cbal = __ballot(cnt > 0u && is_cap != 0u);
                         uint32_t incl = cnt; /* inclusive prefix of the item counts over the lanes */
 #pragma unroll
                         for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -1061,30 +1083,33 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         if (nslot) {
                             const uint32_t item_lo = slot0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 - 1u]) : 0u;
                             const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + nslot - 1u]);
-                            /* all (record, item) pairs of this op, lanes packed: record of item `it` = first slot whose
-                             * inclusive prefix exceeds it (bisection over the LDS prefix) */
-                            for (uint32_t it = item_lo + lane; it < item_hi; it += 64u) {
-                                uint32_t lo_s = slot0, n = nslot;
-                                while (n > 1u) {
-                                    const uint32_t half = n >> 1;
-                                    const bool right = sh.pre[lo_s + half - 1u] <= it;
-                                    lo_s = right ? lo_s + half : lo_s;
-                                    n = right ? n - half : half;
-                                }
-                                const uint32_t base_items = (lo_s == slot0) ? item_lo : sh.pre[lo_s - 1u];
-                                walk_item(sh.seg[lo_s], it - base_items, plain_main, sa, initial_opacity, reach, rc, sh.plane);
+#if defined(OSMT_ABL) && OSMT_ABL == 1
+                            (void)item_lo; (void)item_hi;
+#else
+                            if (plain_main) {
+                                /* slots are in segment order: the edges' records first, the cap stubs' (which need the
+                                 * start-distance terms of opacity_calculator_for_outer_caps, line.rs:22) last — two
+                                 * passes, so the plain runs never execute the dash / cap arithmetic */
+                                const uint32_t n_edge = (uint32_t)__popcll(gbal & ~cbal & lanes_ab);
+                                const uint32_t item_mid = n_edge ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + n_edge - 1u]) : item_lo;
+                                if (n_edge) walk_items<true>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, sa, initial_opacity, rc);
+                                if (nslot > n_edge)
+                                    walk_items<false>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, sa, initial_opacity, rc);
+                            } else {
+                                walk_items<false>(sh, lane, slot0, nslot, item_lo, item_lo, item_hi, sa, initial_opacity, rc);
                             }
+#endif
                         }
                     }
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
-                const double cr = (double)oi->color[0] / 255.0;
-                const double cg = (double)oi->color[1] / 255.0;
-                const double cb = (double)oi->color[2] / 255.0;
+                const double cr = k_u8_over_255[oi->color[0]];
+                const double cg = k_u8_over_255[oi->color[1]];
+                const double cb = k_u8_over_255[oi->color[2]];
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) {
-                    const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * SUB + lx;
+                    const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * PLANE_STRIDE + lx;
                     const unsigned long long bits = sh.plane[idx];
                     if (bits != 0ull) {
                         sh.plane[idx] = 0ull;
@@ -1095,6 +1120,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 __syncthreads(); /* the plane is reused by the next op */
             } else {
                 /* ---------------- fill_contour (fill.rs:16-47): coverage words from k_fill_rows ---------------- */
+                OSMT_DBG(if (lane == 0) sh.dbg[5] += 1u;)
                 const uint32_t geom = oi->fill_geom;
                 const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
                 const uint32_t* __restrict__ mw = g_fmask + ((size_t)oi->arena_off + (size_t)(sub_y - sr0) * ncols + (sub_x - c0)) * SUBH;
@@ -1108,9 +1134,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 if (kind == OSMT_OP_FILL_COLOR) {
                     const double o_ = oi->opacity;
-                    const double sr = o_ * ((double)oi->color[0] / 255.0);
-                    const double sg = o_ * ((double)oi->color[1] / 255.0);
-                    const double sb = o_ * ((double)oi->color[2] / 255.0);
+                    const double sr = o_ * k_u8_over_255[oi->color[0]];
+                    const double sg = o_ * k_u8_over_255[oi->color[1]];
+                    const double sb = o_ * k_u8_over_255[oi->color[2]];
 #pragma unroll
                     for (int j = 0; j < PXT; ++j)
                         if ((cov >> j) & 1u) blend_rgb(acc[j], sr, sg, sb, o_);
@@ -1194,6 +1220,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
                                                         (size_t)tile * g_out_tile_stride) + px;
             *out = v;
+            OSMT_DBG(__syncthreads(); if (j == 0 && ly0 == 0 && lx < 8) *out = sh.dbg[lx];)
         }
     }
 }
@@ -1303,7 +1330,7 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
                        a.sub_rows, a.fmask);
     if (a.n_vsegs)
         hipLaunchKernelGGL(k_stroke_bin, dim3((a.n_vsegs + 63u) / 64u), dim3(64), 0, st, a.ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden,
-                           a.aux, a.vseg_base, a.stroke_op, a.n_strokes, a.n_vsegs, a.scale, a.sub_rows, a.submask, a.rec_n, a.srec, a.skey);
+                           a.aux, a.vseg_base, a.stroke_op, a.n_strokes, a.n_vsegs, a.scale, a.sub_rows, a.submask, a.cand_off, a.srec, a.skey);
     return hipGetLastError();
 }
 
@@ -1315,7 +1342,7 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const dim3 grid(groups * 8u * nsub);
 #define OSMT_LAUNCH_RASTER(F64, LAB)                                                                                   \
     hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.info, a.aux, a.submask, \
-                       a.sub_rows, a.fmask, a.srec, a.skey, a.rec_n, a.images, a.image_pool, a.n_images, a.out,          \
+                       a.sub_rows, a.fmask, a.srec, a.skey, a.images, a.image_pool, a.n_images, a.out,          \
                        a.out_tile_stride, a.labels.info, a.labels.job_label_off, a.labels.tile_labels,                    \
                        a.labels.tile_label_cnt, a.labels.plane)
     if (out_f64) /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */

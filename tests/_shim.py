@@ -26,6 +26,13 @@ def lib():
         L.shim_extra_events.restype = C.c_int32
         L.shim_fmod_pos.argtypes = [C.c_double, C.c_double]
         L.shim_fmod_pos.restype = C.c_double
+        dp = C.POINTER(C.c_double)
+        L.shim_div_exact_check.argtypes = [dp, dp, C.c_size_t, dp]
+        L.shim_div_exact_check.restype = C.c_size_t
+        L.shim_div_exact_sweep.argtypes = [C.c_uint64, C.c_size_t, dp]
+        L.shim_div_exact_sweep.restype = C.c_size_t
+        L.shim_seg_ranges.argtypes = [C.c_int32] * 4 + [C.c_double, C.c_double] + [C.c_int32] * 4 + [ip]
+        L.shim_seg_ranges.restype = C.c_uint32
         L.shim_udiv.argtypes = [C.c_int64, C.c_int64]
         L.shim_udiv.restype = C.c_int64
         L.shim_sizeof.argtypes = [C.c_int]

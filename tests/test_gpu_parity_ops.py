@@ -192,6 +192,25 @@ def test_strokes_all_caps_dashes_widths(gpu_ctx, oracle, scale):
     assert_parity(gpu_ctx, oracle, display_list.concat(tiles), msg=f"strokes scale {scale}")
 
 
+def test_negative_and_huge_widths(gpu_ctx, oracle):
+    """The calculator works with sqrt(h*h - cap_dist^2), i.e. with |half_width| (opacity_calculator.rs:36): a negative
+    width draws like its absolute value, and the stroke cull must size its reach from |h|.  Very wide lines cover
+    whole sub-tiles far from their centre line; widths beyond the supported range are refused, not mis-drawn."""
+    from osm_renderer_amd.lib import OsmtError
+
+    tb = TileBuilder(canvas=(252, 248, 228))
+    tb.stroke([(30, 40), (200, 90), (120, 220)], -9.0, (200, 30, 30), 0.8)
+    tb.stroke([(10, 200), (240, 180)], -3.0, (30, 30, 200), 1.0, dashes=[6, 4], cap=abi.CAP_ROUND, use_caps_for_dashes=True)
+    tb.stroke([(128, -40), (140, 300)], 90.0, (20, 160, 60), 0.5, cap=abi.CAP_SQUARE)
+    tb.stroke([(-500, 128), (700, 131)], 300.0, (250, 250, 0), 0.3)
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="negative / huge widths")
+    bad = TileBuilder()
+    bad.stroke([(0, 0), (10, 10)], 1.0e6, (0, 0, 0), 1.0)
+    with pytest.raises(OsmtError) as e:
+        gpu_ctx.upload(bad.build())
+    assert e.value.code == abi.UNSUPPORTED and "width" in str(e.value)
+
+
 def test_stroke_every_direction(gpu_ctx, oracle):
     # direction sensitivity (SURVEY.md 7 "hard parts"): all octants, both orientations, steep & shallow
     tb = TileBuilder()
