@@ -121,6 +121,8 @@ struct osmt_scene {
     uint32_t* d_op_job = nullptr;
     uint32_t* d_vseg_base = nullptr;
     uint32_t* d_stroke_op = nullptr;
+    uint32_t* d_vseg_blk_slot = nullptr;
+    uint32_t n_bin_slots = 0;
     uint32_t* d_cand_off = nullptr;
     unsigned long long* d_cursors = nullptr;
     uint32_t n_vsegs = 0;
@@ -128,10 +130,10 @@ struct osmt_scene {
     char* d_arena = nullptr;
     uint32_t* d_fmask = nullptr;
     osmt_srec* d_srec = nullptr;
-    uint32_t* d_skey = nullptr;
+    uint2* d_skey = nullptr;
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
-    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_job, h_vseg_base, h_stroke_op, h_lab_wide;
+    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_job, h_vseg_base, h_stroke_op, h_vseg_blk_slot, h_lab_wide;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
     /* public scenes: one event per stream the scene was rendered on, recorded behind the last launch that reads it.
@@ -481,7 +483,8 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.op_blk = sc->d_op_blk;
     a.vseg_base = sc->d_vseg_base;
     a.stroke_op = sc->d_stroke_op;
-    a.n_strokes = sc->n_strokes;
+    a.vseg_blk_slot = sc->d_vseg_blk_slot;
+    a.n_strokes = sc->n_bin_slots;
     a.n_vsegs = sc->n_vsegs;
     a.scale = sc->scale;
     a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
@@ -651,7 +654,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     const size_t W = (size_t)OSMT_TILE_SIZE * s->scale;
     const size_t nsub = (W / OSMT_SUB_W) * (W / OSMT_SUB_H);
     unsigned long long groups = (unsigned long long)n_fills * nsub, recs = (unsigned long long)s->n_vsegs * nsub;
-    const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 4ull);
+    const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 8ull);
     if (worst_bytes > ((unsigned long long)32 << 20)) {
         hipStream_t st = s->own_stream;
         if (s->coord_kind != OSMT_COORD_POINT_I32)
@@ -674,7 +677,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     };
     const size_t o_f = carve((size_t)(groups + 1) * 64);
     const size_t o_r = carve((size_t)(recs + 1) * sizeof(osmt_srec));
-    const size_t o_k = carve((size_t)(recs + 1) * 4);
+    const size_t o_k = carve((size_t)(recs + 1) * 8);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_arena, off + 256);
     if (e != hipSuccess) {
         s->d_arena = nullptr;
@@ -682,7 +685,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     }
     s->d_fmask = (uint32_t*)(s->d_arena + o_f);
     s->d_srec = (osmt_srec*)(s->d_arena + o_r);
-    s->d_skey = (uint32_t*)(s->d_arena + o_k);
+    s->d_skey = (uint2*)(s->d_arena + o_k);
     s->fmask_cap = groups + 1; /* never 0: 0 means "sizing pass" to the kernels */
     s->srec_cap = recs + 1;
     return OSMT_OK;
@@ -736,9 +739,12 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             }
             if (op.kind == OSMT_OP_STROKE) {
                 op_aux[job.op_off + k] = n_strokes++;
-                stroke_op.push_back(job.op_off + k);
-                vseg_base.push_back((uint32_t)n_vsegs);
-                n_vsegs += ne + ((op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE) ? 2u : 0u);
+                const size_t nv = ne + ((op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE) ? 2u : 0u);
+                if (nv) { /* only ops with segments enter the binning table: 64 consecutive segments then span <= 64 entries */
+                    stroke_op.push_back(job.op_off + k);
+                    vseg_base.push_back((uint32_t)n_vsegs);
+                    n_vsegs += nv;
+                }
             } else {
                 ++n_fills;
             }
@@ -749,6 +755,12 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices (stroke segments)");
     }
     vseg_base.push_back((uint32_t)n_vsegs);
+    std::vector<uint32_t>& blk_slot = s->h_vseg_blk_slot;
+    blk_slot.assign((n_vsegs + 63) / 64, 0u);
+    for (size_t e = 0, bk = 0; bk < blk_slot.size(); ++bk) {
+        while (vseg_base[e + 1] <= bk * 64) ++e; /* entry e owns segment 64 * bk */
+        blk_slot[bk] = (uint32_t)e;
+    }
 
     s->ctx = ctx;
     ctx->refs.fetch_add(1);
@@ -784,6 +796,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_opjob = carve(b->n_ops * 4);
     const size_t o_vsegbase = carve(vseg_base.size() * 4);
     const size_t o_strokeop = carve(((size_t)n_strokes + 1) * 4);
+    const size_t o_blkslot = carve((blk_slot.size() + 1) * 4);
     const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     const size_t o_trav = carve(b->n_pts * 8);
@@ -822,6 +835,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
     s->d_vseg_base = (uint32_t*)(s->d_base + o_vsegbase);
     s->d_stroke_op = (uint32_t*)(s->d_base + o_strokeop);
+    s->d_vseg_blk_slot = (uint32_t*)(s->d_base + o_blkslot);
+    s->n_bin_slots = (uint32_t)stroke_op.size();
     s->d_cand_off = (uint32_t*)(s->d_base + o_candoff);
     s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
 
@@ -851,6 +866,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         put(o_opjob, op_job.data(), b->n_ops * 4);
         put(o_vsegbase, vseg_base.data(), vseg_base.size() * 4);
         put(o_strokeop, stroke_op.data(), stroke_op.size() * 4);
+        put(o_blkslot, blk_slot.data(), blk_slot.size() * 4);
         s->h_stage = stage;
         err = hipMemcpyAsync(s->d_base, stage, front_bytes, hipMemcpyHostToDevice, st);
         if (err != hipSuccess) {
@@ -881,6 +897,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_vseg_base, vseg_base.data(), vseg_base.size() * 4);
     if (err == hipSuccess) err = up(s->d_stroke_op, stroke_op.data(), stroke_op.size() * 4);
+    if (err == hipSuccess) err = up(s->d_vseg_blk_slot, blk_slot.data(), blk_slot.size() * 4);
     if (err != hipSuccess) {
         dev_free(ctx, s->d_base);
         scene_delete(s);

@@ -54,6 +54,25 @@ OSMT_HD float osmt_rcp24(int32_t d) {
     return 1.0f / (float)d;
 #endif
 }
+/* 24-bit multiply (one full-rate instruction on the GPU; both operands and the product fit) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OSMT_MUL24(a, b) __mul24((a), (b))
+#else
+#define OSMT_MUL24(a, b) ((a) * (b))
+#endif
+/* floor(n / d) for 0 <= n < 2^24, 0 < d, QUOTIENT < 2^12, reciprocal supplied: with so small a quotient the
+ * estimate (float)n * r is within 1e-3 of n/d, so its truncation is off by at most one and ONE correction round
+ * is enough (the walks' step / correction counts are all < 2048 on this path). */
+OSMT_HD int32_t osmt_udiv24r_small(int32_t n, int32_t d, float r) {
+    int32_t q = (int32_t)((float)n * r);
+    const int32_t rem = n - OSMT_MUL24(q, d);
+    q += (rem >= d) - (rem < 0);
+    return q;
+}
+OSMT_HD int32_t osmt_ceil_div_pos24r_small(int32_t n, int32_t d, float r) {
+    if (n <= 0) return 0;
+    return osmt_udiv24r_small(n + d - 1, d, r);
+}
 /* the same with the reciprocal of d supplied (several quotients share one divisor) */
 OSMT_HD int32_t osmt_udiv24r(int32_t n, int32_t d, float r) {
     int32_t q = (int32_t)((float)n * r);
@@ -106,8 +125,9 @@ OSMT_HD double osmt_fmod_pos(double x, double y) {
  * r within half an ulp of 1/d, q0 = RN(n*r) is within 2 ulps of n/d; e0 = n - d*q0 comes out of the FMA with at
  * most one rounding of a quantity 2^-52 smaller than n, so q1 = RN(q0 + e0*r) is a faithful rounding of n/d; for a
  * faithful q1 the residual e1 = n - d*q1 is exactly representable and q2 = RN(q1 + e1*r) is RN(n/d).  Requires
- * finite operands, d >= 1, n >= 0 and no overflow/underflow — here d = |p2 - p1| in [1, 2^30], n = |cross product|
- * <= 2^60, and any nonzero quotient is >= 2^-30.  Brute-forced against the hardware division in
+ * finite operands and no overflow/underflow — here d = |p2 - p1| in [1, 2^30] with n = |cross product| <= 2^60 (any
+ * nonzero quotient is >= 2^-30), and d = feather_dist (1.0 up to an ulp) with |n| <= ~2^16.  Every step is odd in n,
+ * so a negative numerator gives exactly the negated quotient.  Brute-forced against the hardware division in
  * tests/test_geom_closed_forms.py. */
 OSMT_HD double osmt_div_exact(double n, double d, double r) {
     const double q0 = n * r;
@@ -269,11 +289,11 @@ OSMT_HD void osmt_stroke_step(int32_t a32, int32_t b32, int32_t k32, int32_t* c_
 /* Main perpendicular of step k only: c = corrections so far, pe = p_error (see osmt_stroke_step). */
 OSMT_HD void osmt_stroke_main(int32_t a, int32_t b, int32_t k, int32_t* c_out, int32_t* pe) {
     if (b < OSMT_STEP24_MAX_B) {
-        const float r2b = osmt_rcp24(2 * b); /* both quotients divide by 2b */
-        const int32_t c = osmt_ceil_div_pos24r(2 * a * k - b, 2 * b, r2b);
-        const int32_t d = osmt_ceil_div_pos24r(2 * a * c - b, 2 * b, r2b);
+        const float r2b = osmt_rcp24(2 * b); /* both quotients divide by 2b; a, k, c, d <= b < 2048 */
+        const int32_t c = osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * a, k) - b, 2 * b, r2b);
+        const int32_t d = osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * a, c) - b, 2 * b, r2b);
         *c_out = c;
-        *pe = 2 * a * c - 2 * b * d;
+        *pe = OSMT_MUL24(2 * a, c) - OSMT_MUL24(2 * b, d);
     } else {
         const int64_t c = osmt_corrections(a, b, k);
         const int64_t d = osmt_corrections(a, b, c);
@@ -339,11 +359,11 @@ OSMT_HD int32_t osmt_extra_count(int32_t a, int32_t b, int32_t K) {
 }
 OSMT_HD void osmt_extra_event(int32_t a, int32_t b, int32_t m, int32_t* c_out, int32_t* k_out, int32_t* pe_out) {
     if (b < OSMT_STEP24_MAX_B) {
-        const float r2a = osmt_rcp24(2 * a); /* both quotients divide by 2a */
-        const int32_t c = osmt_udiv24r(2 * b * m - b, 2 * a, r2a) + 1;
+        const float r2a = osmt_rcp24(2 * a); /* both quotients divide by 2a; m <= a, c, k <= b < 2048 */
+        const int32_t c = osmt_udiv24r_small(OSMT_MUL24(2 * b, m) - b, 2 * a, r2a) + 1;
         *c_out = c;
-        *k_out = osmt_udiv24r(2 * b * c - b, 2 * a, r2a);
-        *pe_out = 2 * a * c - 2 * b * m;
+        *k_out = osmt_udiv24r_small(OSMT_MUL24(2 * b, c) - b, 2 * a, r2a);
+        *pe_out = OSMT_MUL24(2 * a, c) - OSMT_MUL24(2 * b, m);
     } else {
         const int64_t A = a, B = b, M = m;
         const int64_t c = osmt_udiv(2 * B * M - B, 2 * A) + 1;

@@ -48,6 +48,7 @@ struct osmt_stroke_aux {
     /* get_opacity_by_center_distance terms for cap_dist == 0 (opacity_calculator.rs:36,171-176):
      * hlw0 = sqrt(h*h - 0*0), feather_from/to/dist and opacity_mul of hlw0 */
     double hlw0, ff0, ft0, fd0, mul0;
+    double rfd0; /* RN(1 / fd0): the feather division of the walk becomes osmt_div_exact */
     osmt_dash_table main;
     osmt_dash_table caps;
 };
@@ -183,7 +184,7 @@ struct osmt_raster_args {
     uint32_t sub_rows;       /* W / OSMT_SUB_H */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
-    const uint32_t* skey;    /* per stroke slot: its sub-tile (sy * subs_per_row + sx), 0xFFFFFFFF = hole */
+    const uint2* skey;       /* per stroke slot: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -205,9 +206,11 @@ struct osmt_prepass_args {
     const uint32_t* op_aux;   /* op -> stroke slot */
     const uint32_t* op_job;   /* op -> job */
     const uint32_t* op_blk;   /* op -> first 64-edge block bbox (0xFFFFFFFF: none) */
-    const uint32_t* vseg_base; /* [n_strokes + 1]: first virtual segment (edges + cap stubs) of every stroke slot */
-    const uint32_t* stroke_op; /* [n_strokes]: stroke slot -> op */
-    uint32_t n_strokes;
+    /* binning table of the stroke ops that HAVE virtual segments (edges + cap stubs), in op order */
+    const uint32_t* vseg_base; /* [n_strokes + 1]: first virtual segment of every entry; last = n_vsegs */
+    const uint32_t* stroke_op; /* [n_strokes]: entry -> op */
+    const uint32_t* vseg_blk_slot; /* [ceil(n_vsegs / 64)]: entry that owns virtual segment 64 * b */
+    uint32_t n_strokes;        /* entries of the binning table */
     uint32_t n_vsegs;
     uint32_t scale;
     uint32_t sub_rows;
@@ -222,7 +225,7 @@ struct osmt_prepass_args {
     unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records); zeroed by the launcher */
     uint32_t* fmask;
     osmt_srec* srec;
-    uint32_t* skey;
+    uint2* skey;
     unsigned long long fmask_cap, srec_cap; /* arena capacities (groups / records); 0 = sizing pass: only the cursors are produced */
 };
 

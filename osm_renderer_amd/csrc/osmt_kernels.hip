@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
         sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
         sa->fd0 = sa->ft0 - sa->ff0;
+        sa->rfd0 = 1.0 / sa->fd0;
         sa->mul0 = fmin(2.0 * sa->hlw0, 1.0);
         const int cap_for_dashes = op.use_caps_for_dashes ? op.cap : OSMT_CAP_NONE;
         if (op.has_dashes) {
@@ -429,9 +430,13 @@ constexpr int NTHREADS = 64;       /* one wave per sub-tile: no cross-wave barri
 constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int ROWSTEP = NTHREADS / SUB;    /* rows between a thread's consecutive pixels */
 constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
-constexpr int SEGCAP = 64;         /* stroke records of one group held in LDS */
+#ifndef OSMT_V_SEGCAP
+#define OSMT_V_SEGCAP 32
+#endif
+constexpr int SEGCAP = OSMT_V_SEGCAP; /* slots of one filter pass = stroke records of one group held in LDS (<= 64 lanes) */
+static_assert(SEGCAP >= 8 && SEGCAP <= 64, "a filter pass is at most one wave wide");
 #ifndef OSMT_V_PLANE_STRIDE
-#define OSMT_V_PLANE_STRIDE 33
+#define OSMT_V_PLANE_STRIDE 32
 #endif
 constexpr int PLANE_STRIDE = OSMT_V_PLANE_STRIDE;
 #ifndef OSMT_V_ROWCAP
@@ -444,19 +449,42 @@ constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before th
 #else
 #define OSMT_DBG(...)
 #endif
+/* One compacted list entry of a chunk: everything the sequential per-op loop needs, staged in LDS by the lane that
+ * owns the op, so the loop itself never waits for global memory. */
+struct OpEntry {
+    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first slot of the op */
+    uint32_t kind_color; /* kind | r << 8 | g << 16 | b << 24 */
+    double opacity;
+    uint32_t aux;        /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
+    uint8_t nv;          /* STROKE: slots of the op, 255 = more than 64 (own filter passes); 0: a fill */
+    uint8_t stage;       /* FILL: index of the staged coverage words; STROKE: index of the staged constants; 255: not staged */
+    uint8_t _pad[2];
+};
+static_assert(sizeof(OpEntry) == 24, "OpEntry layout");
+/* per-op constants of the un-dashed / cap_dist == 0 across test (osmt_stroke_aux), staged with the entry */
+struct StrokeConst {
+    double ff0, ft0, fd0, rfd0, mul0;
+    uint32_t plain_main; /* the main calculator has no dash segments */
+    uint32_t _pad;
+};
+#ifndef OSMT_V_STAGECAP
+#define OSMT_V_STAGECAP 8
+#endif
+constexpr int STAGECAP = OSMT_V_STAGECAP; /* fills / strokes of one chunk whose data is staged in LDS; the rest reads global memory */
+
 struct RasterShared {
-    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] lane iterations [4] sum of per-pass max iterations [5] fill visits [6] set pixels */
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] lane iterations [5] fill visits [6] set pixels */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
-    /* generation alpha plane (f64 bit patterns).  Row stride PLANE_STRIDE = 33 cells: the runs of one pass start on
-     * consecutive steps of the segment's major axis, so a steep segment sends its 64 atomics to one column of
-     * consecutive rows — with a 32-cell stride all of them on ONE bank pair, with 33 on 32 different ones */
-    unsigned long long plane[PLANE_STRIDE * SUBH];
-    uint32_t oplist[OPCHUNK];       /* ops of the chunk that touch this sub-tile, in order */
-    uint32_t oparena[OPCHUNK];      /* their osmt_opinfo.arena_off */
-    uint8_t opnv[OPCHUNK];          /* their record counts: 0 = fill, 1..64, 255 = more than 64 (own passes) */
+    unsigned long long plane[PLANE_STRIDE * SUBH]; /* generation alpha plane (f64 bit patterns) */
+    OpEntry ent[OPCHUNK];           /* ops of the chunk that draw into this sub-tile, in order */
+    uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
+    StrokeConst sconst[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
     uint8_t grp_base[OPCHUNK + 1];  /* first record lane of every list entry of a group */
     uint8_t s_ent[OPCHUNK];         /* group-local index of the k-th STROKE entry of the group */
+#ifdef OSMT_V_LDSPAD
+    uint8_t occupancy_experiment_pad[OSMT_V_LDSPAD];
+#endif
 };
 
 struct SubRect {
@@ -483,7 +511,7 @@ __device__ __forceinline__ void blend_rgb(double* acc, double sr, double sg, dou
  * (get_opacity_by_start_distance returns (1.0, None) without looking at the distance,
  * opacity_calculator.rs:50-55), so long_start_dist / short_start_dist are dead values and
  * the feather terms are the per-op constants of osmt_stroke_aux. */
-__device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_seg& s,
+__device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_seg& s, const StrokeConst& kc,
                                                    const osmt_stroke_aux* __restrict__ sa,
                                                    const osmt_dash_table* __restrict__ tab, double traveled,
                                                    double initial_opacity, int32_t mn, int32_t mx, int32_t p_error,
@@ -501,21 +529,18 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
     const int32_t step_mn = -mul * s.mx_inc; /* p_mn += (when corrected) */
     const int64_t raw_step = (int64_t)(s.swap ? -s.sdx * step_mx : s.sdy * step_mx); /* steps are +-1: 32-bit products */
     const int64_t raw_corr = (int64_t)(s.swap ? s.sdy * step_mn : -s.sdx * step_mn);
-    const double ff0 = sa->ff0, ft0 = sa->ft0, fd0 = sa->fd0, mul0 = sa->mul0;
+    const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
     for (;;) {
         OSMT_DBG(++dbg_iters;)
         const double cd = osmt_div_exact(fabs((double)raw), s.denom, s.rdenom); /* == fabs(raw) / denom (line.rs:116-118) */
         double op;
         bool in_line;
         if (PLAIN) {
-            /* opacity_calculator.rs:171-185 with half_line_width = sqrt(h*h - 0*0) */
-            double v;
-            if (cd < ff0)
-                v = 1.0;
-            else if (cd < ft0)
-                v = div_or_same(ft0 - cd, fd0);
-            else
-                v = 0.0;
+            /* opacity_calculator.rs:171-185 with half_line_width = sqrt(h*h - 0*0); branch-free: the feather
+             * quotient (ft0 - cd) / fd0 is taken exactly from the pre-computed reciprocal and selected afterwards */
+            const double q = osmt_div_exact(ft0 - cd, fd0, rfd0);
+            double v = cd < ff0 ? 1.0 : q;
+            v = cd < ft0 ? v : 0.0;
             const double cdop = mul0 * v;
             op = fmin(1.0, cdop);
             in_line = cdop > 0.0;
@@ -525,7 +550,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
             in_line = opacity_calculate(tab, sa, traveled, cd, sd, &op);
         }
         if (!in_line) break;
-        if (px >= rc.x0 && px <= rc.x1 && py >= rc.y0 && py <= rc.y1) {
+        if ((uint32_t)(px - rc.x0) < (uint32_t)SUB && (uint32_t)(py - rc.y0) < (uint32_t)SUBH) {
             const double alpha = initial_opacity * op;
             /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118);
              * alpha >= +0, so the u64 order of the bit pattern is the f64 order */
@@ -548,7 +573,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
  * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
  * of line.rs:152-154, located directly by osmt_extra_event. */
 template <bool PLAIN>
-__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const osmt_stroke_aux* __restrict__ sa,
+__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
                                           double initial_opacity, const SubRect& rc,
                                           unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
     osmt_seg s;
@@ -571,7 +596,7 @@ __device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, co
     const int32_t mn = s.mn0 + c * s.mn_inc;
     /* seg_ranges only lists runs whose start lies within reach of the sub-tile on both axes */
     const bool use_caps = r.caps_table != 0u;
-    walk_perpendicular(PLAIN, s, sa, use_caps ? &sa->caps : &sa->main, r.traveled, initial_opacity, mn, mx, pe, mul, rc, plane OSMT_DBG(, dbg_iters, dbg_set));
+    walk_perpendicular(PLAIN, s, kc, sa, use_caps ? &sa->caps : &sa->main, r.traveled, initial_opacity, mn, mx, pe, mul, rc, plane OSMT_DBG(, dbg_iters, dbg_set));
 }
 
 /* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of one op, lanes packed: the record of item
@@ -579,7 +604,7 @@ __device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, co
  * of these records belongs to an un-dashed edge (no start-distance terms, per-op feather constants). */
 template <bool PLAIN, class Shared>
 __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t slot0, uint32_t nslot, uint32_t item_base,
-                                           uint32_t it_lo, uint32_t it_hi, const osmt_stroke_aux* __restrict__ sa,
+                                           uint32_t it_lo, uint32_t it_hi, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
                                            double initial_opacity, const SubRect& rc) {
     for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
         uint32_t lo_s = slot0, n = nslot;
@@ -591,7 +616,7 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
         }
         const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
         OSMT_DBG(uint32_t dbg_iters = 0, dbg_set = 0;)
-        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
+        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, kc, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
         OSMT_DBG(atomicAdd(&sh.dbg[2], 1u); atomicAdd(&sh.dbg[3], dbg_iters); atomicAdd(&sh.dbg[6], dbg_set); atomicMax(&sh.dbg[7], dbg_iters);)
     }
     OSMT_DBG(for (uint32_t it0 = it_lo; it0 < it_hi; it0 += 64u) {
@@ -685,14 +710,11 @@ struct FillRowsShared {
     int32_t xmax[ROWCAP][64];
 };
 
-__global__ __launch_bounds__(64) void k_fill_rows(const osmt_op* __restrict__ g_ops, uint32_t n_ops,
-                                                  const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
-                                                  const int2* __restrict__ g_pts, const uint32_t* __restrict__ g_op_blk,
-                                                  const osmt_blk_bbox* __restrict__ g_blk, uint32_t* __restrict__ g_submask,
-                                                  uint32_t sub_rows, uint32_t* __restrict__ g_fmask) {
-    __shared__ FillRowsShared sh;
-    const uint32_t o = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+__device__ __forceinline__ void fill_rows_body(FillRowsShared& sh, const uint32_t o, const uint32_t lane, const osmt_op* __restrict__ g_ops,
+                                               const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
+                                               const int2* __restrict__ g_pts, const uint32_t* __restrict__ g_op_blk,
+                                               const osmt_blk_bbox* __restrict__ g_blk, uint32_t* __restrict__ g_submask,
+                                               uint32_t sub_rows, uint32_t* __restrict__ g_fmask) {
     const osmt_opinfo* __restrict__ oi = &g_info[o];
     const uint32_t kind = oi->kind;
     if (kind != OSMT_OP_FILL_COLOR && kind != OSMT_OP_FILL_IMAGE) return;
@@ -798,22 +820,32 @@ __global__ __launch_bounds__(64) void k_fill_rows(const osmt_op* __restrict__ g_
  * op's slice of the stroke arena and sets the op's bit for that sub-tile.  k_raster's waves then only FILTER the
  * records of the ops they meet (one coalesced key load per 64 records) instead of each re-deriving the ranges of
  * every segment of every op that comes near: the work is done once per (segment, sub-tile), with full lanes. */
-__global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g_ops, const osmt_opinfo* __restrict__ g_info,
-                                                   const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
-                                                   const double* __restrict__ g_trav, const double* __restrict__ g_den,
-                                                   const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
-                                                   const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_stroke_op,
-                                                   uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale, uint32_t sub_rows,
-                                                   uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
-                                                   osmt_srec* __restrict__ g_srec, uint32_t* __restrict__ g_skey) {
-    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+__device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /* 65 words of LDS */, const uint32_t blk, const uint32_t lane,
+                                                const osmt_op* __restrict__ g_ops, const osmt_opinfo* __restrict__ g_info,
+                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
+                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
+                                                const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
+                                                const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_vseg_blk_slot,
+                                                const uint32_t* __restrict__ g_stroke_op, uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale,
+                                                uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
+                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey) {
+    /* slot of every lane's segment: the block's first segment lies in slot s0 (host table), the other 63 in the next
+     * <= 63 slots — one coalesced load of their bases, then a bisection in LDS */
+    const uint32_t g = blk * 64u + lane;
+    const uint32_t s0 = g_vseg_blk_slot[blk];
+    sh_base[lane] = g_vseg_base[min(s0 + lane, n_strokes)];
+    if (lane == 0u) sh_base[64] = g_vseg_base[min(s0 + 64u, n_strokes)];
+    __syncthreads();
     if (g >= n_vsegs) return;
-    uint32_t lo = 0u, hi = n_strokes; /* largest slot with vseg_base[slot] <= g */
+    /* largest j in 0..64 with base[j] <= g: holds for j = 0; entries past the table hold n_vsegs (> g); every slot of
+     * the (compressed) table owns at least one segment, so 64 consecutive segments span at most 64 slots */
+    uint32_t lo = 0u, hi = 65u;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (g_vseg_base[mid] <= g) lo = mid; else hi = mid;
+        if (sh_base[mid] <= g) lo = mid; else hi = mid;
     }
-    const uint32_t v = g - g_vseg_base[lo];
+    const uint32_t v = g - sh_base[lo];
+    lo += s0;
     const uint32_t o = g_stroke_op[lo];
     const osmt_opinfo oi = g_info[o];
     osmt_srec rec;
@@ -864,18 +896,40 @@ __global__ __launch_bounds__(64) void k_stroke_bin(const osmt_op* __restrict__ g
             osmt_item_ranges ir;
             const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, ft, rc.x0, rc.y0, rc.x1, rc.y1, &ir);
             if (cnt == 0u) {
-                g_skey[(size_t)oi.arena_off + slot] = 0xFFFFFFFFu;
+                g_skey[(size_t)oi.arena_off + slot] = make_uint2(0xFFFFFFFFu, 0u);
                 continue;
             }
             rec.k_lo0 = ir.k_lo0; rec.k_n0 = ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = ir.k_n1;
             rec.m_lo0 = ir.m_lo0; rec.n_x0 = ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = ir.n_x1;
             rec.count = cnt;
             g_srec[(size_t)oi.arena_off + slot] = rec;
-            g_skey[(size_t)oi.arena_off + slot] = (uint32_t)(sy * n_sub_x + sx);
+            g_skey[(size_t)oi.arena_off + slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (rec.caps_table << 31));
             rowbits |= 1u << sx;
         }
         if (rowbits) atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
     }
+}
+
+/* Both binning kernels in ONE launch: blocks [0, n_vblk) bin 64 stroke segments each (latency-bound: bisection, a chain
+ * of dependent loads, scattered 80-byte stores), blocks [n_vblk, n_vblk + n_ops) build the coverage rows of one fill op
+ * each (issue-bound) — the two kinds overlap on the machine instead of running back to back. */
+__global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
+                                               const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
+                                               const double* __restrict__ g_trav, const double* __restrict__ g_den,
+                                               const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
+                                               const uint32_t* __restrict__ g_op_blk, const osmt_blk_bbox* __restrict__ g_blk,
+                                               const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_vseg_blk_slot,
+                                               const uint32_t* __restrict__ g_stroke_op, uint32_t n_bin_slots, uint32_t n_vsegs, uint32_t n_vblk,
+                                               uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
+                                               const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
+                                               osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey) {
+    __shared__ FillRowsShared sh;
+    const uint32_t b = blockIdx.x;
+    if (b < n_vblk)
+        stroke_bin_body(reinterpret_cast<uint32_t*>(&sh.xmin[0][0]), b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
+                        g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey);
+    else if (b - n_vblk < n_ops)
+        fill_rows_body(sh, b - n_vblk, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, g_submask, sub_rows, g_fmask);
 }
 
 /* Scenes are rendered by waves that each own one 32x16 sub-tile for the whole display list: the premultiplied f64
@@ -890,7 +944,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * read-only and fetch wave-uniform records with scalar loads */
     const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_opinfo* OSMT_R g_info,
     const osmt_stroke_aux* OSMT_R g_aux, const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows,
-    const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint32_t* OSMT_R g_skey,
+    const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint2* OSMT_R g_skey,
     const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
     uint32_t g_n_images, void* OSMT_R g_out, size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab,
     const uint32_t* OSMT_R g_job_label_off, const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt,
@@ -945,45 +999,91 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
     OSMT_DBG(if (lane < 8) sh.dbg[lane] = 0u; __syncthreads();)
-    uint32_t job_n_ops_abl = job.n_ops; /* (diagnostic builds can zero it) */
+    const uint32_t n_ops = job.n_ops;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-#if defined(OSMT_ABL) && OSMT_ABL == 4
-    if (g_n_jobs) job_n_ops_abl = 0;
-#endif
-    for (uint32_t base = 0; base < job_n_ops_abl; base += OPCHUNK) {
+    /* the sub-tile bits of the NEXT chunk are fetched while the current one is processed */
+    auto load_bits = [&](uint32_t base) -> uint32_t {
+        const uint32_t i = base + lane;
+        return (i < n_ops) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sub_y] : 0u;
+    };
+    uint32_t bits_next = n_ops ? load_bits(0) : 0u;
+
+    for (uint32_t base = 0; base < n_ops; base += OPCHUNK) {
         /* ---- ordered compaction of the ops that draw into this sub-tile (exact bits from the binning kernels) ---- */
-        const uint32_t oi_idx = base + tid;
-        bool hit = false;
-        uint32_t my_nv = 0, my_arena = 0;
-        if (oi_idx < job_n_ops_abl) {
-            hit = (g_submask[(size_t)(job.op_off + oi_idx) * g_sub_rows + sub_y] >> sub_x) & 1u;
-            if (hit) {
-                const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + oi_idx];
-                my_nv = min(hi->rec_cap, 255u); /* slots of a stroke op; 0: a fill */
-                my_arena = hi->arena_off;
-            }
-        }
+        const bool hit = (bits_next >> sub_x) & 1u;
+        if (base + OPCHUNK < n_ops) bits_next = load_bits(base + OPCHUNK);
         const unsigned long long bal = __ballot(hit);
         const uint32_t total = (uint32_t)__popcll(bal);
         if (total == 0u) continue;
+        /* the lane that owns a hit op stages its entry: 48 bytes of osmt_opinfo, one round trip for the whole chunk */
+        uint32_t my_nv = 0;
+        bool is_stroke = false;
+        OpEntry e;
+        uint32_t geom = 0;
+        if (hit) {
+            const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + base + lane];
+            const uint32_t kind = hi->kind;
+            is_stroke = kind == OSMT_OP_STROKE;
+            my_nv = is_stroke ? min(hi->rec_cap, 255u) : 0u;
+            geom = hi->fill_geom;
+            e.arena = hi->arena_off;
+            e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
+            e.opacity = hi->opacity;
+            e.aux = is_stroke ? hi->aux : hi->image_id;
+            e.nv = (uint8_t)(my_nv > (uint32_t)SEGCAP ? 255u : my_nv);
+            e._pad[0] = e._pad[1] = 0;
+        }
+        const unsigned long long sbal = __ballot(hit && is_stroke), fbal = bal & ~sbal;
+        const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
+        const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & lanes_below);
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
-            const uint32_t pos = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            sh.oplist[pos] = oi_idx;
-            sh.opnv[pos] = (uint8_t)(my_nv > 64u ? 255u : my_nv);
-            sh.oparena[pos] = my_arena;
+            if (!is_stroke) {
+                const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
+                e.arena = (e.arena + (sub_y - sr0) * ncols + (sub_x - c0)) * SUBH; /* word index of this sub-tile's 16 rows */
+            }
+            e.stage = (uint8_t)(my_stage < (uint32_t)STAGECAP ? my_stage : 255u);
+            sh.ent[pos] = e;
+            if (is_stroke && my_stage < (uint32_t)STAGECAP) {
+                /* constants of the across test (second round trip, in parallel for all strokes of the chunk) */
+                const osmt_stroke_aux* __restrict__ sa = &g_aux[e.aux];
+                StrokeConst kc;
+                kc.ff0 = sa->ff0;
+                kc.ft0 = sa->ft0;
+                kc.fd0 = sa->fd0;
+                kc.rfd0 = sa->rfd0;
+                kc.mul0 = sa->mul0;
+                kc.plain_main = sa->main.n_segs == 0 ? 1u : 0u;
+                kc._pad = 0;
+                sh.sconst[my_stage] = kc;
+            }
         }
-        const bool any_stroke = __ballot(hit && my_nv != 0u) != 0ull;
+        const bool any_stroke = sbal != 0ull;
         if (any_stroke && !plane_clean) {
             for (uint32_t i = tid; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i] = 0ull;
             plane_clean = true;
         }
         __syncthreads();
+        {
+            /* coverage words of the chunk's fills: lane -> (staged fill, row), all in flight together */
+            const uint32_t n_fill_staged = min((uint32_t)__popcll(fbal), (uint32_t)STAGECAP);
+            for (uint32_t i = lane; i < n_fill_staged * SUBH; i += NTHREADS) {
+                const uint32_t f = i / SUBH, row = i % SUBH;
+                /* the f-th fill of the chunk is the entry at the position of the f-th set bit of fbal among bal */
+                unsigned long long m = fbal;
+                for (uint32_t k = 0; k < f; ++k) m &= m - 1ull;
+                const uint32_t fl = (uint32_t)__builtin_ctzll(m);
+                const uint32_t fpos = (uint32_t)__popcll(bal & ((1ull << fl) - 1ull));
+                sh.fmask[f][row] = g_fmask[(size_t)sh.ent[fpos].arena + row];
+            }
+        }
+        __syncthreads();
 
         uint32_t g0 = 0;
         while (g0 < total) {
-        /* ---- group = consecutive list entries whose stroke records fit in the 64 lanes of ONE filter pass;
-         * an op with more than 64 records forms a group of its own and is filtered 64 records at a time ---- */
+        /* ---- group = consecutive list entries whose stroke slots fit in the 64 lanes of ONE filter pass;
+         * an op with more than 64 slots forms a group of its own and is filtered 64 slots at a time ---- */
         uint32_t gend = g0, V = 0, n_str = 0;
         bool big = false;
         unsigned long long starts = 0ull; /* bit V_j for every stroke entry j of the group */
@@ -991,15 +1091,15 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             gend = total; /* fills only: one group, nothing to lay out */
         } else {
             for (; gend < total; ++gend) {
-                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.opnv[gend]);
-                if (nv > 64u) {
+                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.ent[gend].nv);
+                if (nv > (uint32_t)SEGCAP) {
                     if (gend == g0) {
                         big = true;
                         ++gend;
                     }
                     break;
                 }
-                if (V + nv > 64u) break;
+                if (V + nv > (uint32_t)SEGCAP) break;
                 if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
                 if (nv) {
                     starts |= 1ull << V;
@@ -1015,43 +1115,62 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         bool records_ready = false;
 
         for (uint32_t li = g0; li < gend; ++li) {
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.op_off + sh.oplist[li]));
-            const osmt_opinfo* __restrict__ oi = &g_info[o];
-            const uint32_t kind = oi->kind;
-#if defined(OSMT_ABL) && OSMT_ABL == 2
-            if (kind == OSMT_OP_STROKE) continue;
-#endif
-#if defined(OSMT_ABL) && OSMT_ABL == 3
-            if (kind != OSMT_OP_STROKE) continue;
-#endif
+            const OpEntry& en = sh.ent[li];
+            const uint32_t kc_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.kind_color);
+            const uint32_t kind = kc_ & 255u;
+            const double op_opacity = en.opacity;
+            const double cr = k_u8_over_255[(kc_ >> 8) & 255u], cg = k_u8_over_255[(kc_ >> 16) & 255u], cb = k_u8_over_255[kc_ >> 24];
+            const uint32_t stage = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.stage);
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
-                const osmt_stroke_aux* __restrict__ sa = &g_aux[oi->aux];
                 OSMT_DBG(if (lane == 0) sh.dbg[0] += 1u;)
-                const bool plain_main = sa->main.n_segs == 0;
-                const double initial_opacity = oi->opacity;
-                const uint32_t nrec_op = big ? oi->rec_cap : 0u;
-                const uint32_t n_rounds = big ? (nrec_op + 63u) / 64u : 1u;
+                const uint32_t aux_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.aux);
+                const uint32_t arena = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
+                const osmt_stroke_aux* __restrict__ sa = &g_aux[aux_i];
+                StrokeConst kc;
+                if (stage != 255u) {
+                    kc = sh.sconst[stage];
+                } else { /* more than STAGECAP strokes in one chunk of one sub-tile: read the table directly */
+                    kc.ff0 = sa->ff0;
+                    kc.ft0 = sa->ft0;
+                    kc.fd0 = sa->fd0;
+                    kc.rfd0 = sa->rfd0;
+                    kc.mul0 = sa->mul0;
+                    kc.plain_main = sa->main.n_segs == 0 ? 1u : 0u;
+                    kc._pad = 0;
+                }
+                const bool plain_main = __builtin_amdgcn_readfirstlane((int)kc.plain_main) != 0;
+                uint32_t n_rounds = 1u, big_cap = 0u;
+                if (big) {
+                    /* the op's slot count: the staged nv saturates at 255, the exact value is one scalar load away */
+                    unsigned long long m = bal; /* entry li of the chunk is the li-th set bit of bal */
+                    for (uint32_t k = 0; k < li; ++k) m &= m - 1ull;
+                    big_cap = g_info[job.op_off + base + (uint32_t)__builtin_ctzll(m)].rec_cap;
+                    n_rounds = (big_cap + (uint32_t)SEGCAP - 1u) / (uint32_t)SEGCAP;
+                }
                 for (uint32_t round = 0; round < n_rounds; ++round) {
                     if (big || !records_ready) {
-                        /* ---- filter pass: lane -> (list entry, record of that op); keep the records of THIS
-                         * sub-tile, compact them in lane order (= op order) and prefix-sum their item counts ---- */
+                        /* ---- filter pass: lane -> (list entry, slot of that op); keep the records of THIS sub-tile,
+                         * compact them in lane order (= op order, segment order) and prefix-sum their item counts ---- */
                         if (big) __syncthreads(); /* previous round's records are consumed */
                         uint32_t ridx = 0xFFFFFFFFu;
                         if (big) {
-                            const uint32_t v = round * 64u + lane;
-                            if (v < nrec_op) ridx = oi->arena_off + v;
+                            const uint32_t v = round * (uint32_t)SEGCAP + lane;
+                            if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
                         } else if (lane < V) {
                             /* entry = the k-th stroke of the group, k = strokes starting at or below this lane */
                             const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
                             const uint32_t k = (uint32_t)__popcll(starts & below) - 1u;
                             const uint32_t j = sh.s_ent[k];
-                            ridx = sh.oparena[g0 + j] + (lane - sh.grp_base[j]);
+                            ridx = sh.ent[g0 + j].arena + (lane - sh.grp_base[j]);
                         }
                         uint32_t cnt = 0, is_cap = 0;
-                        if (ridx != 0xFFFFFFFFu && g_skey[ridx] == sub) {
-                            cnt = g_srec[ridx].count;
-                            is_cap = g_srec[ridx].caps_table;
+                        if (ridx != 0xFFFFFFFFu) {
+                            const uint2 key = g_skey[ridx]; /* (sub-tile, item count | cap flag << 31); hole: sub-tile 0xFFFFFFFF */
+                            if (key.x == sub) {
+                                cnt = key.y & 0x7FFFFFFFu;
+                                is_cap = key.y >> 31;
+                            }
                         }
                         gbal = __ballot(cnt > 0u);
                         cbal = __ballot(cnt > 0u && is_cap != 0u);
@@ -1062,7 +1181,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             if (lane >= d) incl += y;
                         }
                         if (cnt > 0u) {
-                            const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << lane) - 1ull));
+                            const uint32_t slot = (uint32_t)__popcll(gbal & lanes_below);
                             sh.seg[slot] = g_srec[ridx];
                             sh.pre[slot] = incl;
                         }
@@ -1070,7 +1189,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         __syncthreads();
                     }
                     /* the op's records are lanes [va, vb) of the filter pass */
-                    uint32_t va = 0, vb = 64u;
+                    uint32_t va = 0, vb = (uint32_t)SEGCAP;
                     if (!big) {
                         va = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0]);
                         vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0 + 1u]);
@@ -1092,11 +1211,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                                  * passes, so the plain runs never execute the dash / cap arithmetic */
                                 const uint32_t n_edge = (uint32_t)__popcll(gbal & ~cbal & lanes_ab);
                                 const uint32_t item_mid = n_edge ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + n_edge - 1u]) : item_lo;
-                                if (n_edge) walk_items<true>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, sa, initial_opacity, rc);
+                                if (n_edge) walk_items<true>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, sa, op_opacity, rc);
                                 if (nslot > n_edge)
-                                    walk_items<false>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, sa, initial_opacity, rc);
+                                    walk_items<false>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, kc, sa, op_opacity, rc);
                             } else {
-                                walk_items<false>(sh, lane, slot0, nslot, item_lo, item_lo, item_hi, sa, initial_opacity, rc);
+                                walk_items<false>(sh, lane, slot0, nslot, item_lo, item_lo, item_hi, kc, sa, op_opacity, rc);
                             }
 #endif
                         }
@@ -1104,44 +1223,38 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
-                const double cr = k_u8_over_255[oi->color[0]];
-                const double cg = k_u8_over_255[oi->color[1]];
-                const double cb = k_u8_over_255[oi->color[2]];
+                /* branch-free: an untouched cell holds alpha = +0.0, and 0*c + (1 - 0)*old == old exactly */
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) {
                     const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * PLANE_STRIDE + lx;
-                    const unsigned long long bits = sh.plane[idx];
-                    if (bits != 0ull) {
-                        sh.plane[idx] = 0ull;
-                        const double al = __longlong_as_double((long long)bits);
-                        blend_rgb(acc[j], al * cr, al * cg, al * cb, al); /* from_color: o * (c/255) */
-                    }
+                    const double al = __longlong_as_double((long long)sh.plane[idx]);
+                    sh.plane[idx] = 0ull;
+                    blend_rgb(acc[j], al * cr, al * cg, al * cb, al); /* from_color: o * (c/255) */
                 }
                 __syncthreads(); /* the plane is reused by the next op */
             } else {
                 /* ---------------- fill_contour (fill.rs:16-47): coverage words from k_fill_rows ---------------- */
                 OSMT_DBG(if (lane == 0) sh.dbg[5] += 1u;)
-                const uint32_t geom = oi->fill_geom;
-                const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
-                const uint32_t* __restrict__ mw = g_fmask + ((size_t)oi->arena_off + (size_t)(sub_y - sr0) * ncols + (sub_x - c0)) * SUBH;
                 uint32_t cov = 0u; /* bit j = this lane's pixel j is covered */
+                if (stage != 255u) {
 #pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    /* wave-uniform addresses (scalar loads); the lane picks the word of its row pair */
-                    const uint32_t w0 = mw[2 * j], w1 = mw[2 * j + 1];
-                    const uint32_t w = ly0 ? w1 : w0;
-                    cov |= ((w >> lx) & 1u) << j;
+                    for (int j = 0; j < PXT; ++j) cov |= ((sh.fmask[stage][ly0 + (uint32_t)j * ROWSTEP] >> lx) & 1u) << j;
+                } else { /* more than STAGECAP fills in one chunk of one sub-tile: read the arena directly */
+                    const uint32_t* __restrict__ mw = g_fmask + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) cov |= ((mw[ly0 + (uint32_t)j * ROWSTEP] >> lx) & 1u) << j;
                 }
                 if (kind == OSMT_OP_FILL_COLOR) {
-                    const double o_ = oi->opacity;
-                    const double sr = o_ * k_u8_over_255[oi->color[0]];
-                    const double sg = o_ * k_u8_over_255[oi->color[1]];
-                    const double sb = o_ * k_u8_over_255[oi->color[2]];
+                    const double o_ = op_opacity;
+                    const double sr = o_ * cr, sg = o_ * cg, sb = o_ * cb;
+                    /* branch-free: an uncovered pixel blends the transparent colour, 0 + (1 - 0)*old == old exactly */
 #pragma unroll
-                    for (int j = 0; j < PXT; ++j)
-                        if ((cov >> j) & 1u) blend_rgb(acc[j], sr, sg, sb, o_);
+                    for (int j = 0; j < PXT; ++j) {
+                        const bool c_ = (cov >> j) & 1u;
+                        blend_rgb(acc[j], c_ ? sr : 0.0, c_ ? sg : 0.0, c_ ? sb : 0.0, c_ ? o_ : 0.0);
+                    }
                 } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
-                    const uint32_t img = oi->image_id;
+                    const uint32_t img = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.aux);
                     if (img < g_n_images) {
                         const osmt_image_desc im = g_images[img];
                         const double4* __restrict__ ipx = g_image_pool + im.offset;
@@ -1326,11 +1439,10 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
     if (a.n_ops == 0) return hipSuccess;
     hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
-    hipLaunchKernelGGL(k_fill_rows, dim3(a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.op_blk, a.blk, a.submask,
-                       a.sub_rows, a.fmask);
-    if (a.n_vsegs)
-        hipLaunchKernelGGL(k_stroke_bin, dim3((a.n_vsegs + 63u) / 64u), dim3(64), 0, st, a.ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden,
-                           a.aux, a.vseg_base, a.stroke_op, a.n_strokes, a.n_vsegs, a.scale, a.sub_rows, a.submask, a.cand_off, a.srec, a.skey);
+    const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
+    hipLaunchKernelGGL(k_prebin, dim3(n_vblk + a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden, a.aux,
+                       a.op_blk, a.blk, a.vseg_base, a.vseg_blk_slot, a.stroke_op, a.n_strokes, a.n_vsegs, n_vblk, a.scale, a.sub_rows,
+                       a.submask, a.cand_off, a.fmask, a.srec, a.skey);
     return hipGetLastError();
 }
 

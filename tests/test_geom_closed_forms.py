@@ -155,7 +155,11 @@ def test_div_exact_equals_the_hardware_division():
     d_int = rnd.integers(1, 1 << 30, size=len(m)).astype(np.float64)
     den = np.where(rnd.random(len(m)) < 0.5, np.sqrt(d_int * d_int + rnd.integers(0, 1 << 30, size=len(m)).astype(np.float64) ** 2), d_int)
     den = np.maximum(den, 1.0)
-    for nn, dd in ((num, den), (np.rint(num), den), (den * rnd.integers(1, 1000, size=len(m)), den)):
+    # the feather quotient (ft0 - cd) / fd0: fd0 = (h + 0.5) - (h - 0.5) is 1.0 up to an ulp, numerators of either sign
+    hw = rnd.random(len(m)) * 40.0
+    fd = (np.maximum(hw + 0.5, 1.0) - np.maximum(hw - 0.5, 0.0))
+    feather = (np.maximum(hw + 0.5, 1.0) - rnd.random(len(m)) * 45.0)
+    for nn, dd in ((num, den), (np.rint(num), den), (den * rnd.integers(1, 1000, size=len(m)), den), (feather, fd)):
         nn = np.ascontiguousarray(nn, dtype=np.float64)
         dd = np.ascontiguousarray(dd, dtype=np.float64)
         miss = L.shim_div_exact_check(nn.ctypes.data_as(C.POINTER(C.c_double)), dd.ctypes.data_as(C.POINTER(C.c_double)), len(nn), bad)
