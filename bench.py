@@ -54,6 +54,15 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPU bandwidth the container may use (cgroup v2 cpu.max), in cores; None = unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +151,31 @@ def main():
     dev = ctx.device
     solo = rank == 0 and world == 1
     count = torch.zeros(1, dtype=torch.int64, device=dev)
+    # The path's only collective: the sum of the per-rank tile counts.  Preferred: the library's own RCCL communicator
+    # (osmt_comm_init_rank + osmt_allreduce_tile_count; the unique id travels through torch.distributed, which the
+    # harness needs anyway for its barriers).  Any failure falls back to torch.distributed.all_reduce — also RCCL.
+    collective = "none (1 GPU)"
+    native_comm = False
+    if dist is not None:
+        collective = "torch.distributed.all_reduce (RCCL)"
+        try:
+            uid = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.from_numpy(shard.comm_unique_id()))
+            dist.broadcast(uid, src=0)
+            shard.comm_init_rank(ctx, uid.cpu().numpy(), rank, world)
+            ok = torch.tensor([1 if shard.allreduce_tile_count(ctx, 1) == world else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            native_comm = bool(ok.item())
+        except Exception as e:  # noqa: BLE001
+            print(f"rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([0], device=dev)
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            except Exception:  # noqa: BLE001
+                pass
+        if native_comm:
+            collective = "osmt_allreduce_tile_count (library-owned RCCL communicator, ncclAllReduce of one uint64)"
 
     def sync_all():
         torch.cuda.synchronize()
@@ -166,8 +200,12 @@ def main():
             if i is not None:
                 ev[i][1].record()
             if dist is not None:
-                count.fill_(dl.n_jobs)
-                dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
+                if native_comm:
+                    torch.cuda.current_stream().synchronize()  # the count is only final once the tiles are
+                    count.fill_(shard.allreduce_tile_count(ctx, dl.n_jobs))
+                else:
+                    count.fill_(dl.n_jobs)
+                    dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
 
         for _ in range(warmup):
             step()
@@ -224,6 +262,7 @@ def main():
             "scale": args.scale,
             "named_config": bool(named),
             "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
+            "collective": collective,
         },
         "roofline": {
             "kernel": "k_raster (fused fill/stroke/blend/to_rgb) — instruction-issue bound by construction, see roofline_issue; "
@@ -255,25 +294,15 @@ def main():
         del c4
 
     if solo and not args.no_extra:
-        # ---- measured HBM copy ceiling (float4 device copy, 1 GiB in + 1 GiB out) -------------------
+        # ---- measured HBM copy ceiling (16 B/lane grid-stride copy kernel of the library, 1 GiB in + 1 GiB out) ----
         try:
-            src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
-            dst = torch.empty_like(src)
-            for _ in range(3):
-                dst.copy_(src)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = 20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9
+            copy_gbs = ctx.hbm_copy_probe(1 << 30, 20)
             result["hbm_copy_ceiling"] = {
                 "value": copy_gbs, "unit": "GB/s", "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
-                "how": "torch vectorised (16 B/lane) elementwise device copy, 1 GiB read + 1 GiB written per launch, 20 launches, HIP events",
+                "how": "osmt_hbm_copy_probe: nontemporal 16 B/lane grid-stride copy kernel, 1 GiB read + 1 GiB written per launch, "
+                       "20 launches, HIP events on the launch stream",
             }
             result["roofline"]["frac_of_copy_ceiling"] = achieved / copy_gbs
-            del src, dst
         except Exception as e:  # noqa: BLE001
             result["hbm_copy_ceiling"] = {"error": str(e)}
 
@@ -505,8 +534,11 @@ def main():
         p1.close()
         tried, cpu_out, n_first = {}, None, 0
         budget_s = 3.0  # per sweep point; ~6 points -> ~20 s of wall clock
-        for th in sorted({1, max(1, cores // 16), max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
-            n_th = int(min(8192, max(2 * th, min(64 * th, budget_s * th / per_tile))))
+        quota = cpu_quota_cores()
+        usable = int(min(cores, quota)) if quota else cores  # threads beyond the cgroup quota only get throttled
+        points = {1, max(1, usable // 4), max(1, usable // 2), usable, min(cores, 2 * usable)}
+        for th in sorted(points):
+            n_th = int(min(8192, max(2 * th, min(64 * th, budget_s * min(th, usable) / per_tile))))
             sample = synth.make_tiles(synth.config_tiles(n_th), zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
             pool_t = oracle_py.Pool(th, args.scale)
             buf = np.empty((n_th, dl.dim, dl.dim, 4), dtype=np.uint8)
@@ -527,6 +559,7 @@ def main():
             "unit": "tiles/s",
             "cores": best_threads,
             "host_logical_cpus": cores,
+            "cgroup_cpu_quota_cores": cpu_quota_cores(),
             "cpu_model": cpu_model(),
             "sweep": {str(k): v for k, v in tried.items()},
             "kind": "port",

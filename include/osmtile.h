@@ -40,7 +40,8 @@ typedef enum osmt_status {
     OSMT_OOM = -2,
     OSMT_HIP_ERROR = -3,
     OSMT_UNSUPPORTED = -4,
-    OSMT_NO_DEVICE = -5
+    OSMT_NO_DEVICE = -5,
+    OSMT_RCCL_ERROR = -6 /* the RCCL library could not be loaded, or a collective failed */
 } osmt_status;
 
 /* One draw_one_area() call of the reference == one op == one "generation"
@@ -284,6 +285,49 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
  * is too small, so the call can be repeated with out_off[n_jobs] bytes). */
 int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off);
+
+/* ---- one node, several GPUs ------------------------------------------------ */
+/* The reference deals tiles round-robin to its worker threads, each with its own TilePixels
+ * (src/http_server.rs:50-83,105-108); tiles never exchange data (neighbours' geometry is duplicated into every
+ * tile's entity list, reader.rs:60-100).  Here a worker is a GPU: tile i of a batch belongs to shard i mod world. */
+
+/* The display list of one shard: jobs rank, rank + world, ... of `batch` with their ops, rings, points and dashes
+ * re-packed into pools of their own (a valid osmt_batch: the shard's op ranges partition its op pool).  The node table
+ * of OSMT_COORD_NODE_REF is shared, not copied: `batch->nodes` must outlive the shard.  Host only. */
+typedef struct osmt_batch_shard osmt_batch_shard;
+int osmt_batch_shard_create(const osmt_batch* batch, uint32_t rank, uint32_t world, osmt_batch_shard** out_shard);
+const osmt_batch* osmt_batch_shard_get(const osmt_batch_shard* shard);
+void osmt_batch_shard_free(osmt_batch_shard* shard);
+
+/* One call, n GPUs of one node: one host thread per context builds its shard and runs osmt_render_batch on it
+ * (upload, kernels and the chunked read-back pipeline of each GPU overlap with the others'); tile i lands at
+ * out_rgba + i * out_tile_stride_bytes exactly as with one GPU — every GPU writes its own interleaved slices of the
+ * one buffer (pinned memory from osmt_host_alloc of ANY of the contexts keeps the copies asynchronous).
+ * *out_tile_count (optional) = the all-reduced number of rendered tiles: over RCCL when osmt_comm_init_local has
+ * joined the contexts, summed on the host otherwise; it equals batch->n_jobs on success. */
+int osmt_render_batch_multi(osmt_ctx* const* ctxs, uint32_t n_ctx, const osmt_batch* batch, uint8_t* out_rgba,
+                            size_t out_tile_stride_bytes, uint64_t* out_tile_count);
+
+/* RCCL communicators for the tile-count reduction (the path's only collective: 8 bytes, latency-bound).  The library
+ * is loaded at the first of these calls (dlopen: an already loaded RCCL — e.g. PyTorch's — is reused).
+ *   one process, n GPUs:  osmt_comm_init_local(ctxs, n)                                   (ncclCommInitAll)
+ *   one process per GPU:  rank 0 calls osmt_comm_unique_id and sends the 128 bytes to the other ranks by its own
+ *                         means; every rank then calls osmt_comm_init_rank(ctx, id, rank, nranks)  (ncclCommInitRank) */
+#define OSMT_COMM_ID_BYTES 128
+int osmt_comm_unique_id(uint8_t id[OSMT_COMM_ID_BYTES]);
+int osmt_comm_init_rank(osmt_ctx* ctx, const uint8_t id[OSMT_COMM_ID_BYTES], uint32_t rank, uint32_t nranks);
+int osmt_comm_init_local(osmt_ctx* const* ctxs, uint32_t n_ctx);
+/* ncclAllReduce(sum) of one uint64 over the communicator of `ctx`; collective: every rank calls it.  Blocks until the
+ * result is on the host. */
+int osmt_allreduce_tile_count(osmt_ctx* ctx, uint64_t local, uint64_t* out_global);
+/* the same for the contexts of ONE process (a grouped call over all of them) */
+int osmt_allreduce_tile_count_local(osmt_ctx* const* ctxs, uint32_t n_ctx, const uint64_t* locals, uint64_t* out_global);
+
+/* ---- diagnostics ------------------------------------------------------------------------------ */
+/* What "HBM speed" is on this device: a 16-byte-per-lane grid-stride copy of `bytes` (read + write, `iters`
+ * launches timed with HIP events after one warm-up); *out_gb_per_s = 2 * bytes * iters / time.  bench.py quotes
+ * roofline fractions against this next to the 8 TB/s datasheet figure. */
+int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ TILE_SIZE = 256  # reference: src/tile.rs:6
 MAX_ZOOM = 18  # reference: src/tile.rs:5
 MAX_DASHES = 16
 
-OK, INVALID_ARG, OOM, HIP_ERROR, UNSUPPORTED, NO_DEVICE = 0, -1, -2, -3, -4, -5
+OK, INVALID_ARG, OOM, HIP_ERROR, UNSUPPORTED, NO_DEVICE, RCCL_ERROR = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 
 OP_NONE, OP_FILL_COLOR, OP_FILL_IMAGE, OP_STROKE = 0, 1, 2, 3
 CAP_NONE, CAP_BUTT, CAP_ROUND, CAP_SQUARE = 0, 1, 2, 3

@@ -10,7 +10,7 @@ SOURCES = ["osmt_kernels.hip", "osmt_labels.hip", "osmt_pngenc.hip", "osmt_api.c
 HEADERS = ["osmt_geom.h", "osmt_internal.h", os.path.join("..", "..", "include", "osmtile.h")]
 # -ffp-contract=off: the reference never fuses a*b+c; its u8 output truncates, so an FMA flips pixels.
 # zlib: PNG encoding of rendered tiles (osmt_png.cpp); --no-undefined: a symbol lost in an edit fails the build, not the first call
-LIBS = ["-lz", "-Wl,--no-undefined"]
+LIBS = ["-lz", "-ldl", "-lpthread", "-Wl,--no-undefined"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 
 

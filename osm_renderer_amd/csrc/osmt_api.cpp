@@ -11,7 +11,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
+
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -93,6 +96,10 @@ struct osmt_ctx {
     /* one reference for the handle returned by osmt_create + one per live scene: osmt_destroy on a context that still
      * has scenes only drops the handle's reference, the last osmt_scene_free tears the context down */
     std::atomic<int> refs{1};
+    /* RCCL communicator of the tile-count reduction (osmt_comm_init_*): ncclComm_t, rank and size */
+    void* comm = nullptr;
+    uint32_t comm_rank = 0, comm_size = 0;
+    unsigned long long* d_count = nullptr; /* two words of device memory for the reduction */
 };
 
 struct osmt_scene {
@@ -302,8 +309,11 @@ int sync_images(osmt_ctx* ctx, image_snapshot* snap) {
     return OSMT_OK;
 }
 
+void comm_destroy(osmt_ctx* ctx);
+
 void ctx_teardown(osmt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
+    comm_destroy(ctx);
     if (ctx->d_images) (void)hipFree(ctx->d_images);
     if (ctx->d_image_pool) (void)hipFree(ctx->d_image_pool);
     for (void* p : ctx->image_graveyard) (void)hipFree(p);
@@ -1495,6 +1505,389 @@ static int osmt_composite_body(osmt_ctx* ctx, const double* planes, const double
 int osmt_composite(osmt_ctx* ctx, const double* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t W,
                    uint32_t H, uint8_t* out_rgba) {
     return guarded([&] { return osmt_composite_body(ctx, planes, canvas, n, L, W, H, out_rgba); });
+}
+
+} /* extern "C" */
+
+/* ======================= one node, several GPUs ======================= */
+struct osmt_batch_shard {
+    osmt_batch b;
+    std::vector<osmt_tile_job> jobs;
+    std::vector<osmt_op> ops;
+    std::vector<osmt_ring> rings;
+    std::vector<double> latlon;
+    std::vector<int32_t> points;
+    std::vector<uint32_t> node_refs;
+    std::vector<double> dashes;
+};
+
+namespace {
+
+/* RCCL entry points, resolved at the first use.  dlopen instead of a link-time dependency: inside a PyTorch process
+ * the HIP runtime in use is PyTorch's own copy, and its own RCCL (already loaded) is the one built against it. */
+typedef struct { char internal[OSMT_COMM_ID_BYTES]; } rccl_unique_id;
+struct rccl_api {
+    void* handle = nullptr;
+    int (*GetUniqueId)(rccl_unique_id*) = nullptr;
+    int (*CommInitRank)(void**, int, rccl_unique_id, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+constexpr int RCCL_UINT64 = 5; /* ncclUint64 */
+constexpr int RCCL_SUM = 0;    /* ncclSum */
+
+rccl_api* rccl() {
+    static rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) { /* a copy that is already mapped wins */
+            api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (api.handle) break;
+        }
+        for (const char* n : names) {
+            if (api.handle) break;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!api.handle) {
+            const char* e = dlerror();
+            api.error = std::string("librccl could not be loaded: ") + (e ? e : "not found");
+            return;
+        }
+        auto sym = [&](const char* name) {
+            void* p = dlsym(api.handle, name);
+            if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + name;
+            return p;
+        };
+        api.GetUniqueId = (int (*)(rccl_unique_id*))sym("ncclGetUniqueId");
+        api.CommInitRank = (int (*)(void**, int, rccl_unique_id, int))sym("ncclCommInitRank");
+        api.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+        api.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
+        api.GroupStart = (int (*)())sym("ncclGroupStart");
+        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+
+int rccl_fail(const char* what, int rc) {
+    rccl_api* r = rccl();
+    return fail(OSMT_RCCL_ERROR, "%s failed: %s", what, (r->GetErrorString && rc) ? r->GetErrorString(rc) : (r->error.empty() ? "unknown" : r->error.c_str()));
+}
+
+#define RCCL_TRY(what, expr)                        \
+    do {                                            \
+        const int _rc = (expr);                     \
+        if (_rc != 0) return rccl_fail(what, _rc);  \
+    } while (0)
+
+int rccl_ready() {
+    rccl_api* r = rccl();
+    if (!r->handle || !r->error.empty()) return fail(OSMT_RCCL_ERROR, "%s", r->error.empty() ? "librccl not available" : r->error.c_str());
+    return OSMT_OK;
+}
+
+int comm_buffers(osmt_ctx* ctx) {
+    if (ctx->d_count) return OSMT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc((void**)&ctx->d_count, 2 * sizeof(unsigned long long)));
+    return OSMT_OK;
+}
+
+}  // namespace
+
+namespace {
+void comm_destroy(osmt_ctx* ctx) {
+    if (ctx->comm) {
+        rccl_api* r = rccl();
+        if (r->CommDestroy) (void)r->CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    if (ctx->d_count) (void)hipFree(ctx->d_count);
+    ctx->d_count = nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+static int shard_create_body(const osmt_batch* b, uint32_t rank, uint32_t world, osmt_batch_shard** out) {
+    if (!out) return fail(OSMT_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (world == 0 || rank >= world) return fail(OSMT_INVALID_ARG, "rank %u not in 0..%u", rank, world);
+    int rc = validate_batch(b);
+    if (rc != OSMT_OK) return rc;
+    osmt_batch_shard* s = new (std::nothrow) osmt_batch_shard();
+    if (!s) return fail(OSMT_OOM, "out of host memory");
+    const bool ll = b->coord_kind == OSMT_COORD_LATLON_F64, nr = b->coord_kind == OSMT_COORD_NODE_REF;
+    for (size_t j = rank; j < b->n_jobs; j += world) { /* tile i -> shard i mod world (http_server.rs:105-108) */
+        osmt_tile_job job = b->jobs[j];
+        const uint32_t old_pt = job.pt_off, new_pt = (uint32_t)(ll ? s->latlon.size() / 2 : nr ? s->node_refs.size() : s->points.size() / 2);
+        const uint32_t old_op = job.op_off;
+        job.op_off = (uint32_t)s->ops.size();
+        job.pt_off = new_pt;
+        for (uint32_t k = 0; k < job.n_ops; ++k) {
+            osmt_op op = b->ops[old_op + k];
+            if (op.kind != OSMT_OP_NONE) {
+                const uint32_t old_ring = op.ring_off;
+                op.ring_off = (uint32_t)s->rings.size();
+                for (uint32_t r = 0; r < op.n_rings; ++r) {
+                    osmt_ring ring = b->rings[old_ring + r];
+                    ring.first_pt = ring.first_pt - old_pt + new_pt;
+                    s->rings.push_back(ring);
+                }
+                if (op.kind == OSMT_OP_STROKE && op.has_dashes) {
+                    const uint32_t old_d = op.dashes_off;
+                    op.dashes_off = (uint32_t)s->dashes.size();
+                    s->dashes.insert(s->dashes.end(), b->dashes + old_d, b->dashes + old_d + op.n_dashes);
+                }
+            }
+            s->ops.push_back(op);
+        }
+        if (ll) s->latlon.insert(s->latlon.end(), b->latlon + 2 * (size_t)old_pt, b->latlon + 2 * ((size_t)old_pt + job.n_pts));
+        else if (nr) s->node_refs.insert(s->node_refs.end(), b->node_refs + old_pt, b->node_refs + old_pt + job.n_pts);
+        else s->points.insert(s->points.end(), b->points + 2 * (size_t)old_pt, b->points + 2 * ((size_t)old_pt + job.n_pts));
+        s->jobs.push_back(job);
+    }
+    memset(&s->b, 0, sizeof s->b);
+    s->b.jobs = s->jobs.data();
+    s->b.n_jobs = s->jobs.size();
+    s->b.ops = s->ops.data();
+    s->b.n_ops = s->ops.size();
+    s->b.rings = s->rings.data();
+    s->b.n_rings = s->rings.size();
+    s->b.coord_kind = b->coord_kind;
+    s->b.scale = b->scale;
+    s->b.latlon = ll ? s->latlon.data() : nullptr;
+    s->b.points = (!ll && !nr) ? s->points.data() : nullptr;
+    s->b.n_pts = ll ? s->latlon.size() / 2 : nr ? s->node_refs.size() : s->points.size() / 2;
+    s->b.dashes = s->dashes.empty() ? nullptr : s->dashes.data();
+    s->b.n_dashes = s->dashes.size();
+    s->b.nodes = nr ? b->nodes : nullptr;
+    s->b.n_nodes = nr ? b->n_nodes : 0;
+    s->b.node_refs = nr ? s->node_refs.data() : nullptr;
+    *out = s;
+    return OSMT_OK;
+}
+
+int osmt_batch_shard_create(const osmt_batch* b, uint32_t rank, uint32_t world, osmt_batch_shard** out) {
+    return guarded([&] { return shard_create_body(b, rank, world, out); });
+}
+
+const osmt_batch* osmt_batch_shard_get(const osmt_batch_shard* s) { return s ? &s->b : nullptr; }
+
+void osmt_batch_shard_free(osmt_batch_shard* s) { delete s; }
+
+static int comm_unique_id_body(uint8_t* id) {
+    if (!id) return fail(OSMT_INVALID_ARG, "NULL argument");
+    int rc = rccl_ready();
+    if (rc != OSMT_OK) return rc;
+    rccl_unique_id u;
+    RCCL_TRY("ncclGetUniqueId", rccl()->GetUniqueId(&u));
+    memcpy(id, u.internal, OSMT_COMM_ID_BYTES);
+    return OSMT_OK;
+}
+
+int osmt_comm_unique_id(uint8_t id[OSMT_COMM_ID_BYTES]) {
+    return guarded([&] { return comm_unique_id_body(id); });
+}
+
+static int comm_init_rank_body(osmt_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t nranks) {
+    if (!ctx || !id) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (nranks == 0 || rank >= nranks) return fail(OSMT_INVALID_ARG, "rank %u not in 0..%u", rank, nranks);
+    int rc = rccl_ready();
+    if (rc != OSMT_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    comm_destroy(ctx);
+    rc = comm_buffers(ctx);
+    if (rc != OSMT_OK) return rc;
+    rccl_unique_id u;
+    memcpy(u.internal, id, OSMT_COMM_ID_BYTES);
+    RCCL_TRY("ncclCommInitRank", rccl()->CommInitRank(&ctx->comm, (int)nranks, u, (int)rank));
+    ctx->comm_rank = rank;
+    ctx->comm_size = nranks;
+    return OSMT_OK;
+}
+
+int osmt_comm_init_rank(osmt_ctx* ctx, const uint8_t id[OSMT_COMM_ID_BYTES], uint32_t rank, uint32_t nranks) {
+    return guarded([&] { return comm_init_rank_body(ctx, id, rank, nranks); });
+}
+
+static int comm_init_local_body(osmt_ctx* const* ctxs, uint32_t n) {
+    if (!ctxs || n == 0) return fail(OSMT_INVALID_ARG, "no contexts");
+    int rc = rccl_ready();
+    if (rc != OSMT_OK) return rc;
+    std::vector<int> devs(n);
+    std::vector<void*> comms(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(OSMT_INVALID_ARG, "context %u is NULL", i);
+        for (uint32_t k = 0; k < i; ++k)
+            if (ctxs[k]->device == ctxs[i]->device) return fail(OSMT_INVALID_ARG, "contexts %u and %u share device %d", k, i, ctxs[i]->device);
+        devs[i] = ctxs[i]->device;
+        comm_destroy(ctxs[i]);
+        rc = comm_buffers(ctxs[i]);
+        if (rc != OSMT_OK) return rc;
+    }
+    RCCL_TRY("ncclCommInitAll", rccl()->CommInitAll(comms.data(), (int)n, devs.data()));
+    for (uint32_t i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_size = n;
+    }
+    return OSMT_OK;
+}
+
+int osmt_comm_init_local(osmt_ctx* const* ctxs, uint32_t n) {
+    return guarded([&] { return comm_init_local_body(ctxs, n); });
+}
+
+static int allreduce_local_body(osmt_ctx* const* ctxs, uint32_t n, const uint64_t* locals, uint64_t* out) {
+    if (!ctxs || !locals || !out || n == 0) return fail(OSMT_INVALID_ARG, "NULL argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (!ctxs[i] || !ctxs[i]->comm || ctxs[i]->comm_size != n) return fail(OSMT_INVALID_ARG, "context %u has no communicator of size %u (osmt_comm_init_local)", i, n);
+    rccl_api* r = rccl();
+    std::vector<hipStream_t> st(n, nullptr);
+    int rc = OSMT_OK;
+    for (uint32_t i = 0; i < n && rc == OSMT_OK; ++i) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || stream_acquire(ctxs[i], &st[i]) != hipSuccess ||
+            hipMemcpyAsync(ctxs[i]->d_count, &locals[i], 8, hipMemcpyHostToDevice, st[i]) != hipSuccess)
+            rc = fail(OSMT_HIP_ERROR, "tile-count staging failed on device %d", ctxs[i]->device);
+    }
+    if (rc == OSMT_OK) {
+        int e = r->GroupStart();
+        for (uint32_t i = 0; i < n && e == 0; ++i) {
+            (void)hipSetDevice(ctxs[i]->device);
+            e = r->AllReduce(ctxs[i]->d_count, ctxs[i]->d_count + 1, 1, RCCL_UINT64, RCCL_SUM, ctxs[i]->comm, st[i]);
+        }
+        const int e2 = r->GroupEnd();
+        if (e != 0 || e2 != 0) rc = rccl_fail("ncclAllReduce", e ? e : e2);
+    }
+    unsigned long long got = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!st[i]) continue;
+        (void)hipSetDevice(ctxs[i]->device);
+        if (rc == OSMT_OK && i == 0 && hipMemcpyAsync(&got, ctxs[0]->d_count + 1, 8, hipMemcpyDeviceToHost, st[0]) != hipSuccess)
+            rc = fail(OSMT_HIP_ERROR, "tile-count read-back failed");
+        if (hipStreamSynchronize(st[i]) != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "tile-count reduction failed on device %d", ctxs[i]->device);
+        stream_release(ctxs[i], st[i]);
+    }
+    if (rc == OSMT_OK) *out = got;
+    return rc;
+}
+
+int osmt_allreduce_tile_count_local(osmt_ctx* const* ctxs, uint32_t n, const uint64_t* locals, uint64_t* out) {
+    return guarded([&] { return allreduce_local_body(ctxs, n, locals, out); });
+}
+
+static int allreduce_body(osmt_ctx* ctx, uint64_t local, uint64_t* out) {
+    if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (!ctx->comm) return fail(OSMT_INVALID_ARG, "the context has no communicator (osmt_comm_init_rank / osmt_comm_init_local)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    HIP_TRY(stream_acquire(ctx, &st));
+    int rc = OSMT_OK;
+    unsigned long long got = 0;
+    hipError_t e = hipMemcpyAsync(ctx->d_count, &local, 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const int n = rccl()->AllReduce(ctx->d_count, ctx->d_count + 1, 1, RCCL_UINT64, RCCL_SUM, ctx->comm, st);
+        if (n != 0) rc = rccl_fail("ncclAllReduce", n);
+    }
+    if (e == hipSuccess && rc == OSMT_OK) e = hipMemcpyAsync(&got, ctx->d_count + 1, 8, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st);
+    stream_release(ctx, st);
+    if (rc == OSMT_OK && (e != hipSuccess || es != hipSuccess)) rc = fail(OSMT_HIP_ERROR, "tile-count reduction: %s", hipGetErrorString(e != hipSuccess ? e : es));
+    if (rc == OSMT_OK) *out = got;
+    return rc;
+}
+
+int osmt_allreduce_tile_count(osmt_ctx* ctx, uint64_t local, uint64_t* out) {
+    return guarded([&] { return allreduce_body(ctx, local, out); });
+}
+
+static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, uint8_t* out, size_t stride, uint64_t* out_count) {
+    if (!ctxs || n == 0 || !batch) return fail(OSMT_INVALID_ARG, "NULL argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (!ctxs[i]) return fail(OSMT_INVALID_ARG, "context %u is NULL", i);
+    int rc = validate_batch(batch);
+    if (rc != OSMT_OK) return rc;
+    if (batch->n_jobs && !out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
+    const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
+    if (stride < W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    /* one host thread per GPU: shard, upload, kernels and read-back of the devices run side by side; shard d writes
+     * tiles d, d + n, ... = base out + d * stride with a tile pitch of n * stride */
+    std::vector<int> rcs(n, OSMT_OK);
+    std::vector<std::string> msgs(n);
+    std::vector<uint64_t> counts(n, 0);
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < n; ++d) {
+        th.emplace_back([&, d] {
+            osmt_batch_shard* sh = nullptr;
+            int r = osmt_batch_shard_create(batch, d, n, &sh);
+            if (r == OSMT_OK && sh->b.n_jobs) r = osmt_render_batch(ctxs[d], &sh->b, out + (size_t)d * stride, (size_t)n * stride);
+            if (r == OSMT_OK) counts[d] = sh->b.n_jobs;
+            if (r != OSMT_OK) msgs[d] = osmt_last_error(); /* thread-local: carry it to the caller's thread */
+            rcs[d] = r;
+            osmt_batch_shard_free(sh);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t d = 0; d < n; ++d)
+        if (rcs[d] != OSMT_OK) return fail(rcs[d], "GPU %u (device %d): %s", d, ctxs[d]->device, msgs[d].c_str());
+    uint64_t total = 0;
+    bool have_comm = n > 1;
+    for (uint32_t d = 0; d < n; ++d) have_comm = have_comm && ctxs[d]->comm && ctxs[d]->comm_size == n;
+    if (have_comm) {
+        rc = allreduce_local_body(ctxs, n, counts.data(), &total);
+        if (rc != OSMT_OK) return rc;
+    } else {
+        for (uint64_t c : counts) total += c;
+    }
+    if (total != batch->n_jobs) return fail(OSMT_HIP_ERROR, "tile count %llu != %zu jobs", (unsigned long long)total, batch->n_jobs);
+    if (out_count) *out_count = total;
+    return OSMT_OK;
+}
+
+int osmt_render_batch_multi(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, uint8_t* out, size_t stride, uint64_t* out_count) {
+    return guarded([&] { return render_batch_multi_body(ctxs, n, batch, out, stride, out_count); });
+}
+
+static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out) {
+    if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (bytes < 16 || iters == 0) return fail(OSMT_INVALID_ARG, "nothing to copy");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n16 = bytes / 16;
+    char* d = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(stream_acquire(ctx, &st));
+    hipError_t e = dev_alloc(ctx, (void**)&d, 2 * n16 * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0x5A, 2 * n16 * 16, st);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = osmt_launch_copy16(d, d + n16 * 16, n16, st); /* warm-up */
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (uint32_t i = 0; i < iters && e == hipSuccess; ++i) e = osmt_launch_copy16(d, d + n16 * 16, n16, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dev_free(ctx, d);
+    stream_release(ctx, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "osmt_hbm_copy_probe: %s", hipGetErrorString(e));
+    *out = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    return OSMT_OK;
+}
+
+int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out) {
+    return guarded([&] { return hbm_copy_probe_body(ctx, bytes, iters, out); });
 }
 
 } /* extern "C" */

@@ -373,6 +373,18 @@ OSMT_HD void osmt_extra_event(int32_t a, int32_t b, int32_t m, int32_t* c_out, i
     }
 }
 
+/* osmt_corrections / osmt_first_step_with_corrections with the 32-bit fast path of short segments (b < 2048 and the
+ * count argument <= b + 2: every numerator stays below 2^24) */
+OSMT_HD int32_t osmt_corrections_any(int32_t a, int32_t b, int32_t k) {
+    if (b < OSMT_STEP24_MAX_B) return osmt_ceil_div_pos24(2 * a * k - b, 2 * b);
+    return (int32_t)osmt_corrections(a, b, k);
+}
+OSMT_HD int64_t osmt_first_step_any(int32_t a, int32_t b, int32_t c) {
+    if (c <= 0) return 0;
+    if (b < OSMT_STEP24_MAX_B) return (int64_t)osmt_udiv24(2 * b * c - b, 2 * a) + 1;
+    return osmt_first_step_with_corrections(a, b, c);
+}
+
 /* the item ranges of one (segment, sub-tile) pair, see osmt_seg_ranges */
 typedef struct osmt_item_ranges {
     int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
@@ -409,7 +421,7 @@ OSMT_HD uint32_t osmt_seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
     const int32_t mn_inc = swap ? (p1y <= p2y ? 1 : -1) : (p1x <= p2x ? 1 : -1);
     const int32_t LO = swap ? rx0 : ry0, HI = swap ? rx1 : ry1;     /* rectangle along the major axis */
     const int32_t mLO = swap ? ry0 : rx0, mHI = swap ? ry1 : rx1;   /* ... along the minor axis */
-    const int32_t c_end = (int32_t)osmt_corrections(amin, bmax, bmax);       /* c_k <= c_end */
+    const int32_t c_end = osmt_corrections_any(amin, bmax, bmax);       /* c_k <= c_end */
     uint32_t total = 0;
     for (int side = 0; side < 2; ++side) {
         const int32_t mul = side ? -1 : 1;
@@ -435,8 +447,8 @@ OSMT_HD uint32_t osmt_seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
                 /* steps with c_k in [cl, ch]: first k with c_k >= cl .. last k with c_k <= ch */
                 int64_t k1 = ka, k2 = kb;
                 if (amin > 0) {
-                    k1 = OSMT_MAX((int64_t)ka, osmt_first_step_with_corrections(amin, bmax, cl));
-                    k2 = OSMT_MIN((int64_t)kb, osmt_first_step_with_corrections(amin, bmax, (int64_t)ch + 1) - 1);
+                    k1 = OSMT_MAX((int64_t)ka, osmt_first_step_any(amin, bmax, cl));
+                    k2 = OSMT_MIN((int64_t)kb, osmt_first_step_any(amin, bmax, ch + 1) - 1);
                 } else if (cl > 0) {
                     continue; /* axis-parallel segment: c_k == 0 on every step */
                 }
@@ -449,8 +461,8 @@ OSMT_HD uint32_t osmt_seg_ranges(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
                 const int32_t e0 = osmt_extra_count(amin, bmax, ka);
                 const int32_t e1 = osmt_extra_count(amin, bmax, OSMT_MIN(kb, bmax - 1) + 1);
                 /* events with start count c_m in [cl, ch]: #events with c_m <= c is d(c) = corrections(a, b, c) */
-                const int32_t f0 = (cl > 0) ? (int32_t)osmt_corrections(amin, bmax, (int64_t)cl - 1) : 0;
-                const int32_t f1 = (int32_t)osmt_corrections(amin, bmax, ch);
+                const int32_t f0 = (cl > 0) ? osmt_corrections_any(amin, bmax, cl - 1) : 0;
+                const int32_t f1 = osmt_corrections_any(amin, bmax, ch);
                 const int32_t ma = OSMT_MAX(e0, f0) + 1, mb = OSMT_MIN(e1, f1);
                 if (ma > mb) continue;
                 m_lo = ma;

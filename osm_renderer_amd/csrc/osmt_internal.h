@@ -85,17 +85,16 @@ static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record
  * are contiguous (arena_off .. + rec_cap) and in segment order — no atomics, the layout is a pure function of the
  * scene; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
  * one coalesced load. */
-struct osmt_srec {
+struct alignas(16) osmt_srec {
     int32_t p1x, p1y, p2x, p2y;
     double traveled;      /* line.rs:31, before this edge (0 for a cap stub) */
     double denom;         /* center_dist_denom (line.rs:104) */
     double rdenom;        /* 1 / denom, correctly rounded (exact-division shortcut of the walk) */
-    int32_t k_lo0, k_n0, k_lo1, k_n1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
-    int32_t m_lo0, n_x0, m_lo1, n_x1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
-    uint32_t caps_table;  /* 1: opacity_calculator_for_outer_caps (line.rs:22) */
-    uint32_t count;       /* items = k_n0 + k_n1 + n_x0 + n_x1 */
+    int32_t k_lo0, k_lo1; /* main perpendiculars: steps [k_lo, k_lo + k_n) per side */
+    int32_t m_lo0, m_lo1; /* extra perpendiculars (line.rs:152-154): events [m_lo, m_lo + n_x) per side */
+    uint16_t k_n0, k_n1, n_x0, n_x1; /* <= sub-tile extent + OSMT_REACH_MAX */
 };
-static_assert(sizeof(osmt_srec) == 80, "osmt_srec layout");
+static_assert(sizeof(osmt_srec) == 64, "osmt_srec is one 64-byte line: four 16-byte stores by k_stroke_bin, four loads by k_raster");
 
 /* Ops with more than 64 edges get one bounding box per block of 64 consecutive edges (running
  * edge index over all rings): k_fill_rows skips the blocks whose rows miss the rows it is working on. */
@@ -243,6 +242,7 @@ hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uin
                            size_t out_stride, uint32_t* out_len, hipStream_t st);
 hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
                                    void* blob, hipStream_t st);
+hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);
 

@@ -476,6 +476,7 @@ struct RasterShared {
     OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] lane iterations [5] fill visits [6] set pixels */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
+    uint8_t seg_cap[SEGCAP];        /* the record belongs to a cap stub (opacity_calculator_for_outer_caps, line.rs:22) */
     unsigned long long plane[PLANE_STRIDE * SUBH]; /* generation alpha plane (f64 bit patterns) */
     OpEntry ent[OPCHUNK];           /* ops of the chunk that draw into this sub-tile, in order */
     uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
@@ -573,7 +574,7 @@ __device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_
  * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
  * of line.rs:152-154, located directly by osmt_extra_event. */
 template <bool PLAIN>
-__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
+__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const bool use_caps, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
                                           double initial_opacity, const SubRect& rc,
                                           unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
     osmt_seg s;
@@ -595,7 +596,6 @@ __device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, co
     const int32_t mx = s.mx0 + k * s.mx_inc;
     const int32_t mn = s.mn0 + c * s.mn_inc;
     /* seg_ranges only lists runs whose start lies within reach of the sub-tile on both axes */
-    const bool use_caps = r.caps_table != 0u;
     walk_perpendicular(PLAIN, s, kc, sa, use_caps ? &sa->caps : &sa->main, r.traveled, initial_opacity, mn, mx, pe, mul, rc, plane OSMT_DBG(, dbg_iters, dbg_set));
 }
 
@@ -616,7 +616,7 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
         }
         const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
         OSMT_DBG(uint32_t dbg_iters = 0, dbg_set = 0;)
-        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, kc, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
+        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, !PLAIN && sh.seg_cap[lo_s] != 0u, kc, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
         OSMT_DBG(atomicAdd(&sh.dbg[2], 1u); atomicAdd(&sh.dbg[3], dbg_iters); atomicAdd(&sh.dbg[6], dbg_set); atomicMax(&sh.dbg[7], dbg_iters);)
     }
     OSMT_DBG(for (uint32_t it0 = it_lo; it0 < it_hi; it0 += 64u) {
@@ -849,7 +849,7 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
     const uint32_t o = g_stroke_op[lo];
     const osmt_opinfo oi = g_info[o];
     osmt_srec rec;
-    rec.caps_table = 0u;
+    uint32_t is_cap = 0u;
     rec.traveled = 0.0;
     uint32_t cand_off;
     if (v < oi.n_edges) {
@@ -874,7 +874,7 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
         rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
         rec.denom = cs.denom;
         rec.rdenom = 1.0 / cs.denom;
-        rec.caps_table = 1u;
+        is_cap = 1u;
         cand_off = cs.cand_off;
     }
     if (rec.p1x == rec.p2x && rec.p1y == rec.p2y) return; /* line.rs:73-75 */
@@ -899,11 +899,10 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
                 g_skey[(size_t)oi.arena_off + slot] = make_uint2(0xFFFFFFFFu, 0u);
                 continue;
             }
-            rec.k_lo0 = ir.k_lo0; rec.k_n0 = ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = ir.k_n1;
-            rec.m_lo0 = ir.m_lo0; rec.n_x0 = ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = ir.n_x1;
-            rec.count = cnt;
+            rec.k_lo0 = ir.k_lo0; rec.k_n0 = (uint16_t)ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = (uint16_t)ir.k_n1;
+            rec.m_lo0 = ir.m_lo0; rec.n_x0 = (uint16_t)ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = (uint16_t)ir.n_x1;
             g_srec[(size_t)oi.arena_off + slot] = rec;
-            g_skey[(size_t)oi.arena_off + slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (rec.caps_table << 31));
+            g_skey[(size_t)oi.arena_off + slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (is_cap << 31));
             rowbits |= 1u << sx;
         }
         if (rowbits) atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
@@ -1184,6 +1183,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             const uint32_t slot = (uint32_t)__popcll(gbal & lanes_below);
                             sh.seg[slot] = g_srec[ridx];
                             sh.pre[slot] = incl;
+                            sh.seg_cap[slot] = (uint8_t)is_cap;
                         }
                         records_ready = true;
                         __syncthreads();
@@ -1414,7 +1414,23 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
     }
 }
 
+/* osmt_hbm_copy_probe: the plain streaming copy every HBM fraction is compared with */
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const v4u* __restrict__ src, v4u* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace
+
+hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, hipStream_t st) {
+    if (n16 == 0) return hipSuccess;
+    const size_t blocks = (n16 + 255) / 256;
+    const uint32_t grid = (uint32_t)(blocks < 256 * 32 ? blocks : 256 * 32); /* 256 CUs x 32 resident blocks, grid-stride beyond */
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, reinterpret_cast<const v4u*>(src), reinterpret_cast<v4u*>(dst), n16);
+    return hipGetLastError();
+}
 
 /* ---- launchers (C++ internal interface, see osmt_internal.h) ---------------- */
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,

@@ -22,7 +22,9 @@ EXPORTS = [
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_scene_set_labels", "osmt_scene_read_label_status",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
-    "osmt_validate_batch",
+    "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
+    "osmt_comm_unique_id", "osmt_comm_init_rank", "osmt_comm_init_local", "osmt_allreduce_tile_count",
+    "osmt_allreduce_tile_count_local", "osmt_hbm_copy_probe",
 ]
 
 
@@ -53,6 +55,18 @@ def load():
     L.osmt_register_image.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.osmt_render_batch.argtypes = [vp, C.POINTER(abi.Batch), u8p, C.c_size_t]
     L.osmt_validate_batch.argtypes = [C.POINTER(abi.Batch)]
+    L.osmt_batch_shard_create.argtypes = [C.POINTER(abi.Batch), C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.osmt_batch_shard_get.argtypes = [vp]
+    L.osmt_batch_shard_get.restype = C.POINTER(abi.Batch)
+    L.osmt_batch_shard_free.argtypes = [vp]
+    L.osmt_batch_shard_free.restype = None
+    L.osmt_render_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(abi.Batch), u8p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.osmt_comm_unique_id.argtypes = [u8p]
+    L.osmt_comm_init_rank.argtypes = [vp, u8p, C.c_uint32, C.c_uint32]
+    L.osmt_comm_init_local.argtypes = [C.POINTER(vp), C.c_uint32]
+    L.osmt_allreduce_tile_count.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.osmt_allreduce_tile_count_local.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.osmt_hbm_copy_probe.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_double)]
     L.osmt_scene_upload.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(vp)]
     L.osmt_scene_free.argtypes = [vp]
     L.osmt_scene_free.restype = None

@@ -1,0 +1,92 @@
+"""osmt_render_batch_multi, the RCCL tile-count reduction and the HBM copy probe through the C ABI."""
+import numpy as np
+import pytest
+
+from osm_renderer_amd import abi, shard, synth
+from osm_renderer_amd.lib import OsmtError
+from osm_renderer_amd.renderer import Context
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_batch_multi_on_one_device_equals_the_single_call(gpu_ctx, oracle):
+    """Three contexts (three worker threads inside the call), here all on device 0: every shard writes its own
+    interleaved slices of the one pinned buffer; pixels equal the one-GPU call and the oracle; count = n_jobs."""
+    dl = synth.make_tiles(synth.config_tiles(41), n_poly=12, n_line=10)
+    want = gpu_ctx.render_batch_host(dl)
+    ctxs = [gpu_ctx, Context(0), Context(0)]
+    pin = gpu_ctx.host_alloc((dl.n_jobs, dl.dim, dl.dim, 4))
+    try:
+        pin[:] = 3
+        got, cnt = shard.render_batch_multi(ctxs, dl, out=pin)
+        assert cnt == dl.n_jobs
+        np.testing.assert_array_equal(got, want)
+        got2, cnt2 = shard.render_batch_multi(ctxs[:1], dl)  # n = 1, pageable output
+        assert cnt2 == dl.n_jobs
+        np.testing.assert_array_equal(got2, want)
+        pick = [0, 1, 2, 20, 40]
+        np.testing.assert_array_equal(want[pick], oracle.render_batch(dl.subset(pick), threads=5))
+        few = dl.subset([0, 1])  # fewer tiles than GPUs: one shard is empty
+        got3, cnt3 = shard.render_batch_multi(ctxs, few)
+        assert cnt3 == 2
+        np.testing.assert_array_equal(got3, want[:2])
+    finally:
+        gpu_ctx.host_free(pin)
+        ctxs[1].close()
+        ctxs[2].close()
+
+
+def test_render_batch_multi_reports_the_failing_gpu(gpu_ctx):
+    bad = synth.config2(4)
+    bad.ops["ring_off"][7] = 10**7
+    with pytest.raises(OsmtError) as e:
+        shard.render_batch_multi([gpu_ctx], bad)
+    assert e.value.code == abi.INVALID_ARG
+
+
+def test_rccl_tile_count_reduction_single_rank(gpu_ctx):
+    """The collective of the path over a one-rank communicator (all a one-GPU box can host): unique id, init, sum."""
+    uid = shard.comm_unique_id()
+    assert uid.shape == (abi.COMM_ID_BYTES,) and uid.any()
+    shard.comm_init_rank(gpu_ctx, uid, 0, 1)
+    assert shard.allreduce_tile_count(gpu_ctx, 1250) == 1250
+    assert shard.allreduce_tile_count(gpu_ctx, (1 << 40) + 7) == (1 << 40) + 7
+    # a grouped local reduction over the same single context
+    shard.comm_init_local([gpu_ctx])
+    out, cnt = shard.render_batch_multi([gpu_ctx], synth.config2(3))
+    assert cnt == 3 and out.shape[0] == 3
+
+
+def test_rccl_local_communicator_over_all_visible_gpus():
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU tier); the one-rank path is covered above")
+    ctxs = [Context(d) for d in range(n)]
+    try:
+        shard.comm_init_local(ctxs)
+        dl = synth.make_tiles(synth.config_tiles(10 * n + 3), n_poly=10, n_line=8)
+        got, cnt = shard.render_batch_multi(ctxs, dl)
+        assert cnt == dl.n_jobs
+        np.testing.assert_array_equal(got, ctxs[0].render_batch_host(dl))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_comm_errors(gpu_ctx):
+    c = Context(0)
+    try:
+        with pytest.raises(OsmtError) as e:
+            shard.allreduce_tile_count(c, 1)  # no communicator yet
+        assert e.value.code == abi.INVALID_ARG
+        with pytest.raises(OsmtError):
+            shard.comm_init_local([c, gpu_ctx])  # two contexts on one device cannot form a communicator
+    finally:
+        c.close()
+
+
+def test_hbm_copy_probe(gpu_ctx):
+    gbs = gpu_ctx.hbm_copy_probe(1 << 28, 5)
+    assert 500.0 < gbs < 8000.0, gbs
