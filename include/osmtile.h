@@ -324,10 +324,11 @@ int osmt_allreduce_tile_count(osmt_ctx* ctx, uint64_t local, uint64_t* out_globa
 int osmt_allreduce_tile_count_local(osmt_ctx* const* ctxs, uint32_t n_ctx, const uint64_t* locals, uint64_t* out_global);
 
 /* ---- diagnostics ------------------------------------------------------------------------------ */
-/* What "HBM speed" is on this device: a 16-byte-per-lane grid-stride copy of `bytes` (read + write, `iters`
- * launches timed with HIP events after one warm-up); *out_gb_per_s = 2 * bytes * iters / time.  bench.py quotes
- * roofline fractions against this next to the 8 TB/s datasheet figure. */
-int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_gb_per_s);
+/* What "HBM speed" is on this device: a 16-byte-per-lane grid-stride stream over `bytes`, `iters` launches timed with
+ * HIP events after one warm-up.  *out_copy_gb_per_s = copy (bytes read + bytes written); *out_read_gb_per_s (optional)
+ * = the same stream read only — the ceiling of a read-dominated pass such as the layer composite.  bench.py quotes
+ * roofline fractions against these next to the 8 TB/s datasheet figure. */
+int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy_gb_per_s, double* out_read_gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -1856,38 +1856,41 @@ int osmt_render_batch_multi(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch*
     return guarded([&] { return render_batch_multi_body(ctxs, n, batch, out, stride, out_count); });
 }
 
-static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out) {
-    if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
+static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy, double* out_read) {
+    if (!ctx || !out_copy) return fail(OSMT_INVALID_ARG, "NULL argument");
     if (bytes < 16 || iters == 0) return fail(OSMT_INVALID_ARG, "nothing to copy");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n16 = bytes / 16;
     char* d = nullptr;
     hipStream_t st = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     HIP_TRY(stream_acquire(ctx, &st));
     hipError_t e = dev_alloc(ctx, (void**)&d, 2 * n16 * 16);
     if (e == hipSuccess) e = hipMemsetAsync(d, 0x5A, 2 * n16 * 16, st);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = osmt_launch_copy16(d, d + n16 * 16, n16, st); /* warm-up */
-    if (e == hipSuccess) e = hipEventRecord(e0, st);
-    for (uint32_t i = 0; i < iters && e == hipSuccess; ++i) e = osmt_launch_copy16(d, d + n16 * 16, n16, st);
-    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreate(&ev[k]);
+    if (e == hipSuccess) e = osmt_launch_copy16(d, d + n16 * 16, n16, false, st); /* warm-up */
+    if (e == hipSuccess) e = hipEventRecord(ev[0], st);
+    for (uint32_t i = 0; i < iters && e == hipSuccess; ++i) e = osmt_launch_copy16(d, d + n16 * 16, n16, false, st);
+    if (e == hipSuccess) e = hipEventRecord(ev[1], st);
+    for (uint32_t i = 0; i < iters && e == hipSuccess; ++i) e = osmt_launch_copy16(d, d + n16 * 16, n16, true, st);
+    if (e == hipSuccess) e = hipEventRecord(ev[2], st);
     const hipError_t es = hipStreamSynchronize(st);
     if (e == hipSuccess) e = es;
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
+    float ms_copy = 0.f, ms_read = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_copy, ev[0], ev[1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_read, ev[1], ev[2]);
+    for (int k = 0; k < 3; ++k)
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
     dev_free(ctx, d);
     stream_release(ctx, st);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "osmt_hbm_copy_probe: %s", hipGetErrorString(e));
-    *out = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    *out_copy = 2.0 * (double)(n16 * 16) * iters / ((double)ms_copy * 1e-3) / 1e9;
+    if (out_read) *out_read = (double)(n16 * 16) * iters / ((double)ms_read * 1e-3) / 1e9;
     return OSMT_OK;
 }
 
-int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out) {
-    return guarded([&] { return hbm_copy_probe_body(ctx, bytes, iters, out); });
+int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy, double* out_read) {
+    return guarded([&] { return hbm_copy_probe_body(ctx, bytes, iters, out_copy, out_read); });
 }
 
 } /* extern "C" */

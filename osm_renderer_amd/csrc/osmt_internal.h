@@ -242,7 +242,7 @@ hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uin
                            size_t out_stride, uint32_t* out_len, hipStream_t st);
 hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
                                    void* blob, hipStream_t st);
-hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, hipStream_t st);
+hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, bool read_only, hipStream_t st);
 hipError_t osmt_launch_composite(const void* planes, const double canvas[4], uint32_t n, uint32_t L, uint32_t npx,
                                  void* out, hipStream_t st);
 

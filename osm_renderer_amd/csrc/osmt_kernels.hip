@@ -1416,19 +1416,47 @@ __global__ __launch_bounds__(256) void k_composite(const v2d* __restrict__ plane
 
 /* osmt_hbm_copy_probe: the plain streaming copy every HBM fraction is compared with */
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+/* four independent 16-byte loads in flight per lane and trip; blocks own contiguous 16 KiB pieces */
 __global__ __launch_bounds__(256) void k_copy16(const v4u* __restrict__ src, v4u* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * 256u;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    const size_t stride = (size_t)gridDim.x * 1024u;
+    size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    for (; i + 768u < n; i += stride) {
+        const v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256u);
+        const v4u c = __builtin_nontemporal_load(src + i + 512u), d = __builtin_nontemporal_load(src + i + 768u);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + 256u);
+        __builtin_nontemporal_store(c, dst + i + 512u);
+        __builtin_nontemporal_store(d, dst + i + 768u);
+    }
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (i + 256u * k < n && i + 768u >= n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i + 256u * k), dst + i + 256u * k);
+}
+/* the read half alone: every lane folds what it loads into one word and the block leaves a single store behind */
+__global__ __launch_bounds__(256) void k_read16(const v4u* __restrict__ src, uint32_t* __restrict__ sink, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 1024u;
+    v4u acc = {0u, 0u, 0u, 0u};
+    size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    for (; i + 768u < n; i += stride) {
+        const v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256u);
+        const v4u c = __builtin_nontemporal_load(src + i + 512u), d = __builtin_nontemporal_load(src + i + 768u);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (i + 256u * k < n && i + 768u >= n) acc ^= __builtin_nontemporal_load(src + i + 256u * k);
+    const uint32_t w = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (w == 0x9E3779B9u) sink[blockIdx.x] = w; /* data-dependent, practically never taken: keeps the loads alive */
 }
 
 }  // namespace
 
-hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, hipStream_t st) {
+hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, bool read_only, hipStream_t st) {
     if (n16 == 0) return hipSuccess;
-    const size_t blocks = (n16 + 255) / 256;
-    const uint32_t grid = (uint32_t)(blocks < 256 * 32 ? blocks : 256 * 32); /* 256 CUs x 32 resident blocks, grid-stride beyond */
-    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, reinterpret_cast<const v4u*>(src), reinterpret_cast<v4u*>(dst), n16);
+    const size_t blocks = (n16 + 1023) / 1024;
+    const uint32_t grid = (uint32_t)(blocks < 256 * 16 ? blocks : 256 * 16); /* 256 CUs x 16 blocks, grid-stride beyond */
+    if (read_only)
+        hipLaunchKernelGGL(k_read16, dim3(grid), dim3(256), 0, st, reinterpret_cast<const v4u*>(src), reinterpret_cast<uint32_t*>(dst), n16);
+    else
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, reinterpret_cast<const v4u*>(src), reinterpret_cast<v4u*>(dst), n16);
     return hipGetLastError();
 }
 

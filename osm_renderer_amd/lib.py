@@ -66,7 +66,7 @@ def load():
     L.osmt_comm_init_local.argtypes = [C.POINTER(vp), C.c_uint32]
     L.osmt_allreduce_tile_count.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.osmt_allreduce_tile_count_local.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.osmt_hbm_copy_probe.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_double)]
+    L.osmt_hbm_copy_probe.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.osmt_scene_upload.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(vp)]
     L.osmt_scene_free.argtypes = [vp]
     L.osmt_scene_free.restype = None

@@ -195,10 +195,10 @@ class Context:
         return [out[int(off[i]) : int(off[i + 1])].tobytes() for i in range(dl.n_jobs)]
 
     def hbm_copy_probe(self, nbytes=1 << 30, iters=20):
-        """osmt_hbm_copy_probe: GB/s (read + write) of a 16-byte-per-lane device copy."""
-        out = C.c_double(0.0)
-        check(load().osmt_hbm_copy_probe(self._h, int(nbytes), int(iters), C.byref(out)))
-        return float(out.value)
+        """osmt_hbm_copy_probe: (copy GB/s counting read + write, read-only GB/s) of a 16-byte-per-lane device stream."""
+        cp, rd = C.c_double(0.0), C.c_double(0.0)
+        check(load().osmt_hbm_copy_probe(self._h, int(nbytes), int(iters), C.byref(cp), C.byref(rd)))
+        return float(cp.value), float(rd.value)
 
     # -- stages --------------------------------------------------------------------
     def project(self, latlon, zoom, tx, ty, scale=1.0):

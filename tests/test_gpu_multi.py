@@ -88,5 +88,5 @@ def test_comm_errors(gpu_ctx):
 
 
 def test_hbm_copy_probe(gpu_ctx):
-    gbs = gpu_ctx.hbm_copy_probe(1 << 28, 5)
-    assert 500.0 < gbs < 8000.0, gbs
+    cp, rd = gpu_ctx.hbm_copy_probe(1 << 28, 5)
+    assert 500.0 < cp < 8000.0 and 500.0 < rd < 8000.0, (cp, rd)
