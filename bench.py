@@ -536,12 +536,12 @@ def main():
         per_tile = (time.perf_counter() - t) / probe.n_jobs
         p1.close()
         tried, cpu_out, n_first = {}, None, 0
-        budget_s = 3.0  # per sweep point; ~6 points -> ~20 s of wall clock
+        budget_s = 2.5  # seconds of wall clock per sweep point (5 points), i.e. ~10-30 s of CPU work per point at the quota
         quota = cpu_quota_cores()
         usable = int(min(cores, quota)) if quota else cores  # threads beyond the cgroup quota only get throttled
         points = {1, max(1, usable // 4), max(1, usable // 2), usable, min(cores, 2 * usable)}
         for th in sorted(points):
-            n_th = int(min(8192, max(2 * th, min(64 * th, budget_s * min(th, usable) / per_tile))))
+            n_th = int(min(8192, max(2 * th, budget_s * min(th, usable) / per_tile)))
             sample = synth.make_tiles(synth.config_tiles(n_th), zoom=15, scale=args.scale, n_poly=args.n_poly, n_line=args.n_line)
             pool_t = oracle_py.Pool(th, args.scale)
             buf = np.empty((n_th, dl.dim, dl.dim, 4), dtype=np.uint8)
