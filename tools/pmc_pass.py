@@ -70,8 +70,8 @@ def run_pass(counters, child_args, timeout=240, keep_dir=None):
                 res.setdefault(k, {}).update(v)
         if keep_dir:
             os.makedirs(keep_dir, exist_ok=True)
-            for db in dbs:
-                shutil.copy(db, keep_dir)
+            for db in dbs:  # one database per pass: name it after the pass's first counter
+                shutil.copy(db, os.path.join(keep_dir, f"{counters[0]}_{os.path.basename(db)}"))
         return res
     except subprocess.TimeoutExpired:
         return {"error": f"rocprofv3 pass timed out after {timeout} s"}
