@@ -158,22 +158,30 @@ def main():
     native_comm = False
     if dist is not None:
         collective = "torch.distributed.all_reduce (RCCL)"
+        # step 1, no collective of the library yet: can EVERY rank load RCCL through the library?  (a rank that cannot
+        # must not leave the others waiting inside ncclCommInitRank)
         try:
-            uid = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid.copy_(torch.from_numpy(shard.comm_unique_id()))
-            dist.broadcast(uid, src=0)
-            shard.comm_init_rank(ctx, uid.cpu().numpy(), rank, world)
-            ok = torch.tensor([1 if shard.allreduce_tile_count(ctx, 1) == world else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            native_comm = bool(ok.item())
+            my_uid = shard.comm_unique_id()
+            can = 1
         except Exception as e:  # noqa: BLE001
-            print(f"rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-            flag = torch.tensor([0], device=dev)
+            print(f"rank {rank}: RCCL not loadable through libosmtile ({e})", file=sys.stderr)
+            my_uid, can = None, 0
+        flag = torch.tensor([can], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
             try:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            except Exception:  # noqa: BLE001
-                pass
+                uid = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid.copy_(torch.from_numpy(my_uid))
+                dist.broadcast(uid, src=0)
+                shard.comm_init_rank(ctx, uid.cpu().numpy(), rank, world)
+                ok = 1 if shard.allreduce_tile_count(ctx, 1) == world else 0
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                ok = 0
+            okt = torch.tensor([ok], device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            native_comm = bool(okt.item())
         if native_comm:
             collective = "osmt_allreduce_tile_count (library-owned RCCL communicator, ncclAllReduce of one uint64)"
 

@@ -159,18 +159,20 @@ OSMT_HD int osmt_fill_row_extent(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
     const int64_t j = p1y < p2y ? (int64_t)y - p1y : (int64_t)p1y - y;
     int64_t i0, i1;
     if (a < 2048 && b < 2048) {
-        /* short edge: (2j+1)a + 2b - 1 < 2^24, both divisions in 32-bit arithmetic */
+        /* short edge: (2j+1)a + 2b - 1 < 2^24 and every quotient is <= a < 2^11: both divisions share the f32
+         * reciprocal of 2b and need one correction round (osmt_udiv24r_small) */
         const int32_t a32 = (int32_t)a, b32 = (int32_t)b, j32 = (int32_t)j;
+        const float r2b = osmt_rcp24(2 * b32);
         int32_t q0, q1;
         if (a32 >= b32) {
-            q0 = (j32 == 0) ? 0 : osmt_ceil_div_pos24((2 * j32 - 1) * a32, 2 * b32);
-            q1 = (j32 == b32) ? a32 : osmt_ceil_div_pos24((2 * j32 + 1) * a32, 2 * b32) - 1;
+            q0 = (j32 == 0) ? 0 : osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 - 1, a32), 2 * b32, r2b);
+            q1 = (j32 == b32) ? a32 : osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 + 1, a32), 2 * b32, r2b) - 1;
         } else {
-            q0 = osmt_udiv24(2 * j32 * a32 + b32, 2 * b32);
+            q0 = osmt_udiv24r_small(OSMT_MUL24(2 * j32, a32) + b32, 2 * b32, r2b);
             if (j32 == b32) {
                 q1 = a32;
             } else {
-                q1 = osmt_ceil_div_pos24((2 * j32 + 1) * a32, 2 * b32) - 1;
+                q1 = osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 + 1, a32), 2 * b32, r2b) - 1;
                 if (q1 < q0) q1 = q0;
             }
         }

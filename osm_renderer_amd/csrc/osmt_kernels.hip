@@ -201,95 +201,101 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     }
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * a.scale);
     const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = W / OSMT_SUB_W;
-    double traveled = 0.0;
+    const bool is_stroke = op.kind == OSMT_OP_STROKE;
+    /* total edges first (rings only): the cap stub of the LAST iterated edge is recognised on the fly */
     uint32_t n_edges = 0;
+    for (uint32_t r = 0; r < op.n_rings; ++r) {
+        const uint32_t np = rings[op.ring_off + r].n_pts;
+        if (np >= 2u) n_edges += np - 1u;
+    }
+    oi.n_edges = n_edges;
+    const double hw = op.width / 2.0;
+    const double ft = stroke_ft(hw);
+    const bool caps = is_stroke && (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
+    osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0u, 1.0}, c1 = {0, 0, 0, 0, 0, 0u, 1.0};
+    unsigned long long cand = 0ull; /* slots reserved so far: one per (virtual segment, sub-tile of its window) */
+    double traveled = 0.0;
+    uint32_t seen = 0; /* running edge index + 1 over all rings (point_pairs.rs:36-40) */
     /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
     const uint32_t blk_off = a.op_blk[o];
     uint32_t cur_blk = 0xFFFFFFFFu;
     osmt_blk_bbox bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
+    /* ONE pass over the points.  A thread walks its op alone, so what it waits for is the latency of its own loads:
+     * the points are fetched four iterations ahead through a rotating register window. */
     for (uint32_t r = 0; r < op.n_rings; ++r) {
         const osmt_ring ring = rings[op.ring_off + r];
-        int2 prev = make_int2(0, 0);
-        for (uint32_t i = 0; i < ring.n_pts; ++i) {
-            const int2 p = pts[ring.first_pt + i];
-            if (blk_off != 0xFFFFFFFFu && i > 0) {
-                const uint32_t b_ = (n_edges + i - 1u) >> 6; /* running edge index / 64 */
-                if (b_ != cur_blk) {
-                    if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
-                    cur_blk = b_;
-                    bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
-                }
-                bb.x0 = min(bb.x0, min(prev.x, p.x));
-                bb.y0 = min(bb.y0, min(prev.y, p.y));
-                bb.x1 = max(bb.x1, max(prev.x, p.x));
-                bb.y1 = max(bb.y1, max(prev.y, p.y));
-            }
+        const int2* __restrict__ rp = pts + ring.first_pt;
+        const uint32_t np = ring.n_pts;
+        const int2 zero2 = make_int2(0, 0);
+        int2 q0 = np > 0u ? rp[0] : zero2, q1 = np > 1u ? rp[1] : zero2, q2 = np > 2u ? rp[2] : zero2, q3 = np > 3u ? rp[3] : zero2;
+        int2 prev = zero2;
+        for (uint32_t i = 0; i < np; ++i) {
+            const int2 p = q0;
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = (i + 4u < np) ? rp[i + 4u] : zero2;
             oi.x0 = min(oi.x0, p.x);
             oi.x1 = max(oi.x1, p.x);
             oi.y0 = min(oi.y0, p.y);
             oi.y1 = max(oi.y1, p.y);
-            if (op.kind == OSMT_OP_STROKE) {
-                if (i > 0) {
+            if (i > 0u) {
+                ++seen;
+                if (blk_off != 0xFFFFFFFFu) {
+                    const uint32_t b_ = (seen - 1u) >> 6; /* running edge index / 64 */
+                    if (b_ != cur_blk) {
+                        if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
+                        cur_blk = b_;
+                        bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
+                    }
+                    bb.x0 = min(bb.x0, min(prev.x, p.x));
+                    bb.y0 = min(bb.y0, min(prev.y, p.y));
+                    bb.x1 = max(bb.x1, max(prev.x, p.x));
+                    bb.y1 = max(bb.y1, max(prev.y, p.y));
+                }
+                if (is_stroke) {
                     /* |p2 - p1| is both the traveled increment (line.rs:31) and center_dist_denom
                      * (line.rs:104: sqrt(dy*dy + dx*dx) of the absolute deltas — the same f64) */
                     const double len = point_dist(prev.x, prev.y, p.x, p.y);
-                    a.den[ring.first_pt + i - 1] = len;
-                    a.rden[ring.first_pt + i - 1] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
+                    const uint32_t e = ring.first_pt + i - 1u;
+                    a.den[e] = len;
+                    a.rden[e] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
                     traveled += len;
+                    a.cand_off[e] = (uint32_t)min(cand, 0xFFFFFFFFull);
+                    if (!(prev.x == p.x && prev.y == p.y)) { /* a degenerate edge draws nothing (line.rs:73-75) */
+                        cand += window_count(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
+                        /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
+                         * degenerate (`first` is consumed by a degenerate first edge) */
+                        if (caps && seen == 1u) {
+                            const int2 ce = push_away_from(prev, p, hw);
+                            c0 = {prev.x, prev.y, ce.x, ce.y, 1, 0u, point_dist(ce.x, ce.y, prev.x, prev.y)};
+                        }
+                        if (caps && seen == n_edges) {
+                            const int2 ce = push_away_from(p, prev, hw);
+                            c1 = {p.x, p.y, ce.x, ce.y, 1, 0u, point_dist(ce.x, ce.y, p.x, p.y)};
+                        }
+                    }
                 }
-                a.trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
             }
+            if (is_stroke) a.trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
             prev = p;
         }
-        if (ring.n_pts >= 2) n_edges += ring.n_pts - 1;
     }
     if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
-    oi.n_edges = n_edges;
-    if (op.kind == OSMT_OP_STROKE) {
-        const double hw = op.width / 2.0;
-        const double ft = stroke_ft(hw);
-        const bool caps = (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
+    if (is_stroke) {
         osmt_stroke_aux* sa = &a.aux[oi.aux];
         sa->half_width = hw;
-        /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
-         * degenerate (`first` is consumed by a degenerate first edge); and the record reservation:
-         * one slot per (virtual segment, sub-tile of its window) */
-        unsigned long long cand = 0ull;
-        {
-            osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0u, 1.0}, c1 = {0, 0, 0, 0, 0, 0u, 1.0};
-            uint32_t seen = 0;
-            for (uint32_t r = 0; r < op.n_rings; ++r) {
-                const osmt_ring ring = rings[op.ring_off + r];
-                for (uint32_t i = 1; i < ring.n_pts; ++i) {
-                    ++seen;
-                    const int2 pa = pts[ring.first_pt + i - 1];
-                    const int2 pb = pts[ring.first_pt + i];
-                    a.cand_off[ring.first_pt + i - 1] = (uint32_t)min(cand, 0xFFFFFFFFull);
-                    if (pa.x == pb.x && pa.y == pb.y) continue; /* line.rs:73-75: draws nothing */
-                    cand += window_count(vseg_window(pa.x, pa.y, pb.x, pb.y, a.den[ring.first_pt + i - 1], ft, n_sub_x, n_sub_y));
-                    if (!caps) continue;
-                    if (seen == 1) {
-                        const int2 ce = push_away_from(pa, pb, hw);
-                        c0 = {pa.x, pa.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, pa.x, pa.y)};
-                    }
-                    if (seen == n_edges) {
-                        const int2 ce = push_away_from(pb, pa, hw);
-                        c1 = {pb.x, pb.y, ce.x, ce.y, 1, 0, point_dist(ce.x, ce.y, pb.x, pb.y)};
-                    }
-                }
-            }
-            /* a stub that push_away_from rounds back onto its own start draws nothing (line.rs:73-75) */
-            if (c0.valid && (c0.p1x != c0.p2x || c0.p1y != c0.p2y)) {
-                c0.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-                cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
-            }
-            if (c1.valid && (c1.p1x != c1.p2x || c1.p1y != c1.p2y)) {
-                c1.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-                cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
-            }
-            sa->cap_seg[0] = c0;
-            sa->cap_seg[1] = c1;
+        /* a stub that push_away_from rounds back onto its own start draws nothing (line.rs:73-75) */
+        if (c0.valid && (c0.p1x != c0.p2x || c0.p1y != c0.p2y)) {
+            c0.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
+            cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
         }
+        if (c1.valid && (c1.p1x != c1.p2x || c1.p1y != c1.p2y)) {
+            c1.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
+            cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
+        }
+        sa->cap_seg[0] = c0;
+        sa->cap_seg[1] = c1;
         sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
         sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
