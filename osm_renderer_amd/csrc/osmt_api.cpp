@@ -141,6 +141,7 @@ struct osmt_scene {
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
     std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_job, h_vseg_base, h_stroke_op, h_vseg_blk_slot, h_lab_wide;
+    std::vector<osmt_label_band> h_lab_bands;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
     /* public scenes: one event per stream the scene was rendered on, recorded behind the last launch that reads it.
@@ -158,6 +159,8 @@ struct osmt_scene {
     double* d_lab_a = nullptr;
     double* d_lab_s_wide = nullptr;
     uint32_t* d_lab_wide = nullptr;
+    osmt_label_band* d_lab_bands = nullptr;
+    uint32_t n_lab_bands = 0;
     uint32_t n_lab_wide = 0;
     uint32_t* d_lab_bitmap = nullptr;
     uint8_t* d_lab_ok = nullptr;
@@ -543,6 +546,8 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         ll.n_jobs = sc->n_jobs;
         ll.scale = sc->scale;
         ll.n_wide = sc->n_lab_wide;
+        ll.bands = sc->d_lab_bands;
+        ll.n_bands = sc->n_lab_bands;
         ll.job_label_off = sc->d_job_label_off;
         ll.segs = sc->d_lab_segs;
         ll.wide = sc->d_lab_wide;
@@ -1015,6 +1020,8 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * sc->scale);
     std::vector<osmt_labelinfo>& info = sc->h_lab_info; /* kept alive: the upload may be stream-ordered */
     std::vector<uint32_t>& wide = sc->h_lab_wide;
+    std::vector<osmt_label_band>& bands = sc->h_lab_bands;
+    bands.clear();
     info.assign(lb->n_labels, osmt_labelinfo{});
     wide.clear();
     size_t cells = 0, wide_cells = 0;
@@ -1069,10 +1076,16 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
                 o.wide_off = (uint32_t)wide_cells;
                 wide_cells += 64 * cols;
                 wide.push_back(l);
+            } else {
+                const uint32_t band_rows = std::min<uint32_t>(64u, OSMT_LABEL_LDS_CELLS / (uint32_t)cols);
+                for (uint32_t rb = 0; rb < rows; rb += band_rows) bands.push_back(osmt_label_band{l, rb});
             }
         }
     }
     if (cells > ((size_t)1 << 31)) return fail(OSMT_UNSUPPORTED, "label coverage windows need %zu cells (> 2^31)", cells);
+    /* every band scans all of its label's draw_line calls: longest first (ties keep draw order) */
+    std::stable_sort(bands.begin(), bands.end(),
+                     [&](const osmt_label_band& a, const osmt_label_band& b) { return info[a.label].n_segs > info[b.label].n_segs; });
 
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -1088,6 +1101,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     const size_t o_a = carve((cells + 1) * 8);
     const size_t o_s = carve((wide_cells + 1) * 8);
     const size_t o_wide = carve((wide.size() + 1) * 4);
+    const size_t o_bands = carve((bands.size() + 1) * sizeof(osmt_label_band));
     const size_t o_bm = carve(words * 4 <= 96 * 1024 ? 4 : (size_t)sc->n_jobs * words * 4); /* scale 1: the map lives in LDS */
     const size_t o_tl = carve(lb->n_labels * sizeof(osmt_tile_label));
     const size_t o_tlc = carve((size_t)sc->n_jobs * 4);
@@ -1107,6 +1121,8 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     sc->d_lab_s_wide = (double*)(base + o_s);
     sc->d_lab_wide = (uint32_t*)(base + o_wide);
     sc->n_lab_wide = (uint32_t)wide.size();
+    sc->d_lab_bands = (osmt_label_band*)(base + o_bands);
+    sc->n_lab_bands = (uint32_t)bands.size();
     sc->d_tile_labels = (osmt_tile_label*)(base + o_tl);
     sc->d_tile_label_cnt = (uint32_t*)(base + o_tlc);
     sc->d_lab_bitmap = (uint32_t*)(base + o_bm);
@@ -1120,6 +1136,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     if (e == hipSuccess) e = up(sc->d_job_label_off, lb->job_label_off, ((size_t)sc->n_jobs + 1) * 4);
     if (e == hipSuccess) e = up(sc->d_lab_segs, lb->segs, lb->n_segs * 32);
     if (e == hipSuccess) e = up(sc->d_lab_wide, wide.data(), wide.size() * 4);
+    if (e == hipSuccess) e = up(sc->d_lab_bands, bands.data(), bands.size() * sizeof(osmt_label_band));
     /* the verdicts and the error word are cleared by the label stage itself, on the render stream (osmt_launch_labels) */
     if (e != hipSuccess) {
         dev_free(ctx, sc->d_lab_base);

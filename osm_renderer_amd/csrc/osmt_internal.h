@@ -149,8 +149,17 @@ struct osmt_tile_label {
     uint32_t _pad;
 };
 
+/* One k_label_cover wave: OSMT_LABEL_LDS_CELLS / cols stripes of one label's window, starting at stripe `rbase`.  Stripes
+ * never share a cell, so the bands of a label are independent waves; the list is ordered by falling work
+ * (draw_line calls to scan), so that the longest bands start first and the kernel does not end on one straggler. */
+struct osmt_label_band {
+    uint32_t label, rbase;
+};
+
 struct osmt_label_launch {
     const osmt_labelinfo* info;
+    const osmt_label_band* bands;
+    uint32_t n_bands;
     uint32_t n_labels, n_jobs, scale, n_wide;
     const uint32_t* job_label_off;
     const double* segs;

@@ -11,7 +11,7 @@
 /* ------------------------------------------------------------------------- */
 /* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
  *
- * k_label_cover    one wave per label.  Lane = one stripe y of the label's window; the wave digests the
+ * k_label_cover    one wave per band of a label's window (osmt_label_band).  Lane = one stripe y; the wave digests the
  *                  draw_line calls 64 at a time (one call per lane: the y-independent part of draw_line,
  *                  two f64 divisions) into LDS, then every lane walks the calls that cross the band IN
  *                  CALL ORDER and adds those that cross its stripe into its own row of the LDS-resident
@@ -101,15 +101,14 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab, uint32_t n_labels,
+__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab,
+                                                    const osmt_label_band* __restrict__ g_band, uint32_t n_bands,
                                                     const double4* __restrict__ g_seg, double* __restrict__ g_a,
                                                     uint32_t* g_err) {
     __shared__ double sh_a[LC_CELLS];
     __shared__ double sh_s[LC_CELLS];
-    const uint32_t l = blockIdx.x;
-    if (l >= n_labels) return;
-    const osmt_labelinfo* __restrict__ li = g_lab + l;
-    if (!li->has_text || li->ry0 > li->ry1 || li->cols == 0 || li->cols > LC_CELLS) return;
+    if (blockIdx.x >= n_bands) return;
+    const osmt_labelinfo* __restrict__ li = g_lab + g_band[blockIdx.x].label;
     const uint32_t lane = threadIdx.x;
     const int32_t ry0 = li->ry0, cx0 = li->cx0;
     const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
@@ -118,7 +117,8 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
     double* __restrict__ A = g_a + li->plane_off;
     const uint32_t band_rows = min(64u, LC_CELLS / cols);
     bool oob = false;
-    for (uint32_t rbase = 0; rbase < R; rbase += band_rows) {
+    {
+        const uint32_t rbase = g_band[blockIdx.x].rbase;
         const uint32_t nrow = min(band_rows, R - rbase);
         const uint32_t cnt = nrow * cols;
         for (uint32_t i = lane; i < cnt; i += 64u) {
@@ -130,17 +130,28 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
         const int32_t y = ry0 + (int32_t)(rbase + lane);
         double* a_row = sh_a + (active ? lane * cols : 0u);
         double* s_row = sh_s + (active ? lane * cols : 0u);
-        /* the stripe owner keeps the cell it is adding to in a register (consecutive calls of a curve land in
-         * the same cell): LDS is touched only when the cell changes */
-        uint32_t a_col = LC_NOCOL, s_col = LC_NOCOL;
-        double a_val = 0.0, s_val = 0.0;
+        /* Every cell belongs to exactly one channel, so each channel keeps the cell it is adding to in a register that
+         * is UNIFORM across the wave (the run's addends arrive by v_readlane, the sum is the same in every lane): no
+         * divergent code between the head of a run and its last addend, and LDS is touched only when a channel moves
+         * on to another cell. */
+        uint32_t ckey[LC_CH];
+        double cval[LC_CH];
+#pragma unroll
+        for (int k = 0; k < LC_CH; ++k) {
+            ckey[k] = LC_NOCOL;
+            cval[k] = 0.0;
+        }
         uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys (x - cx0) */
         const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
+        auto cell_of = [&](uint32_t K) -> double* { return ((K >> 31) ? sh_s : sh_a) + ((K >> 20) & 0x7FFu) * cols + (K & 0xFFFFFu); };
+        double4 seg_next = n_segs > lane ? segs[lane] : make_double4(0.0, 0.0, 0.0, 0.0);
         for (uint32_t base = 0; base < n_segs; base += 64u) {
             /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
             const uint32_t i = base + lane;
+            const double4 seg_cur = seg_next;
+            if (i + 64u < n_segs) seg_next = segs[i + 64u]; /* in flight while this batch is worked on */
             bool overlaps = false, slow = false;
-            osmt_label_seg sg;
+            osmt_label_seg sg = {};
             uint32_t chmask = 0u;
             uint32_t ekey[LC_CH]; /* kind << 31 | local stripe << 20 | column */
             double eval[LC_CH];
@@ -149,10 +160,13 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                 ekey[k] = 0xFFFFFFFFu;
                 eval[k] = 0.0;
             }
-            if (i < n_segs) {
-                sg = label_seg_prep(segs[i]);
-                overlaps = sg.yl >= band0 && sg.yf <= band1; /* also drops delta == 0 (yf > yl) */
+            if (i < n_segs) /* draw_line returns at once for delta == 0 (font/rasterizer.rs:30-32) */
+                overlaps = seg_cur.y != seg_cur.w && (int32_t)floor(fmax(seg_cur.y, seg_cur.w)) >= band0 &&
+                           (int32_t)floor(fmin(seg_cur.y, seg_cur.w)) <= band1;
+            if (!__ballot(overlaps)) continue; /* 64 calls of glyphs in other bands: no division spent on them */
+            {
                 if (overlaps) {
+                    sg = label_seg_prep(seg_cur);
                     const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
                     auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
                         const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     }
                 }
             }
-            /* ---- phase 2, lane = stripe: the parked sums are applied strictly in call order ---- */
+            /* ---- phase 2: the parked sums are applied strictly in call order, the whole wave in step ---- */
             unsigned long long rest = __ballot(overlaps);
             const unsigned long long slowm = __ballot(overlaps && slow);
             while (rest) {
@@ -232,33 +246,16 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                         hm &= hm - 1ull;
                         const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((cont >> 1) >> h));
                         const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)h);
-                        const uint32_t col = K & 0xFFFFFu;
-                        if (((K >> 20) & 0x7FFu) == lane) { /* the stripe's owner; v_readlane below ignores EXEC */
-                            uint32_t src = h, left = run;
-                            if (K >> 31) {
-                                if (col != s_col) {
-                                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-                                    s_val = s_row[col];
-                                    s_col = col;
-                                }
-                                do {
-                                    s_val += readlane_f64(eval[ch], src);
-                                    ++src;
-                                } while (--left);
-                            } else {
-                                if (col != a_col) {
-                                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-                                    a_val = a_row[col];
-                                    a_col = col;
-                                }
-                                do {
-                                    a_val += readlane_f64(eval[ch], src);
-                                    ++src;
-                                } while (--left);
+                        if (K != ckey[ch]) { /* the channel moves to another cell */
+                            if (ckey[ch] != LC_NOCOL && lane == 0u) *cell_of(ckey[ch]) = cval[ch];
+                            cval[ch] = *cell_of(K); /* same wave, LDS in order: sees the store above */
+                            ckey[ch] = K;
+                            if (((K >> 20) & 0x7FFu) == lane) {
+                                c_min = min(c_min, K & 0xFFFFFu);
+                                c_max = max(c_max, K & 0xFFFFFu);
                             }
-                            c_min = min(c_min, col);
-                            c_max = max(c_max, col);
                         }
+                        for (uint32_t src = h; src < h + run; ++src) cval[ch] += readlane_f64(eval[ch], src);
                     }
                 }
                 if (sl >= 64u) break;
@@ -274,9 +271,11 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     q.sign = readlane_f64(sg.sign, j);
                     q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
                     q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
-                    if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-                    if (s_col != LC_NOCOL) s_row[s_col] = s_val;
-                    a_col = s_col = LC_NOCOL;
+#pragma unroll
+                    for (int k = 0; k < LC_CH; ++k) {
+                        if (ckey[k] != LC_NOCOL && lane == 0u) *cell_of(ckey[k]) = cval[k];
+                        ckey[k] = LC_NOCOL;
+                    }
                     if (active && y >= q.yf && y <= q.yl) {
                         int32_t x_min = INT32_MAX, x_max = INT32_MIN;
                         oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
@@ -289,8 +288,10 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                 rest &= ~((2ull << sl) - 1ull);
             }
         }
-        if (a_col != LC_NOCOL) a_row[a_col] = a_val;
-        if (s_col != LC_NOCOL) s_row[s_col] = s_val;
+#pragma unroll
+        for (int k = 0; k < LC_CH; ++k)
+            if (ckey[k] != LC_NOCOL && lane == 0u) *cell_of(ckey[k]) = cval[k];
+        __syncthreads(); /* one wave: orders lane 0's stores before the row owners' scan */
         /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
         if (active && c_min <= c_max) {
             double s_acc = 0.0;
@@ -449,7 +450,7 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
     hipError_t ce = hipMemsetAsync(a.ok, 0, a.n_labels, st);
     if (ce == hipSuccess) ce = hipMemsetAsync(a.err, 0, 4, st);
     if (ce != hipSuccess) return ce;
-    hipLaunchKernelGGL(k_label_cover, dim3(a.n_labels), dim3(64), 0, st, a.info, a.n_labels, segs, a.plane_a, a.err);
+    if (a.n_bands) hipLaunchKernelGGL(k_label_cover, dim3(a.n_bands), dim3(64), 0, st, a.info, a.bands, a.n_bands, segs, a.plane_a, a.err);
     if (a.n_wide)
         hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
                            a.plane_s_wide, a.err);
