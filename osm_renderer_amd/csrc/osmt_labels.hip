@@ -86,13 +86,13 @@ __device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
 
 #define LC_CELLS OSMT_LABEL_LDS_CELLS
 
-/* A draw_line call parks its sums in its lane's registers, one per CHANNEL = (column parity, A/S kind, stripe
- * parity): the cells one short call touches always fall into different channels, and a given cell always falls
- * into the same one, so "consecutive calls adding to the same cell" is simply "consecutive lanes with the same
- * key in that channel".  Calls whose cells collide in a channel (three cells wide, ...) are replayed stripe by
- * stripe by the row owners instead. */
+/* A draw_line call parks its sums in LDS, one per CHANNEL = (column parity, A/S kind, stripe parity): the cells
+ * one short call touches always fall into different channels, and a given cell always falls into the same one, so
+ * every channel is a chain of sums that no other channel's cells take part in.  Calls whose cells collide in a
+ * channel (three cells wide, three stripes tall, ...) are replayed stripe by stripe by the row owners instead. */
 #define LC_CH 8
-#define LC_NOCOL 0xFFFFFFFFu
+static_assert(LC_CELLS < 1024, "a parked sum's cell is stripe << 10 | column");
+#define LC_NOCELL 0xFFFFu /* stripe 63, column 1023: no window has it (cols <= OSMT_LABEL_LDS_CELLS < 1024) */
 
 __device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                                                     uint32_t* g_err) {
     __shared__ double sh_a[LC_CELLS];
     __shared__ double sh_s[LC_CELLS];
+    __shared__ double sh_ev_val[LC_CH * 64]; /* [channel][call of the batch]: the sum the call parks in that channel */
+    __shared__ uint16_t sh_ev_key[LC_CH * 64]; /* its cell: local stripe << 10 | column (the kind is the channel's) */
+    __shared__ uint32_t sh_cmin[64], sh_cmax[64]; /* per stripe: columns of its keys */
     if (blockIdx.x >= n_bands) return;
     const osmt_labelinfo* __restrict__ li = g_lab + g_band[blockIdx.x].label;
     const uint32_t lane = threadIdx.x;
@@ -125,25 +128,25 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
             sh_a[i] = 0.0;
             sh_s[i] = 0.0;
         }
+        sh_cmin[lane] = 0xFFFFFFFFu;
+        sh_cmax[lane] = 0u;
         __syncthreads();
         const bool active = lane < nrow;
         const int32_t y = ry0 + (int32_t)(rbase + lane);
         double* a_row = sh_a + (active ? lane * cols : 0u);
         double* s_row = sh_s + (active ? lane * cols : 0u);
-        /* Every cell belongs to exactly one channel, so each channel keeps the cell it is adding to in a register that
-         * is UNIFORM across the wave (the run's addends arrive by v_readlane, the sum is the same in every lane): no
-         * divergent code between the head of a run and its last addend, and LDS is touched only when a channel moves
-         * on to another cell. */
-        uint32_t ckey[LC_CH];
-        double cval[LC_CH];
-#pragma unroll
-        for (int k = 0; k < LC_CH; ++k) {
-            ckey[k] = LC_NOCOL;
-            cval[k] = 0.0;
-        }
-        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys (x - cx0) */
+        /* Phase 2 belongs to the first LC_CH lanes, one per channel.  Every cell belongs to exactly one channel, so the
+         * channels' sums are independent chains: lane c walks channel c's parked sums in call order and keeps the
+         * cell it is adding to in a register (consecutive calls of a curve land in the same cell; LDS is touched
+         * only when the channel moves on to another cell).  The chains of the eight channels advance together. */
+        double* const my_plane = ((lane >> 1) & 1u) ? sh_s : sh_a;
+        const double* const my_val = sh_ev_val + (lane < LC_CH ? lane * 64u : 0u);
+        const uint16_t* const my_key = sh_ev_key + (lane < LC_CH ? lane * 64u : 0u);
+        uint32_t ckey = LC_NOCELL;
+        double cval = 0.0;
+        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys added by replayed calls (x - cx0) */
         const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
-        auto cell_of = [&](uint32_t K) -> double* { return ((K >> 31) ? sh_s : sh_a) + ((K >> 20) & 0x7FFu) * cols + (K & 0xFFFFFu); };
+        auto cell_of = [&](uint32_t K) -> double* { return my_plane + (K >> 10) * cols + (K & 1023u); };
         double4 seg_next = n_segs > lane ? segs[lane] : make_double4(0.0, 0.0, 0.0, 0.0);
         for (uint32_t base = 0; base < n_segs; base += 64u) {
             /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
@@ -153,110 +156,88 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
             bool overlaps = false, slow = false;
             osmt_label_seg sg = {};
             uint32_t chmask = 0u;
-            uint32_t ekey[LC_CH]; /* kind << 31 | local stripe << 20 | column */
-            double eval[LC_CH];
-#pragma unroll
-            for (int k = 0; k < LC_CH; ++k) {
-                ekey[k] = 0xFFFFFFFFu;
-                eval[k] = 0.0;
-            }
             if (i < n_segs) /* draw_line returns at once for delta == 0 (font/rasterizer.rs:30-32) */
                 overlaps = seg_cur.y != seg_cur.w && (int32_t)floor(fmax(seg_cur.y, seg_cur.w)) >= band0 &&
                            (int32_t)floor(fmin(seg_cur.y, seg_cur.w)) <= band1;
             if (!__ballot(overlaps)) continue; /* 64 calls of glyphs in other bands: no division spent on them */
-            {
-                if (overlaps) {
-                    sg = label_seg_prep(seg_cur);
-                    const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
-                    auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
-                        const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
-                        if ((chmask >> ch) & 1u) slow = true;
-                        chmask |= 1u << ch;
-                        const uint32_t key = (kind << 31) | (row << 20) | col;
-#pragma unroll
-                        for (int k = 0; k < LC_CH; ++k)
-                            if ((uint32_t)k == ch) {
-                                ekey[k] = key;
-                                eval[k] = val;
-                            }
-                    };
-                    for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
-                        /* font/rasterizer.rs:46-80 for stripe yy */
-                        const double y_bottom = fmax((double)yy, sg.y_min);
-                        const double y_top = fmin((double)(yy + 1), sg.y_max);
-                        const double y_delta = y_top - y_bottom;
-                        const double x_at_bottom = sg.x0 + (y_bottom - sg.y0) * sg.slope;
-                        const double x_at_top = sg.x0 + (y_top - sg.y0) * sg.slope;
-                        const bool flip_edge = !(x_at_bottom <= x_at_top);
-                        const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
-                        const double x_largest = flip_edge ? x_at_bottom : x_at_top;
-                        const int32_t x_to = (int32_t)floor(x_largest);
-                        const int32_t x_from = (int32_t)floor(x_smallest);
-                        if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
-                            oob = true;
-                            continue;
-                        }
-                        if (x_to - x_from >= 2) { /* three cells in one stripe share a channel: replay */
-                            slow = true;
-                            break;
-                        }
-                        const uint32_t row = (uint32_t)(yy - band0);
-                        for (int32_t x = x_from; x <= x_to; ++x) {
-                            const double x_left = fmax((double)x, x_smallest);
-                            const double x_next = (double)(x + 1);
-                            const double x_right = fmin(x_next, x_largest);
-                            double pixel_area = (x_next - x_right) * y_delta;
-                            const double trapezoid_width = x_right - x_left;
-                            if (trapezoid_width > 0.0) {
-                                const double y_at_left = sg.y0 + (x_left - sg.x0) * sg.slope_recip;
-                                const double y_at_right = sg.y0 + (x_right - sg.x0) * sg.slope_recip;
-                                const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
-                                                                          : (y_at_left - y_bottom) + (y_at_right - y_bottom);
-                                pixel_area += trapezoid_width * trapezoid_height / 2.0;
-                            }
-                            emit(0u, row, (uint32_t)(x - cx0), sg.sign * pixel_area);
-                        }
-                        emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
+            if (overlaps) {
+                sg = label_seg_prep(seg_cur);
+                const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
+                auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
+                    const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
+                    if ((chmask >> ch) & 1u) slow = true; /* a second cell of this call in the channel: replay */
+                    chmask |= 1u << ch;
+                    sh_ev_key[ch * 64u + lane] = (uint16_t)((row << 10) | col);
+                    sh_ev_val[ch * 64u + lane] = val;
+                };
+                for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
+                    /* font/rasterizer.rs:46-80 for stripe yy */
+                    const double y_bottom = fmax((double)yy, sg.y_min);
+                    const double y_top = fmin((double)(yy + 1), sg.y_max);
+                    const double y_delta = y_top - y_bottom;
+                    const double x_at_bottom = sg.x0 + (y_bottom - sg.y0) * sg.slope;
+                    const double x_at_top = sg.x0 + (y_top - sg.y0) * sg.slope;
+                    const bool flip_edge = !(x_at_bottom <= x_at_top);
+                    const double x_smallest = flip_edge ? x_at_top : x_at_bottom;
+                    const double x_largest = flip_edge ? x_at_bottom : x_at_top;
+                    const int32_t x_to = (int32_t)floor(x_largest);
+                    const int32_t x_from = (int32_t)floor(x_smallest);
+                    if (x_from < cx0 || x_to + 1 >= cx0 + (int32_t)cols) { /* cannot happen: the window is conservative */
+                        oob = true;
+                        continue;
                     }
+                    if (x_to - x_from >= 2) { /* three cells in one stripe share a channel: replay */
+                        slow = true;
+                        break;
+                    }
+                    const uint32_t row = (uint32_t)(yy - band0);
+                    for (int32_t x = x_from; x <= x_to; ++x) {
+                        const double x_left = fmax((double)x, x_smallest);
+                        const double x_next = (double)(x + 1);
+                        const double x_right = fmin(x_next, x_largest);
+                        double pixel_area = (x_next - x_right) * y_delta;
+                        const double trapezoid_width = x_right - x_left;
+                        if (trapezoid_width > 0.0) {
+                            const double y_at_left = sg.y0 + (x_left - sg.x0) * sg.slope_recip;
+                            const double y_at_right = sg.y0 + (x_right - sg.x0) * sg.slope_recip;
+                            const double trapezoid_height = flip_edge ? (y_top - y_at_left) + (y_top - y_at_right)
+                                                                      : (y_at_left - y_bottom) + (y_at_right - y_bottom);
+                            pixel_area += trapezoid_width * trapezoid_height / 2.0;
+                        }
+                        emit(0u, row, (uint32_t)(x - cx0), sg.sign * pixel_area);
+                    }
+                    emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
                 }
             }
-            /* ---- phase 2: the parked sums are applied strictly in call order, the whole wave in step ---- */
+            /* ---- phase 2, lane = channel: the parked sums are applied strictly in call order ---- */
             unsigned long long rest = __ballot(overlaps);
             const unsigned long long slowm = __ballot(overlaps && slow);
+            unsigned long long mine = 0ull; /* the calls that parked a sum in my channel */
+#pragma unroll
+            for (int c = 0; c < LC_CH; ++c) {
+                const unsigned long long m = __ballot(overlaps && !slow && ((chmask >> c) & 1u));
+                if (lane == (uint32_t)c) mine = m;
+            }
+            __syncthreads(); /* one wave: the parked sums are in LDS */
             while (rest) {
-                /* calls before the next replayed one form a segment whose channels can be handled one by one: sums to
-                 * different cells are independent, sums to one cell (one channel, equal keys) stay in call order */
+                /* calls before the next replayed one: their sums go through the channels */
                 const unsigned long long sl_rest = slowm & rest;
                 const uint32_t sl = sl_rest ? (uint32_t)__builtin_ctzll(sl_rest) : 64u;
                 const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
-                const bool in_seg = (seg >> lane) & 1ull;
-#pragma unroll
-                for (int ch = 0; ch < LC_CH; ++ch) {
-                    const bool valid = in_seg && ((chmask >> ch) & 1u);
-                    const unsigned long long vm = __ballot(valid);
-                    if (!vm) continue;
-                    const uint32_t key = ekey[ch];
-                    const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1);
-                    const bool pvalid = lane != 0u && ((vm >> (lane - 1u)) & 1ull);
-                    const bool head = valid && !(pvalid && pkey == key);
-                    unsigned long long hm = __ballot(head);
-                    const unsigned long long cont = vm & ~hm; /* lanes continuing their predecessor's run */
-                    while (hm) {
-                        const uint32_t h = (uint32_t)__builtin_ctzll(hm);
-                        hm &= hm - 1ull;
-                        const uint32_t run = 1u + (uint32_t)__builtin_ctzll(~((cont >> 1) >> h));
-                        const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)h);
-                        if (K != ckey[ch]) { /* the channel moves to another cell */
-                            if (ckey[ch] != LC_NOCOL && lane == 0u) *cell_of(ckey[ch]) = cval[ch];
-                            cval[ch] = *cell_of(K); /* same wave, LDS in order: sees the store above */
-                            ckey[ch] = K;
-                            if (((K >> 20) & 0x7FFu) == lane) {
-                                c_min = min(c_min, K & 0xFFFFFu);
-                                c_max = max(c_max, K & 0xFFFFFu);
-                            }
-                        }
-                        for (uint32_t src = h; src < h + run; ++src) cval[ch] += readlane_f64(eval[ch], src);
+                unsigned long long m = mine & seg;
+                while (m) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t K = my_key[j];
+                    const double v = my_val[j];
+                    if (K != ckey) { /* the channel moves to another cell */
+                        if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
+                        cval = *cell_of(K);
+                        ckey = K;
+                        atomicMin(&sh_cmin[K >> 10], K & 1023u);
+                        atomicMax(&sh_cmax[K >> 10], K & 1023u);
                     }
+                    cval += v;
                 }
                 if (sl >= 64u) break;
                 { /* the replayed call works on LDS directly: write the cached cells back first */
@@ -271,11 +252,9 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     q.sign = readlane_f64(sg.sign, j);
                     q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
                     q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
-#pragma unroll
-                    for (int k = 0; k < LC_CH; ++k) {
-                        if (ckey[k] != LC_NOCOL && lane == 0u) *cell_of(ckey[k]) = cval[k];
-                        ckey[k] = LC_NOCOL;
-                    }
+                    if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
+                    ckey = LC_NOCELL;
+                    __syncthreads();
                     if (active && y >= q.yf && y <= q.yl) {
                         int32_t x_min = INT32_MAX, x_max = INT32_MIN;
                         oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
@@ -284,14 +263,15 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                             c_max = max(c_max, (uint32_t)(x_max - cx0));
                         }
                     }
+                    __syncthreads();
                 }
                 rest &= ~((2ull << sl) - 1ull);
             }
         }
-#pragma unroll
-        for (int k = 0; k < LC_CH; ++k)
-            if (ckey[k] != LC_NOCOL && lane == 0u) *cell_of(ckey[k]) = cval[k];
-        __syncthreads(); /* one wave: orders lane 0's stores before the row owners' scan */
+        if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
+        __syncthreads(); /* one wave: orders the channel lanes' stores before the row owners' scan */
+        c_min = min(c_min, sh_cmin[lane]);
+        c_max = max(c_max, sh_cmax[lane]);
         /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
         if (active && c_min <= c_max) {
             double s_acc = 0.0;
@@ -303,7 +283,6 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
         __syncthreads();
         double* __restrict__ dst = A + (size_t)rbase * cols;
         for (uint32_t i = lane; i < cnt; i += 64u) dst[i] = sh_a[i];
-        __syncthreads();
     }
     if (oob) atomicOr(g_err, 1u);
 }
