@@ -101,74 +101,90 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab,
-                                                    const osmt_label_band* __restrict__ g_band, uint32_t n_bands,
-                                                    const double4* __restrict__ g_seg, double* __restrict__ g_a,
-                                                    uint32_t* g_err) {
+/* channel list strides, skewed so that the eight channel lanes reading entry j of their lists hit different banks */
+#define LC_VSTRIDE 65 /* doubles */
+#define LC_KSTRIDE 66 /* uint16 */
+
+/* what the producer wave hands to the consumer wave with one batch of 64 calls */
+struct LcBatch {
+    unsigned long long mine[LC_CH]; /* per channel: the calls that parked a sum in it */
+    unsigned long long rest, slowm; /* calls that cross the band; those of them that have to be replayed */
+    uint32_t base;                  /* index of the batch's first call */
+    uint32_t done;                  /* no more batches */
+};
+
+__device__ __forceinline__ unsigned long long first_lane_u64(unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+/* one wave's LDS traffic stays in program order; this only keeps the compiler from moving it */
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab,
+                                                     const osmt_label_band* __restrict__ g_band, uint32_t n_bands,
+                                                     const double4* __restrict__ g_seg, double* __restrict__ g_a,
+                                                     uint32_t* g_err) {
     __shared__ double sh_a[LC_CELLS];
     __shared__ double sh_s[LC_CELLS];
-    __shared__ double sh_ev_val[LC_CH * 64]; /* [channel][call of the batch]: the sum the call parks in that channel */
-    __shared__ uint16_t sh_ev_key[LC_CH * 64]; /* its cell: local stripe << 10 | column (the kind is the channel's) */
+    __shared__ double sh_ev_val[2][LC_CH * LC_VSTRIDE]; /* [buffer][channel][call of the batch]: the parked sum */
+    __shared__ uint16_t sh_ev_key[2][LC_CH * LC_KSTRIDE]; /* its cell: local stripe << 10 | column (the kind is the channel's) */
+    __shared__ LcBatch sh_batch[2];
     __shared__ uint32_t sh_cmin[64], sh_cmax[64]; /* per stripe: columns of its keys */
     if (blockIdx.x >= n_bands) return;
     const osmt_labelinfo* __restrict__ li = g_lab + g_band[blockIdx.x].label;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool producer = threadIdx.x < 64u;
     const int32_t ry0 = li->ry0, cx0 = li->cx0;
     const uint32_t R = (uint32_t)(li->ry1 - ry0 + 1), cols = li->cols;
     const uint32_t n_segs = li->n_segs;
     const double4* __restrict__ segs = g_seg + li->seg_off;
     double* __restrict__ A = g_a + li->plane_off;
     const uint32_t band_rows = min(64u, LC_CELLS / cols);
+    const uint32_t rbase = g_band[blockIdx.x].rbase;
+    const uint32_t nrow = min(band_rows, R - rbase);
+    const uint32_t cnt = nrow * cols;
+    const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
     bool oob = false;
-    {
-        const uint32_t rbase = g_band[blockIdx.x].rbase;
-        const uint32_t nrow = min(band_rows, R - rbase);
-        const uint32_t cnt = nrow * cols;
-        for (uint32_t i = lane; i < cnt; i += 64u) {
-            sh_a[i] = 0.0;
-            sh_s[i] = 0.0;
-        }
+    for (uint32_t i = threadIdx.x; i < cnt; i += 128u) {
+        sh_a[i] = 0.0;
+        sh_s[i] = 0.0;
+    }
+    if (producer) {
         sh_cmin[lane] = 0xFFFFFFFFu;
         sh_cmax[lane] = 0u;
-        __syncthreads();
-        const bool active = lane < nrow;
-        const int32_t y = ry0 + (int32_t)(rbase + lane);
-        double* a_row = sh_a + (active ? lane * cols : 0u);
-        double* s_row = sh_s + (active ? lane * cols : 0u);
-        /* Phase 2 belongs to the first LC_CH lanes, one per channel.  Every cell belongs to exactly one channel, so the
-         * channels' sums are independent chains: lane c walks channel c's parked sums in call order and keeps the
-         * cell it is adding to in a register (consecutive calls of a curve land in the same cell; LDS is touched
-         * only when the channel moves on to another cell).  The chains of the eight channels advance together. */
-        double* const my_plane = ((lane >> 1) & 1u) ? sh_s : sh_a;
-        const double* const my_val = sh_ev_val + (lane < LC_CH ? lane * 64u : 0u);
-        const uint16_t* const my_key = sh_ev_key + (lane < LC_CH ? lane * 64u : 0u);
-        uint32_t ckey = LC_NOCELL;
-        double cval = 0.0;
-        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys added by replayed calls (x - cx0) */
-        const int32_t band0 = ry0 + (int32_t)rbase, band1 = band0 + (int32_t)nrow - 1;
-        auto cell_of = [&](uint32_t K) -> double* { return my_plane + (K >> 10) * cols + (K & 1023u); };
+    }
+    __syncthreads();
+    if (producer) {
+        /* ---- lane = draw_line call: all the f64 work of the call's stripes inside the band, parked per channel ---- */
+        uint32_t k = 0; /* batches handed over so far */
         double4 seg_next = n_segs > lane ? segs[lane] : make_double4(0.0, 0.0, 0.0, 0.0);
         for (uint32_t base = 0; base < n_segs; base += 64u) {
-            /* ---- phase 1, lane = draw_line call: all the f64 work of the call's stripes inside the band ---- */
             const uint32_t i = base + lane;
             const double4 seg_cur = seg_next;
             if (i + 64u < n_segs) seg_next = segs[i + 64u]; /* in flight while this batch is worked on */
             bool overlaps = false, slow = false;
-            osmt_label_seg sg = {};
             uint32_t chmask = 0u;
             if (i < n_segs) /* draw_line returns at once for delta == 0 (font/rasterizer.rs:30-32) */
                 overlaps = seg_cur.y != seg_cur.w && (int32_t)floor(fmax(seg_cur.y, seg_cur.w)) >= band0 &&
                            (int32_t)floor(fmin(seg_cur.y, seg_cur.w)) <= band1;
-            if (!__ballot(overlaps)) continue; /* 64 calls of glyphs in other bands: no division spent on them */
+            const unsigned long long rest = __ballot(overlaps);
+            if (!rest) continue; /* 64 calls of glyphs in other bands: no division spent on them */
+            double* const ev_val = sh_ev_val[k & 1u];
+            uint16_t* const ev_key = sh_ev_key[k & 1u];
             if (overlaps) {
-                sg = label_seg_prep(seg_cur);
+                const osmt_label_seg sg = label_seg_prep(seg_cur);
                 const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
                 auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
                     const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
                     if ((chmask >> ch) & 1u) slow = true; /* a second cell of this call in the channel: replay */
                     chmask |= 1u << ch;
-                    sh_ev_key[ch * 64u + lane] = (uint16_t)((row << 10) | col);
-                    sh_ev_val[ch * 64u + lane] = val;
+                    ev_key[ch * LC_KSTRIDE + lane] = (uint16_t)((row << 10) | col);
+                    ev_val[ch * LC_VSTRIDE + lane] = val;
                 };
                 for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
                     /* font/rasterizer.rs:46-80 for stripe yy */
@@ -209,27 +225,74 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                     emit(1u, row, (uint32_t)(x_to + 1 - cx0), sg.sign * y_delta);
                 }
             }
-            /* ---- phase 2, lane = channel: the parked sums are applied strictly in call order ---- */
-            unsigned long long rest = __ballot(overlaps);
+            LcBatch* const hb = &sh_batch[k & 1u];
             const unsigned long long slowm = __ballot(overlaps && slow);
-            unsigned long long mine = 0ull; /* the calls that parked a sum in my channel */
+            /* every channel's parked sums move to the front of its list (in place: the wave reads before it writes,
+             * and a sum never moves up), so that the consumer walks them without looking for the next call */
 #pragma unroll
             for (int c = 0; c < LC_CH; ++c) {
-                const unsigned long long m = __ballot(overlaps && !slow && ((chmask >> c) & 1u));
-                if (lane == (uint32_t)c) mine = m;
+                const bool has = overlaps && !slow && ((chmask >> c) & 1u);
+                const unsigned long long m = __ballot(has);
+                if (lane == (uint32_t)c) hb->mine[c] = m;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint16_t key = 0;
+                double val = 0.0;
+                if (has) {
+                    key = ev_key[c * LC_KSTRIDE + lane];
+                    val = ev_val[c * LC_VSTRIDE + lane];
+                }
+                wave_lds_order();
+                if (has) {
+                    ev_key[c * LC_KSTRIDE + rank] = key;
+                    ev_val[c * LC_VSTRIDE + rank] = val;
+                }
             }
-            __syncthreads(); /* one wave: the parked sums are in LDS */
+            if (lane == 0u) {
+                hb->rest = rest;
+                hb->slowm = slowm;
+                hb->base = base;
+                hb->done = 0u;
+            }
+            __syncthreads(); /* hand-over k: the consumer takes this buffer, the producer moves on to the other one */
+            ++k;
+        }
+        if (lane == 0u) sh_batch[k & 1u].done = 1u;
+        __syncthreads();
+    } else {
+        /* ---- lane = channel (the first LC_CH lanes): the parked sums are applied strictly in call order.  Every
+         * cell belongs to exactly one channel, so the channels' sums are independent chains that advance side by
+         * side; a lane keeps the cell it is adding to in a register (consecutive calls of a curve land in the same
+         * cell), LDS is touched only when its channel moves on to another cell. ---- */
+        const bool active = lane < nrow;
+        const int32_t y = ry0 + (int32_t)(rbase + lane);
+        double* a_row = sh_a + (active ? lane * cols : 0u);
+        double* s_row = sh_s + (active ? lane * cols : 0u);
+        double* const my_plane = ((lane >> 1) & 1u) ? sh_s : sh_a;
+        uint32_t ckey = LC_NOCELL;
+        double cval = 0.0;
+        uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys added by replayed calls (x - cx0) */
+        auto cell_of = [&](uint32_t K) -> double* { return my_plane + (K >> 10) * cols + (K & 1023u); };
+        for (uint32_t k = 0;; ++k) {
+            __syncthreads(); /* hand-over k */
+            const LcBatch* const hb = &sh_batch[k & 1u];
+            if (__builtin_amdgcn_readfirstlane((int)hb->done)) break;
+            const double* const my_val = sh_ev_val[k & 1u] + (lane < LC_CH ? lane * LC_VSTRIDE : 0u);
+            const uint16_t* const my_key = sh_ev_key[k & 1u] + (lane < LC_CH ? lane * LC_KSTRIDE : 0u);
+            unsigned long long rest = first_lane_u64(hb->rest);
+            const unsigned long long slowm = first_lane_u64(hb->slowm);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb->base);
+            const unsigned long long mine = lane < LC_CH ? hb->mine[lane] : 0ull;
+            uint32_t pos = 0; /* sums of my channel applied so far */
             while (rest) {
                 /* calls before the next replayed one: their sums go through the channels */
                 const unsigned long long sl_rest = slowm & rest;
                 const uint32_t sl = sl_rest ? (uint32_t)__builtin_ctzll(sl_rest) : 64u;
                 const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
-                unsigned long long m = mine & seg;
-                while (m) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const uint32_t K = my_key[j];
-                    const double v = my_val[j];
+                const uint32_t end = pos + (uint32_t)__popcll(mine & seg);
+                while (pos < end) {
+                    const uint32_t K = my_key[pos];
+                    const double v = my_val[pos];
+                    ++pos;
                     if (K != ckey) { /* the channel moves to another cell */
                         if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
                         cval = *cell_of(K);
@@ -241,20 +304,10 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                 }
                 if (sl >= 64u) break;
                 { /* the replayed call works on LDS directly: write the cached cells back first */
-                    const uint32_t j = sl;
-                    osmt_label_seg q;
-                    q.x0 = readlane_f64(sg.x0, j);
-                    q.y0 = readlane_f64(sg.y0, j);
-                    q.slope = readlane_f64(sg.slope, j);
-                    q.slope_recip = readlane_f64(sg.slope_recip, j);
-                    q.y_min = readlane_f64(sg.y_min, j);
-                    q.y_max = readlane_f64(sg.y_max, j);
-                    q.sign = readlane_f64(sg.sign, j);
-                    q.yf = __builtin_amdgcn_readlane(sg.yf, (int)j);
-                    q.yl = __builtin_amdgcn_readlane(sg.yl, (int)j);
+                    const osmt_label_seg q = label_seg_prep(segs[base + sl]);
                     if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
                     ckey = LC_NOCELL;
-                    __syncthreads();
+                    wave_lds_order();
                     if (active && y >= q.yf && y <= q.yl) {
                         int32_t x_min = INT32_MAX, x_max = INT32_MIN;
                         oob |= !label_stripe(q, y, cx0, cols, a_row, s_row, x_min, x_max);
@@ -263,13 +316,13 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                             c_max = max(c_max, (uint32_t)(x_max - cx0));
                         }
                     }
-                    __syncthreads();
+                    wave_lds_order();
                 }
                 rest &= ~((2ull << sl) - 1ull);
             }
         }
         if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
-        __syncthreads(); /* one wave: orders the channel lanes' stores before the row owners' scan */
+        wave_lds_order();
         c_min = min(c_min, sh_cmin[lane]);
         c_max = max(c_max, sh_cmax[lane]);
         /* save_to_figure (:115-147) for this stripe: keys span [c_min, c_max]; the rest of the row stays 0 */
@@ -280,10 +333,10 @@ __global__ __launch_bounds__(64) void k_label_cover(const osmt_labelinfo* __rest
                 a_row[c] = fmin(a_row[c] + s_acc, 1.0);
             }
         }
-        __syncthreads();
-        double* __restrict__ dst = A + (size_t)rbase * cols;
-        for (uint32_t i = lane; i < cnt; i += 64u) dst[i] = sh_a[i];
     }
+    __syncthreads();
+    double* __restrict__ dst = A + (size_t)rbase * cols;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 128u) dst[i] = sh_a[i];
     if (oob) atomicOr(g_err, 1u);
 }
 
@@ -429,7 +482,7 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
     hipError_t ce = hipMemsetAsync(a.ok, 0, a.n_labels, st);
     if (ce == hipSuccess) ce = hipMemsetAsync(a.err, 0, 4, st);
     if (ce != hipSuccess) return ce;
-    if (a.n_bands) hipLaunchKernelGGL(k_label_cover, dim3(a.n_bands), dim3(64), 0, st, a.info, a.bands, a.n_bands, segs, a.plane_a, a.err);
+    if (a.n_bands) hipLaunchKernelGGL(k_label_cover, dim3(a.n_bands), dim3(128), 0, st, a.info, a.bands, a.n_bands, segs, a.plane_a, a.err);
     if (a.n_wide)
         hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
                            a.plane_s_wide, a.err);
