@@ -1291,10 +1291,17 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     if (LABELS) {
         const osmt_tile_label* OSMT_R tl = g_tl + g_job_label_off[tile];
         const uint32_t n_tl = g_tl_cnt[tile];
-        for (uint32_t k = 0; k < n_tl; ++k) {
-            const osmt_tile_label e = tl[k];
-            if (e.x0 > rc.x1 || e.x1 < rc.x0 || e.y0 > rc.y1 || e.y1 < rc.y0) continue;
-            const osmt_labelinfo* OSMT_R li = g_lab + e.label;
+        /* the tile's survivors are tested against the sub-tile 64 at a time (one load, one ballot): only the few
+         * that reach into it are walked */
+        for (uint32_t kb = 0; kb < n_tl; kb += 64u) {
+          const uint32_t kk = kb + lane;
+          osmt_tile_label e = {};
+          if (kk < n_tl) e = tl[kk];
+          unsigned long long hm = __ballot(kk < n_tl && !(e.x0 > rc.x1 || e.x1 < rc.x0 || e.y0 > rc.y1 || e.y1 < rc.y0));
+          while (hm) {
+            const uint32_t hj = (uint32_t)__builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            const osmt_labelinfo* OSMT_R li = g_lab + (uint32_t)__builtin_amdgcn_readlane((int)e.label, (int)hj);
             const int32_t ry0 = li->ry0, ry1 = li->ry1, cx0 = li->cx0;
             const int32_t cx1 = cx0 + (int32_t)li->cols - 1;
             const bool text_hit = li->has_text && ry0 <= rc.y1 && ry1 >= rc.y0 && cx0 <= rc.x1 && cx1 >= rc.x0;
@@ -1321,6 +1328,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     blend_rgb(acc[j], c.x, c.y, c.z, c.w);
                 }
             }
+          }
         }
     }
 

@@ -388,6 +388,29 @@ __global__ __launch_bounds__(64) void k_label_cover_wide(const osmt_labelinfo* _
 }
 
 #define OSMT_LABEL_RESOLVE_THREADS 256
+
+/* workgroup barrier that orders LDS traffic only (global loads issued before it stay in flight) */
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/* i / d and i % d from d's float reciprocal; `small`: i < 2^22, so that (float)i is exact and the product is within
+ * one of the quotient (relative error 2^-23): one step either way settles it.  Otherwise the plain division. */
+__device__ __forceinline__ uint32_t resolve_divmod(bool small, uint32_t i, uint32_t d, float rcp, uint32_t& rem) {
+    if (!small) {
+        rem = i % d;
+        return i / d;
+    }
+    uint32_t q = (uint32_t)((float)i * rcp);
+    int32_t r = (int32_t)(i - q * d);
+    if (r < 0) {
+        --q;
+        r += (int32_t)d;
+    } else if (r >= (int32_t)d) {
+        ++q;
+        r -= (int32_t)d;
+    }
+    rem = (uint32_t)r;
+    return q;
+}
 /* LDS_BM: the (3W)^2-bit ownership map lives in LDS (scale 1: 72 KB); otherwise in global memory. */
 template <bool LDS_BM>
 __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
@@ -401,8 +424,10 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
     const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
     const size_t words = ((size_t)EW * EW + 31u) / 32u;
+    __shared__ uint32_t sh_hit[3];
     uint32_t* bm = LDS_BM ? sh_bm : g_bitmap + (size_t)tile * words;
     for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
+    if (tid < 3u) sh_hit[tid] = 0u;
     if (!LDS_BM) __threadfence();
     __syncthreads();
     auto test = [&](uint32_t bit) -> bool {
@@ -411,51 +436,113 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
     };
     const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
     uint32_t n_out = 0; /* thread 0: succeeded labels that reach into the tile itself */
-    for (uint32_t l = l0; l < l1; ++l) {
+    /* The labels are a serial chain (a verdict decides what the next label collides with), so what a label needs from
+     * global memory is fetched while its predecessor is being decided: its record and the first RP x 256 cells. */
+    constexpr int RP = 4;
+    struct View {
+        int32_t ix0, iy0, ry0, ry1, cx0;
+        uint32_t iw, ih, cols, n_cells;
+        bool has_cells;
+        const double* A;
+    };
+    auto view_of = [&](uint32_t l) -> View {
         const osmt_labelinfo* __restrict__ li = g_lab + l;
-        const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
-        const uint32_t iw = li->icon_w, ih = li->icon_h;
-        const bool has_cells = li->has_text && li->ry0 <= li->ry1 && li->cols > 0;
-        const int32_t ry0 = li->ry0, cx0 = li->cx0;
-        const uint32_t cols = li->cols;
-        const uint32_t n_cells = has_cells ? (uint32_t)(li->ry1 - ry0 + 1) * cols : 0u;
-        const double* __restrict__ A = g_a + li->plane_off;
+        View v;
+        v.ix0 = li->icon_x, v.iy0 = li->icon_y;
+        v.iw = li->icon_w, v.ih = li->icon_h;
+        v.ry0 = li->ry0, v.ry1 = li->ry1, v.cx0 = li->cx0;
+        v.cols = li->cols;
+        v.has_cells = li->has_text && v.ry0 <= v.ry1 && v.cols > 0;
+        v.n_cells = v.has_cells ? (uint32_t)(v.ry1 - v.ry0 + 1) * v.cols : 0u;
+        v.A = g_a + li->plane_off;
+        return v;
+    };
+    View cur = {};
+    double cv[RP] = {};
+    if (l0 < l1) {
+        cur = view_of(l0);
+#pragma unroll
+        for (int k = 0; k < RP; ++k) {
+            const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
+            cv[k] = i < cur.n_cells ? cur.A[i] : 0.0;
+        }
+    }
+    for (uint32_t l = l0; l < l1; ++l) {
+        View nxt = {};
+        double nv[RP] = {};
+        if (l + 1 < l1) {
+            nxt = view_of(l + 1);
+#pragma unroll
+            for (int k = 0; k < RP; ++k) {
+                const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
+                nv[k] = i < nxt.n_cells ? nxt.A[i] : 0.0;
+            }
+        }
+        const int32_t ix0 = cur.ix0, iy0 = cur.iy0, ry0 = cur.ry0, cx0 = cur.cx0;
+        const uint32_t iw = cur.iw, ih = cur.ih, cols = cur.cols, n_cells = cur.n_cells;
+        const double* __restrict__ A = cur.A;
+        const float rcp_iw = 1.0f / (float)max(iw, 1u), rcp_cols = 1.0f / (float)max(cols, 1u);
+        const bool small_icon = (uint64_t)iw * ih < (1u << 22), small_cells = n_cells < (1u << 22);
         bool failed = false;
         for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
             bool hit = false;
+            auto pixel = [&](int32_t x, int32_t y) {
+                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
+                if (pass == 0)
+                    hit |= test(bit);
+                else
+                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            };
             for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
-                const int32_t x = ix0 + (int32_t)(i % iw), y = iy0 + (int32_t)(i / iw);
+                uint32_t rx;
+                const uint32_t rq = resolve_divmod(small_icon, i, iw, rcp_iw, rx);
+                const int32_t x = ix0 + (int32_t)rx, y = iy0 + (int32_t)rq;
                 if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
-                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
-                if (pass == 0)
-                    hit |= test(bit);
-                else
-                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+                pixel(x, y);
             }
-            for (uint32_t i = tid; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) {
-                if (!(A[i] > 0.0)) continue;
-                const int32_t x = cx0 + (int32_t)(i % cols), y = ry0 + (int32_t)(i / cols);
-                if (x < -W || x >= 2 * W) continue; /* rows are clipped already */
-                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
-                if (pass == 0)
-                    hit |= test(bit);
-                else
-                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
+            auto cell = [&](uint32_t i, double a) {
+                if (!(a > 0.0)) return;
+                uint32_t rx;
+                const uint32_t rq = resolve_divmod(small_cells, i, cols, rcp_cols, rx);
+                const int32_t x = cx0 + (int32_t)rx, y = ry0 + (int32_t)rq;
+                if (x < -W || x >= 2 * W) return; /* rows are clipped already */
+                pixel(x, y);
+            };
+#pragma unroll
+            for (int k = 0; k < RP; ++k) {
+                const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
+                if (i < n_cells) cell(i, cv[k]);
             }
+            for (uint32_t i = tid + RP * OSMT_LABEL_RESOLVE_THREADS; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) cell(i, A[i]);
             if (pass == 0) {
-                failed = __syncthreads_or(hit ? 1 : 0) != 0;
+                if (LDS_BM) {
+                    /* the verdict goes through LDS and a barrier that waits for LDS only: __syncthreads would also
+                     * wait for the next label's cells, which are meant to stay in flight (slot l % 3 is cleared
+                     * two labels ahead, a barrier before its first use) */
+                    uint32_t* flag = sh_hit + (l - l0) % 3u;
+                    if (__ballot(hit) && (tid & 63u) == 0u) atomicOr(flag, 1u);
+                    lds_barrier();
+                    failed = *flag != 0u;
+                    if (tid == 0) sh_hit[(l - l0 + 2u) % 3u] = 0u;
+                } else {
+                    failed = __syncthreads_or(hit ? 1 : 0) != 0;
+                }
                 if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
                 if (failed) break;
             } else {
-                if (!LDS_BM) __threadfence();
-                __syncthreads();
+                if (LDS_BM) {
+                    lds_barrier();
+                } else {
+                    __threadfence();
+                    __syncthreads();
+                }
             }
         }
         if (!failed && tid == 0) {
             /* what k_raster has to look at: the label's pixels clipped to the tile [0, W)^2 */
             int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
-            if (has_cells) {
-                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = li->ry1;
+            if (cur.has_cells) {
+                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = cur.ry1;
             }
             if (iw) {
                 bx0 = min(bx0, ix0), bx1 = max(bx1, ix0 + (int32_t)iw - 1);
@@ -470,6 +557,9 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
                 g_tl[l0 + n_out++] = e;
             }
         }
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) cv[k] = nv[k];
     }
     if (tid == 0) g_tl_cnt[tile] = n_out;
 }
