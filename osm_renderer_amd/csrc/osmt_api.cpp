@@ -160,6 +160,7 @@ struct osmt_scene {
     double* d_lab_s_wide = nullptr;
     uint32_t* d_lab_wide = nullptr;
     osmt_label_band* d_lab_bands = nullptr;
+    unsigned long long* d_lab_bits = nullptr;
     uint32_t n_lab_bands = 0;
     uint32_t n_lab_wide = 0;
     uint32_t* d_lab_bitmap = nullptr;
@@ -552,6 +553,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         ll.segs = sc->d_lab_segs;
         ll.wide = sc->d_lab_wide;
         ll.plane_a = sc->d_lab_a;
+        ll.cell_bits = sc->d_lab_bits;
         ll.plane_s_wide = sc->d_lab_s_wide;
         ll.bitmap = sc->d_lab_bitmap;
         ll.ok = sc->d_lab_ok;
@@ -1024,7 +1026,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     bands.clear();
     info.assign(lb->n_labels, osmt_labelinfo{});
     wide.clear();
-    size_t cells = 0, wide_cells = 0;
+    size_t cells = 0, wide_cells = 0, bit_words = 0; /* bit_words < cells / 64 + bands <= 2^26 */
     for (uint32_t j = 0; j < sc->n_jobs; ++j) {
         for (uint32_t l = lb->job_label_off[j]; l < lb->job_label_off[j + 1]; ++l) {
             const osmt_label& in = lb->labels[l];
@@ -1077,8 +1079,12 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
                 wide_cells += 64 * cols;
                 wide.push_back(l);
             } else {
-                const uint32_t band_rows = std::min<uint32_t>(64u, OSMT_LABEL_LDS_CELLS / (uint32_t)cols);
-                for (uint32_t rb = 0; rb < rows; rb += band_rows) bands.push_back(osmt_label_band{l, rb});
+                const uint32_t band_rows = osmt_label_band_rows((uint32_t)cols);
+                o.wide_off = (uint32_t)bit_words;
+                for (uint32_t rb = 0; rb < rows; rb += band_rows) {
+                    bands.push_back(osmt_label_band{l, rb});
+                    bit_words += osmt_label_band_words((uint32_t)cols);
+                }
             }
         }
     }
@@ -1100,6 +1106,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     const size_t o_segs = carve(lb->n_segs * 32);
     const size_t o_a = carve((cells + 1) * 8);
     const size_t o_s = carve((wide_cells + 1) * 8);
+    const size_t o_bits = carve((bit_words + 2) * 8); /* + the word a funnel read may touch behind the last stream */
     const size_t o_wide = carve((wide.size() + 1) * 4);
     const size_t o_bands = carve((bands.size() + 1) * sizeof(osmt_label_band));
     const size_t o_bm = carve(words * 4 <= 96 * 1024 ? 4 : (size_t)sc->n_jobs * words * 4); /* scale 1: the map lives in LDS */
@@ -1119,6 +1126,7 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     sc->d_lab_segs = (double*)(base + o_segs);
     sc->d_lab_a = (double*)(base + o_a);
     sc->d_lab_s_wide = (double*)(base + o_s);
+    sc->d_lab_bits = (unsigned long long*)(base + o_bits);
     sc->d_lab_wide = (uint32_t*)(base + o_wide);
     sc->n_lab_wide = (uint32_t)wide.size();
     sc->d_lab_bands = (osmt_label_band*)(base + o_bands);

@@ -132,7 +132,9 @@ struct osmt_labelinfo {
     uint32_t icon_w, icon_h; /* 0 x 0: no icon */
     uint64_t icon_off;       /* first pixel in the image pool (double4 units) */
     uint8_t has_text, color[3];
-    uint32_t wide_off; /* windows wider than the LDS band: first cell of a 64-stripe S scratch (k_label_cover_wide) */
+    /* windows wider than the LDS band: first cell of a 64-stripe S scratch (k_label_cover_wide); all others: first
+     * 64-bit word of the label's coverage bit streams (one per band, see osmt_label_band) */
+    uint32_t wide_off;
 };
 static_assert(sizeof(osmt_labelinfo) == 64, "osmt_labelinfo must be one 64-byte record");
 
@@ -155,6 +157,13 @@ struct osmt_tile_label {
 struct osmt_label_band {
     uint32_t label, rbase;
 };
+/* Besides the f64 totals a band leaves ONE BIT per cell (total > 0) for k_label_resolve, in cell order, 64 cells
+ * per word; band b of a label starts at word wide_off + b * osmt_label_band_words(cols). */
+__host__ __device__ static inline uint32_t osmt_label_band_rows(uint32_t cols) {
+    const uint32_t r = OSMT_LABEL_LDS_CELLS / cols;
+    return r < 64u ? r : 64u;
+}
+__host__ __device__ static inline uint32_t osmt_label_band_words(uint32_t cols) { return (osmt_label_band_rows(cols) * cols + 63u) / 64u; }
 
 struct osmt_label_launch {
     const osmt_labelinfo* info;
@@ -165,6 +174,7 @@ struct osmt_label_launch {
     const double* segs;
     const uint32_t* wide; /* labels that need k_label_cover_wide */
     double* plane_a;
+    unsigned long long* cell_bits; /* coverage bit streams (osmt_label_band_words) */
     double* plane_s_wide;
     uint32_t* bitmap; /* scale > 1 only */
     uint8_t* ok;

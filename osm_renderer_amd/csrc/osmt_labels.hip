@@ -128,7 +128,7 @@ __device__ __forceinline__ void wave_lds_order() {
 __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __restrict__ g_lab,
                                                      const osmt_label_band* __restrict__ g_band, uint32_t n_bands,
                                                      const double4* __restrict__ g_seg, double* __restrict__ g_a,
-                                                     uint32_t* g_err) {
+                                                     unsigned long long* __restrict__ g_bits, uint32_t* g_err) {
     __shared__ double sh_a[LC_CELLS];
     __shared__ double sh_s[LC_CELLS];
     __shared__ double sh_ev_val[2][LC_CH * LC_VSTRIDE]; /* [buffer][channel][call of the batch]: the parked sum */
@@ -335,8 +335,17 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
         }
     }
     __syncthreads();
+    /* the band goes out coalesced: the totals for k_raster, and one bit per cell (total > 0: the pixels the label
+     * would set, rasterizer.rs:137) for k_label_resolve */
     double* __restrict__ dst = A + (size_t)rbase * cols;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 128u) dst[i] = sh_a[i];
+    unsigned long long* __restrict__ bits = g_bits + li->wide_off + (size_t)(rbase / band_rows) * osmt_label_band_words(cols);
+    for (uint32_t i0 = (threadIdx.x & ~63u); i0 < cnt; i0 += 128u) {
+        const uint32_t i = i0 + lane;
+        const double v = i < cnt ? sh_a[i] : 0.0;
+        if (i < cnt) dst[i] = v;
+        const unsigned long long m = __ballot(v > 0.0);
+        if (lane == 0u) bits[i0 >> 6] = m;
+    }
     if (oob) atomicOr(g_err, 1u);
 }
 
@@ -387,10 +396,6 @@ __global__ __launch_bounds__(64) void k_label_cover_wide(const osmt_labelinfo* _
     if (oob) atomicOr(g_err, 1u);
 }
 
-#define OSMT_LABEL_RESOLVE_THREADS 256
-
-/* workgroup barrier that orders LDS traffic only (global loads issued before it stay in flight) */
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* i / d and i % d from d's float reciprocal; `small`: i < 2^22, so that (float)i is exact and the product is within
  * one of the quotient (relative error 2^-23): one step either way settles it.  Otherwise the plain division. */
@@ -412,141 +417,207 @@ __device__ __forceinline__ uint32_t resolve_divmod(bool small, uint32_t i, uint3
     return q;
 }
 /* LDS_BM: the (3W)^2-bit ownership map lives in LDS (scale 1: 72 KB); otherwise in global memory. */
+/* ONE WAVE per tile: a label's pixels are handled 32 at a time — a row of an icon is a run of ones, a row of a text
+ * window is a piece of the band's coverage bit stream (k_label_cover) shifted onto the ownership map — so a label is a
+ * few dozen word operations and no workgroup barrier stands between two labels.  The labels are a serial chain (a
+ * verdict decides what the next label collides with) and only two such waves fit a CU beside their 72 KB maps, so
+ * nothing else would hide a trip to memory: the tile's label records are staged in LDS 64 at a time, and the stream
+ * words of label l + 1 are requested before label l is decided.  Windows wider than the LDS band
+ * (k_label_cover_wide, no bit stream) are walked cell by cell. */
+#define LR_STAGE 64u
 template <bool LDS_BM>
-__global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
+__global__ __launch_bounds__(64) void k_label_resolve(
     const osmt_labelinfo* __restrict__ g_lab, const uint32_t* __restrict__ g_job_label_off, uint32_t n_jobs, uint32_t scale,
-    const double* __restrict__ g_a, uint32_t* g_bitmap, uint8_t* g_ok, osmt_tile_label* __restrict__ g_tl,
-    uint32_t* __restrict__ g_tl_cnt) {
+    const double* __restrict__ g_a, const unsigned long long* __restrict__ g_bits, uint32_t* g_bitmap, uint8_t* g_ok,
+    osmt_tile_label* __restrict__ g_tl, uint32_t* __restrict__ g_tl_cnt) {
     extern __shared__ uint32_t sh_bm[];
+    __shared__ osmt_labelinfo sh_li[LR_STAGE];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_jobs) return;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = threadIdx.x;
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
-    const uint32_t EW = 3u * (uint32_t)W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72) */
-    const size_t words = ((size_t)EW * EW + 31u) / 32u;
-    __shared__ uint32_t sh_hit[3];
+    const int32_t EW = 3 * W; /* labels_bb is the 3x3-tile square [-W, 2W) (tile_pixels.rs:67-72); a multiple of 32 */
+    const uint32_t row_words = (uint32_t)EW / 32u;
+    const size_t words = (size_t)EW * row_words;
     uint32_t* bm = LDS_BM ? sh_bm : g_bitmap + (size_t)tile * words;
-    for (size_t i = tid; i < words; i += OSMT_LABEL_RESOLVE_THREADS) bm[i] = 0u;
-    if (tid < 3u) sh_hit[tid] = 0u;
-    if (!LDS_BM) __threadfence();
-    __syncthreads();
-    auto test = [&](uint32_t bit) -> bool {
-        if (LDS_BM) return (bm[bit >> 5] >> (bit & 31u)) & 1u;
-        return (__hip_atomic_load(bm + (bit >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31u)) & 1u;
-    };
     const uint32_t l0 = g_job_label_off[tile], l1 = g_job_label_off[tile + 1];
-    uint32_t n_out = 0; /* thread 0: succeeded labels that reach into the tile itself */
-    /* The labels are a serial chain (a verdict decides what the next label collides with), so what a label needs from
-     * global memory is fetched while its predecessor is being decided: its record and the first RP x 256 cells. */
-    constexpr int RP = 4;
-    struct View {
+    auto stage = [&](uint32_t first) { /* records first .. first + 63 -> LDS, one per lane */
+        if (first + lane < l1) {
+            const uint4* src = reinterpret_cast<const uint4*>(g_lab + first + lane);
+            uint4* dst = reinterpret_cast<uint4*>(&sh_li[lane]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = src[k];
+        }
+    };
+    stage(l0);
+    if (LDS_BM) {
+        uint4* z = reinterpret_cast<uint4*>(sh_bm); /* EW * EW / 32 words: a multiple of 4 */
+        for (size_t i = lane; i < words / 4u; i += 64u) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (size_t i = lane; i < words; i += 64u) bm[i] = 0u;
+        __threadfence();
+    }
+    wave_lds_order();
+    /* pass 0: does the word collide with an earlier succeeded label?  pass 1: take ownership.  Words of one row run
+     * never repeat; an icon and a text of the same label may meet in a word, hence the atomic OR. */
+    auto word_op = [&](int pass, uint32_t wi, uint32_t m, bool& hit) {
+        if (!m) return;
+        if (pass == 0) {
+            const uint32_t have = LDS_BM ? bm[wi] : __hip_atomic_load(bm + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hit |= (have & m) != 0u;
+        } else {
+            atomicOr(bm + wi, m);
+        }
+    };
+    /* what a label is, in map words */
+    struct Plan {
         int32_t ix0, iy0, ry0, ry1, cx0;
-        uint32_t iw, ih, cols, n_cells;
-        bool has_cells;
+        uint32_t iw, ih, cols;
+        bool has_cells, streamed;
+        int32_t ia, ib, ta, tb, iya; /* clipped icon / text column runs, first icon row inside the map */
+        uint32_t iw0, inw, irows, tw0, tnw, R, band_rows, band_words;
+        const uint32_t* stream;
         const double* A;
     };
-    auto view_of = [&](uint32_t l) -> View {
-        const osmt_labelinfo* __restrict__ li = g_lab + l;
-        View v;
-        v.ix0 = li->icon_x, v.iy0 = li->icon_y;
-        v.iw = li->icon_w, v.ih = li->icon_h;
-        v.ry0 = li->ry0, v.ry1 = li->ry1, v.cx0 = li->cx0;
-        v.cols = li->cols;
-        v.has_cells = li->has_text && v.ry0 <= v.ry1 && v.cols > 0;
-        v.n_cells = v.has_cells ? (uint32_t)(v.ry1 - v.ry0 + 1) * v.cols : 0u;
-        v.A = g_a + li->plane_off;
-        return v;
+    auto plan_of = [&](uint32_t l) -> Plan {
+        const osmt_labelinfo* li = &sh_li[(l - l0) % LR_STAGE];
+        Plan p;
+        p.ix0 = li->icon_x, p.iy0 = li->icon_y, p.ry0 = li->ry0, p.ry1 = li->ry1, p.cx0 = li->cx0;
+        p.iw = li->icon_w, p.ih = li->icon_h, p.cols = li->cols;
+        p.has_cells = li->has_text && p.ry0 <= p.ry1 && p.cols > 0;
+        /* a row run [dx0, dx1) of map columns, clipped to the map (set_label_pixel: outside labels_bb -> true,
+         * nothing to own): words w0 .. w0 + nw - 1 of the row */
+        auto clip_run = [&](int32_t dx0, int32_t dx1, int32_t& a, int32_t& b, uint32_t& w0, uint32_t& nw) {
+            a = max(dx0, 0), b = min(dx1, EW);
+            w0 = (uint32_t)a >> 5;
+            nw = a < b ? (((uint32_t)(b - 1) >> 5) - w0 + 1u) : 0u;
+        };
+        clip_run(p.ix0 + W, p.ix0 + W + (int32_t)p.iw, p.ia, p.ib, p.iw0, p.inw);
+        p.iya = max(p.iy0, -W);
+        const int32_t iyb = min(p.iy0 + (int32_t)p.ih, 2 * W);
+        p.irows = (p.iw && p.iya < iyb) ? (uint32_t)(iyb - p.iya) : 0u;
+        clip_run(p.cx0 + W, p.cx0 + W + (int32_t)p.cols, p.ta, p.tb, p.tw0, p.tnw);
+        p.streamed = p.has_cells && p.cols <= LC_CELLS;
+        p.R = p.has_cells ? (uint32_t)(p.ry1 - p.ry0 + 1) : 0u; /* rows are clipped to the map already */
+        p.band_rows = p.streamed ? osmt_label_band_rows(p.cols) : 1u;
+        p.band_words = p.streamed ? osmt_label_band_words(p.cols) : 0u;
+        p.stream = reinterpret_cast<const uint32_t*>(g_bits + li->wide_off);
+        p.A = g_a + li->plane_off;
+        return p;
     };
-    View cur = {};
-    double cv[RP] = {};
-    if (l0 < l1) {
-        cur = view_of(l0);
-#pragma unroll
-        for (int k = 0; k < RP; ++k) {
-            const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
-            cv[k] = i < cur.n_cells ? cur.A[i] : 0.0;
+    /* text item `it` of band `band` (rows rb ..): where its word lands, and which stream bits it is */
+    struct TextItem {
+        uint32_t wi, sbit, nb, sh;
+    };
+    auto text_item = [&](const Plan& p, uint32_t rb, uint32_t it, float rcp) -> TextItem {
+        uint32_t k;
+        const uint32_t r = resolve_divmod(true, it, p.tnw, rcp, k); /* < 64 rows x 21 words */
+        const uint32_t w = p.tw0 + k;
+        const int32_t lo = max(p.ta, (int32_t)(w << 5)), hi = min(p.tb, (int32_t)(w << 5) + 32);
+        TextItem t;
+        t.nb = (uint32_t)(hi - lo);
+        t.sh = (uint32_t)lo & 31u;
+        t.sbit = r * p.cols + (uint32_t)(lo - (p.cx0 + W)); /* first cell of the piece in the band */
+        t.wi = (uint32_t)(p.ry0 + (int32_t)(rb + r) + W) * row_words + w;
+        return t;
+    };
+    auto text_mask = [&](const TextItem& t, uint32_t w0, uint32_t w1) -> uint32_t {
+        const uint64_t pair = (uint64_t)w0 | ((uint64_t)w1 << 32);
+        const uint32_t m = (uint32_t)(pair >> (t.sbit & 31u));
+        return (t.nb >= 32u ? m : (m & ((1u << t.nb) - 1u))) << t.sh;
+    };
+    /* the first 64 text items of a label (band 0): requested one label ahead */
+    auto request = [&](const Plan& p, TextItem& t, uint32_t& w0, uint32_t& w1) {
+        t = TextItem{0u, 0u, 0u, 0u};
+        w0 = w1 = 0u;
+        if (!p.streamed) return;
+        const uint32_t n_items = min(p.band_rows, p.R) * p.tnw;
+        if (lane < n_items) {
+            t = text_item(p, 0u, lane, 1.0f / (float)max(p.tnw, 1u));
+            w0 = p.stream[t.sbit >> 5];
+            w1 = p.stream[(t.sbit >> 5) + 1u];
         }
+    };
+    uint32_t n_out = 0; /* succeeded labels that reach into the tile itself */
+    Plan cur = {};
+    TextItem ct = {};
+    uint32_t cw0 = 0, cw1 = 0;
+    if (l0 < l1) {
+        cur = plan_of(l0);
+        request(cur, ct, cw0, cw1);
     }
     for (uint32_t l = l0; l < l1; ++l) {
-        View nxt = {};
-        double nv[RP] = {};
+        Plan nxt = {};
+        TextItem nt = {};
+        uint32_t nw0 = 0, nw1 = 0;
         if (l + 1 < l1) {
-            nxt = view_of(l + 1);
-#pragma unroll
-            for (int k = 0; k < RP; ++k) {
-                const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
-                nv[k] = i < nxt.n_cells ? nxt.A[i] : 0.0;
+            if ((l + 1 - l0) % LR_STAGE == 0u) { /* every staged record has been planned: next 64 */
+                wave_lds_order();
+                stage(l + 1);
+                wave_lds_order();
             }
+            nxt = plan_of(l + 1);
+            request(nxt, nt, nw0, nw1);
         }
-        const int32_t ix0 = cur.ix0, iy0 = cur.iy0, ry0 = cur.ry0, cx0 = cur.cx0;
-        const uint32_t iw = cur.iw, ih = cur.ih, cols = cur.cols, n_cells = cur.n_cells;
-        const double* __restrict__ A = cur.A;
-        const float rcp_iw = 1.0f / (float)max(iw, 1u), rcp_cols = 1.0f / (float)max(cols, 1u);
-        const bool small_icon = (uint64_t)iw * ih < (1u << 22), small_cells = n_cells < (1u << 22);
+        const Plan& p = cur;
+        const uint32_t first_items = p.streamed ? min(p.band_rows, p.R) * p.tnw : 0u;
+        const uint32_t first_mask = lane < first_items ? text_mask(ct, cw0, cw1) : 0u;
         bool failed = false;
-        for (int pass = 0; pass < 2; ++pass) { /* 0: collide with earlier succeeded labels, 1: take ownership */
+        for (int pass = 0; pass < 2 && !failed; ++pass) {
             bool hit = false;
-            auto pixel = [&](int32_t x, int32_t y) {
-                const uint32_t bit = (uint32_t)(y + W) * EW + (uint32_t)(x + W);
-                if (pass == 0)
-                    hit |= test(bit);
-                else
-                    atomicOr(bm + (bit >> 5), 1u << (bit & 31u));
-            };
-            for (uint32_t i = tid; i < iw * ih; i += OSMT_LABEL_RESOLVE_THREADS) {
-                uint32_t rx;
-                const uint32_t rq = resolve_divmod(small_icon, i, iw, rcp_iw, rx);
-                const int32_t x = ix0 + (int32_t)rx, y = iy0 + (int32_t)rq;
-                if (x < -W || x >= 2 * W || y < -W || y >= 2 * W) continue; /* set_label_pixel: outside labels_bb -> true */
-                pixel(x, y);
+            { /* icon rows: runs of ones */
+                const uint32_t n_items = p.irows * p.inw;
+                const float rcp = 1.0f / (float)max(p.inw, 1u);
+                for (uint32_t it = lane; it < n_items; it += 64u) {
+                    uint32_t k;
+                    const uint32_t r = resolve_divmod(n_items < (1u << 22), it, p.inw, rcp, k);
+                    const uint32_t w = p.iw0 + k;
+                    const int32_t lo = max(p.ia, (int32_t)(w << 5)), hi = min(p.ib, (int32_t)(w << 5) + 32);
+                    const uint32_t nb = (uint32_t)(hi - lo);
+                    const uint32_t m = (nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u)) << ((uint32_t)lo & 31u);
+                    word_op(pass, (uint32_t)(p.iya + W + (int32_t)r) * row_words + w, m, hit);
+                }
             }
-            auto cell = [&](uint32_t i, double a) {
-                if (!(a > 0.0)) return;
-                uint32_t rx;
-                const uint32_t rq = resolve_divmod(small_cells, i, cols, rcp_cols, rx);
-                const int32_t x = cx0 + (int32_t)rx, y = ry0 + (int32_t)rq;
-                if (x < -W || x >= 2 * W) return; /* rows are clipped already */
-                pixel(x, y);
-            };
-#pragma unroll
-            for (int k = 0; k < RP; ++k) {
-                const uint32_t i = tid + (uint32_t)k * OSMT_LABEL_RESOLVE_THREADS;
-                if (i < n_cells) cell(i, cv[k]);
+            if (p.streamed) { /* text rows: pieces of the bands' coverage bit streams */
+                word_op(pass, ct.wi, first_mask, hit);
+                const float rcp = 1.0f / (float)max(p.tnw, 1u);
+                uint32_t band = 0;
+                for (uint32_t rb = 0; rb < p.R; rb += p.band_rows, ++band) {
+                    const uint32_t n_items = min(p.band_rows, p.R - rb) * p.tnw;
+                    const uint32_t* __restrict__ sw = p.stream + (size_t)band * p.band_words * 2u;
+                    for (uint32_t it = lane + (rb == 0u ? 64u : 0u); it < n_items; it += 64u) {
+                        const TextItem t = text_item(p, rb, it, rcp);
+                        word_op(pass, t.wi, text_mask(t, sw[t.sbit >> 5], sw[(t.sbit >> 5) + 1u]), hit);
+                    }
+                }
+            } else if (p.has_cells) { /* no bit stream: cell by cell from the totals */
+                const uint32_t n_cells = p.R * p.cols;
+                const float rcp = 1.0f / (float)p.cols;
+                for (uint32_t i = lane; i < n_cells; i += 64u) {
+                    if (!(p.A[i] > 0.0)) continue;
+                    uint32_t c;
+                    const uint32_t r = resolve_divmod(n_cells < (1u << 22), i, p.cols, rcp, c);
+                    const int32_t dx = p.cx0 + W + (int32_t)c;
+                    if (dx < 0 || dx >= EW) continue; /* rows are clipped already */
+                    word_op(pass, (uint32_t)(p.ry0 + (int32_t)r + W) * row_words + ((uint32_t)dx >> 5), 1u << ((uint32_t)dx & 31u), hit);
+                }
             }
-            for (uint32_t i = tid + RP * OSMT_LABEL_RESOLVE_THREADS; i < n_cells; i += OSMT_LABEL_RESOLVE_THREADS) cell(i, A[i]);
             if (pass == 0) {
-                if (LDS_BM) {
-                    /* the verdict goes through LDS and a barrier that waits for LDS only: __syncthreads would also
-                     * wait for the next label's cells, which are meant to stay in flight (slot l % 3 is cleared
-                     * two labels ahead, a barrier before its first use) */
-                    uint32_t* flag = sh_hit + (l - l0) % 3u;
-                    if (__ballot(hit) && (tid & 63u) == 0u) atomicOr(flag, 1u);
-                    lds_barrier();
-                    failed = *flag != 0u;
-                    if (tid == 0) sh_hit[(l - l0 + 2u) % 3u] = 0u;
-                } else {
-                    failed = __syncthreads_or(hit ? 1 : 0) != 0;
-                }
-                if (tid == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
-                if (failed) break;
-            } else {
-                if (LDS_BM) {
-                    lds_barrier();
-                } else {
-                    __threadfence();
-                    __syncthreads();
-                }
+                failed = __ballot(hit) != 0ull;
+                if (lane == 0) g_ok[l] = failed ? 0 : 1; /* bump_label_generation(succeeded) */
             }
+            if (!LDS_BM) __threadfence();
+            wave_lds_order();
         }
-        if (!failed && tid == 0) {
+        if (!failed && lane == 0) {
             /* what k_raster has to look at: the label's pixels clipped to the tile [0, W)^2 */
             int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
-            if (cur.has_cells) {
-                bx0 = cx0, bx1 = cx0 + (int32_t)cols - 1, by0 = ry0, by1 = cur.ry1;
+            if (p.has_cells) {
+                bx0 = p.cx0, bx1 = p.cx0 + (int32_t)p.cols - 1, by0 = p.ry0, by1 = p.ry1;
             }
-            if (iw) {
-                bx0 = min(bx0, ix0), bx1 = max(bx1, ix0 + (int32_t)iw - 1);
-                by0 = min(by0, iy0), by1 = max(by1, iy0 + (int32_t)ih - 1);
+            if (p.iw) {
+                bx0 = min(bx0, p.ix0), bx1 = max(bx1, p.ix0 + (int32_t)p.iw - 1);
+                by0 = min(by0, p.iy0), by1 = max(by1, p.iy0 + (int32_t)p.ih - 1);
             }
             bx0 = max(bx0, 0), by0 = max(by0, 0), bx1 = min(bx1, W - 1), by1 = min(by1, W - 1);
             if (bx0 <= bx1 && by0 <= by1) {
@@ -558,10 +629,11 @@ __global__ __launch_bounds__(OSMT_LABEL_RESOLVE_THREADS) void k_label_resolve(
             }
         }
         cur = nxt;
-#pragma unroll
-        for (int k = 0; k < RP; ++k) cv[k] = nv[k];
+        ct = nt;
+        cw0 = nw0;
+        cw1 = nw1;
     }
-    if (tid == 0) g_tl_cnt[tile] = n_out;
+    if (lane == 0) g_tl_cnt[tile] = n_out;
 }
 
 hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
@@ -572,7 +644,7 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
     hipError_t ce = hipMemsetAsync(a.ok, 0, a.n_labels, st);
     if (ce == hipSuccess) ce = hipMemsetAsync(a.err, 0, 4, st);
     if (ce != hipSuccess) return ce;
-    if (a.n_bands) hipLaunchKernelGGL(k_label_cover, dim3(a.n_bands), dim3(128), 0, st, a.info, a.bands, a.n_bands, segs, a.plane_a, a.err);
+    if (a.n_bands) hipLaunchKernelGGL(k_label_cover, dim3(a.n_bands), dim3(128), 0, st, a.info, a.bands, a.n_bands, segs, a.plane_a, a.cell_bits, a.err);
     if (a.n_wide)
         hipLaunchKernelGGL(k_label_cover_wide, dim3(a.n_wide), dim3(64), 0, st, a.info, a.wide, a.n_wide, segs, a.plane_a,
                            a.plane_s_wide, a.err);
@@ -583,11 +655,11 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st) {
         const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_label_resolve<true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (ae != hipSuccess) return ae;
-        hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), bm_bytes, st, a.info,
-                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+        hipLaunchKernelGGL(k_label_resolve<true>, dim3(a.n_jobs), dim3(64), bm_bytes, st, a.info, a.job_label_off, a.n_jobs,
+                           a.scale, a.plane_a, a.cell_bits, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
     } else {
-        hipLaunchKernelGGL(k_label_resolve<false>, dim3(a.n_jobs), dim3(OSMT_LABEL_RESOLVE_THREADS), 0, st, a.info,
-                           a.job_label_off, a.n_jobs, a.scale, a.plane_a, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
+        hipLaunchKernelGGL(k_label_resolve<false>, dim3(a.n_jobs), dim3(64), 0, st, a.info, a.job_label_off, a.n_jobs,
+                           a.scale, a.plane_a, a.cell_bits, a.bitmap, a.ok, a.tile_labels, a.tile_label_cnt);
     }
     return hipGetLastError();
 }

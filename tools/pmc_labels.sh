@@ -9,5 +9,5 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA 
   i=$((i+1))
   rm -rf /tmp/pl_$i
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pl_$i -o p -- python tools/bench_labels.py 1024 24 2 > /dev/null 2>/tmp/pl_$i.err || tail -3 /tmp/pl_$i.err
-  python tools/rocpd_summary.py $(find /tmp/pl_$i -name '*.db' | head -1) | grep -E "k_label_cover" | cut -c1-100
+  python tools/rocpd_summary.py $(find /tmp/pl_$i -name '*.db' | head -1) | grep -E "${PMC_KERNEL:-k_label_cover}" | cut -c1-100
 done
