@@ -138,10 +138,11 @@ struct osmt_labelinfo {
 };
 static_assert(sizeof(osmt_labelinfo) == 64, "osmt_labelinfo must be one 64-byte record");
 
-/* Accumulator cells (A and S each) one k_label_cover wave keeps in LDS: a label's window is processed in
- * bands of OSMT_LABEL_LDS_CELLS / cols stripes; windows with more columns take k_label_cover_wide. */
+/* Accumulator cells (A and S each) one k_label_cover workgroup keeps in LDS: a label's window is processed in
+ * bands of OSMT_LABEL_LDS_CELLS / cols stripes; windows with more columns take k_label_cover_wide.  576: with the
+ * hand-over buffers a workgroup takes 20 336 B, eight fit a CU (640 cells: seven; measured 448 .. 896, profiles/). */
 #ifndef OSMT_LABEL_LDS_CELLS
-#define OSMT_LABEL_LDS_CELLS 640
+#define OSMT_LABEL_LDS_CELLS 576
 #endif
 
 /* k_label_resolve -> k_raster: a succeeded label that reaches into the tile, with the box to test sub-tiles against */

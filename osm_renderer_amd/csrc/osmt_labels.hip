@@ -11,19 +11,26 @@
 /* ------------------------------------------------------------------------- */
 /* Label pass: font/rasterizer.rs + tile_pixels.rs:131-162 + labeler.rs:91-106.
  *
- * k_label_cover    one wave per band of a label's window (osmt_label_band).  Lane = one stripe y; the wave digests the
- *                  draw_line calls 64 at a time (one call per lane: the y-independent part of draw_line,
- *                  two f64 divisions) into LDS, then every lane walks the calls that cross the band IN
- *                  CALL ORDER and adds those that cross its stripe into its own row of the LDS-resident
- *                  A / S accumulators — the per-key f64 sums therefore happen in exactly the reference's
- *                  order (BTreeMap entry += ..., :77,:80) with no atomics.  Then the lane runs
- *                  save_to_figure's scan over [x_min, x_max] of its stripe (:121-143) and the band is
- *                  copied out coalesced: total = min(a + s_acc, 1.0) per cell, 0 where the stripe has no key.
- * k_label_resolve  one workgroup per tile, labels strictly in draw order: a label succeeds iff none of
+ * k_label_cover    one workgroup of TWO waves per band of a label's window (osmt_label_band: the stripes of a band
+ *                  never share a cell with another band, and the list is ordered longest-first).  The per-key f64
+ *                  sums of the reference (BTreeMap entry += ..., :77,:80) do not associate, so every cell must see
+ *                  its addends in draw_line call order; everything else is free:
+ *                    producer wave  lane = draw_line call, 64 at a time: the call's whole arithmetic (:27-80, two f64
+ *                                   divisions) for its stripes in the band; each resulting sum is PARKED in the list
+ *                                   of its CHANNEL (column parity, A/S kind, stripe parity) in LDS, lists compacted;
+ *                    consumer wave  lane = channel: a cell belongs to exactly one channel, so the eight lists are
+ *                                   independent chains walked side by side in call order, the running cell in a
+ *                                   register, into the LDS-resident A / S accumulators (no atomics);
+ *                  double-buffered hand-over (one barrier per batch).  Calls whose cells collide in a channel are
+ *                  replayed stripe by stripe by the consumer (lane = stripe) at their place in the order.  Then
+ *                  lane = stripe runs save_to_figure's scan over [x_min, x_max] (:121-143) and the band goes out
+ *                  coalesced: total = min(a + s_acc, 1.0) per cell (0 where the stripe has no key) for k_raster, one
+ *                  bit per cell (total > 0) for k_label_resolve.
+ * k_label_resolve  one wave per tile, labels strictly in draw order: a label succeeds iff none of
  *                  the pixels it would set (icon rectangle, then cells with total > 0) inside labels_bb
  *                  belongs to an earlier SUCCEEDED label (set_label_pixel, tile_pixels.rs:131-148;
  *                  pixels of failed labels are overwritten freely); succeeded labels mark their pixels
- *                  in a (3W)^2-bit ownership map.  The early `return false` of draw_icon /
+ *                  in a (3W)^2-bit ownership map, 32 pixels per operation.  The early `return false` of draw_icon /
  *                  save_to_figure only skips pixels of a label that is not blended anyway.
  * k_raster<LABELS> blends the succeeded labels over the area canvas before to_rgb_triples. */
 /* draw_line for stripe y (font/rasterizer.rs:46-80) into the stripe's own accumulator rows */
