@@ -176,6 +176,9 @@ def main():
                 dist.broadcast(uid, src=0)
                 shard.comm_init_rank(ctx, uid.cpu().numpy(), rank, world)
                 ok = 1 if shard.allreduce_tile_count(ctx, 1) == world else 0
+                if ok:
+                    shard.allreduce_tile_count_enqueue(ctx, 1)
+                    ok = 1 if shard.allreduce_tile_count_result(ctx) == world else 0
             except Exception as e:  # noqa: BLE001
                 print(f"rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
                 ok = 0
@@ -183,7 +186,7 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             native_comm = bool(okt.item())
         if native_comm:
-            collective = "osmt_allreduce_tile_count (library-owned RCCL communicator, ncclAllReduce of one uint64)"
+            collective = "osmt_allreduce_tile_count_enqueue (library-owned RCCL communicator, ncclAllReduce of one uint64 on the render stream)"
 
     def sync_all():
         torch.cuda.synchronize()
@@ -208,9 +211,8 @@ def main():
             if i is not None:
                 ev[i][1].record()
             if dist is not None:
-                if native_comm:
-                    torch.cuda.current_stream().synchronize()  # the count is only final once the tiles are
-                    count.fill_(shard.allreduce_tile_count(ctx, dl.n_jobs))
+                if native_comm:  # queued behind the raster stage on the same stream, no host synchronisation
+                    shard.allreduce_tile_count_enqueue(ctx, dl.n_jobs)
                 else:
                     count.fill_(dl.n_jobs)
                     dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
@@ -228,7 +230,7 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-            total = int(count.item())
+            total = shard.allreduce_tile_count_result(ctx) if native_comm else int(count.item())
             assert total == len(global_tiles_xy), (total, len(global_tiles_xy))
         raster_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         return {"elapsed": elapsed, "total_tiles": total, "raster_ms": raster_ms, "dl": dl, "scene": scene, "out": out, "step": step}

@@ -320,6 +320,11 @@ int osmt_comm_init_local(osmt_ctx* const* ctxs, uint32_t n_ctx);
 /* ncclAllReduce(sum) of one uint64 over the communicator of `ctx`; collective: every rank calls it.  Blocks until the
  * result is on the host. */
 int osmt_allreduce_tile_count(osmt_ctx* ctx, uint64_t local, uint64_t* out_global);
+/* The same reduction behind the kernels of a render: enqueued on `stream` (the stream the batch was rendered on), no
+ * host synchronisation, so the next batch's kernels queue up behind it.  `..._result` copies the most recent sum back
+ * and waits for `stream` only.  Collective: every rank enqueues the same number of reductions. */
+int osmt_allreduce_tile_count_enqueue(osmt_ctx* ctx, uint64_t local, void* stream);
+int osmt_allreduce_tile_count_result(osmt_ctx* ctx, void* stream, uint64_t* out_global);
 /* the same for the contexts of ONE process (a grouped call over all of them) */
 int osmt_allreduce_tile_count_local(osmt_ctx* const* ctxs, uint32_t n_ctx, const uint64_t* locals, uint64_t* out_global);
 

@@ -99,7 +99,7 @@ struct osmt_ctx {
     /* RCCL communicator of the tile-count reduction (osmt_comm_init_*): ncclComm_t, rank and size */
     void* comm = nullptr;
     uint32_t comm_rank = 0, comm_size = 0;
-    unsigned long long* d_count = nullptr; /* two words of device memory for the reduction */
+    unsigned long long* d_count = nullptr; /* device words of the reductions: [0], [1] blocking call, [2], [3] enqueued one */
 };
 
 struct osmt_scene {
@@ -1621,7 +1621,7 @@ int rccl_ready() {
 int comm_buffers(osmt_ctx* ctx) {
     if (ctx->d_count) return OSMT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc((void**)&ctx->d_count, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&ctx->d_count, 4 * sizeof(unsigned long long)));
     return OSMT_OK;
 }
 
@@ -1832,6 +1832,39 @@ static int allreduce_body(osmt_ctx* ctx, uint64_t local, uint64_t* out) {
 
 int osmt_allreduce_tile_count(osmt_ctx* ctx, uint64_t local, uint64_t* out) {
     return guarded([&] { return allreduce_body(ctx, local, out); });
+}
+
+static int allreduce_enqueue_body(osmt_ctx* ctx, uint64_t local, void* stream) {
+    if (!ctx) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (!ctx->comm) return fail(OSMT_INVALID_ARG, "the context has no communicator (osmt_comm_init_rank / osmt_comm_init_local)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    /* the addend goes in as two 32-bit fills: stream-ordered, no host buffer that would have to outlive the call */
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_count + 2), (int)(uint32_t)local, 1, st));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)((char*)(ctx->d_count + 2) + 4), (int)(uint32_t)(local >> 32), 1, st));
+    const int n = rccl()->AllReduce(ctx->d_count + 2, ctx->d_count + 3, 1, RCCL_UINT64, RCCL_SUM, ctx->comm, st);
+    if (n != 0) return rccl_fail("ncclAllReduce", n);
+    return OSMT_OK;
+}
+
+int osmt_allreduce_tile_count_enqueue(osmt_ctx* ctx, uint64_t local, void* stream) {
+    return guarded([&] { return allreduce_enqueue_body(ctx, local, stream); });
+}
+
+static int allreduce_result_body(osmt_ctx* ctx, void* stream, uint64_t* out) {
+    if (!ctx || !out) return fail(OSMT_INVALID_ARG, "NULL argument");
+    if (!ctx->comm) return fail(OSMT_INVALID_ARG, "the context has no communicator (osmt_comm_init_rank / osmt_comm_init_local)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long got = 0;
+    HIP_TRY(hipMemcpyAsync(&got, ctx->d_count + 3, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = got;
+    return OSMT_OK;
+}
+
+int osmt_allreduce_tile_count_result(osmt_ctx* ctx, void* stream, uint64_t* out) {
+    return guarded([&] { return allreduce_result_body(ctx, stream, out); });
 }
 
 static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, uint8_t* out, size_t stride, uint64_t* out_count) {

@@ -24,7 +24,7 @@ EXPORTS = [
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
     "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
     "osmt_comm_unique_id", "osmt_comm_init_rank", "osmt_comm_init_local", "osmt_allreduce_tile_count",
-    "osmt_allreduce_tile_count_local", "osmt_hbm_copy_probe",
+    "osmt_allreduce_tile_count_local", "osmt_allreduce_tile_count_enqueue", "osmt_allreduce_tile_count_result", "osmt_hbm_copy_probe",
 ]
 
 
@@ -65,6 +65,8 @@ def load():
     L.osmt_comm_init_rank.argtypes = [vp, u8p, C.c_uint32, C.c_uint32]
     L.osmt_comm_init_local.argtypes = [C.POINTER(vp), C.c_uint32]
     L.osmt_allreduce_tile_count.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.osmt_allreduce_tile_count_enqueue.argtypes = [vp, C.c_uint64, vp]
+    L.osmt_allreduce_tile_count_result.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.osmt_allreduce_tile_count_local.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.osmt_hbm_copy_probe.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.osmt_scene_upload.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(vp)]

@@ -82,6 +82,25 @@ def allreduce_tile_count(ctx, local):
     return int(out.value)
 
 
+def allreduce_tile_count_enqueue(ctx, local, stream=None):
+    """osmt_allreduce_tile_count_enqueue: the same reduction queued behind the render on `stream` (default: torch's
+    current stream); no host synchronisation."""
+    import torch
+
+    s = torch.cuda.current_stream() if stream is None else stream
+    check(load().osmt_allreduce_tile_count_enqueue(ctx._h, int(local), C.c_void_p(s.cuda_stream)))
+
+
+def allreduce_tile_count_result(ctx, stream=None):
+    """osmt_allreduce_tile_count_result: the most recent enqueued sum (waits for `stream` only)."""
+    import torch
+
+    s = torch.cuda.current_stream() if stream is None else stream
+    out = C.c_uint64(0)
+    check(load().osmt_allreduce_tile_count_result(ctx._h, C.c_void_p(s.cuda_stream), C.byref(out)))
+    return int(out.value)
+
+
 def reduce_tile_count(local_count, dist=None, device=None):
     """Sum of per-rank tile counts through torch.distributed (gloo on CPU, RCCL when the group is 'nccl'): the
     CPU-testable twin of allreduce_tile_count.  Returns the global count."""

@@ -1,6 +1,7 @@
 """osmt_render_batch_multi, the RCCL tile-count reduction and the HBM copy probe through the C ABI."""
 import numpy as np
 import pytest
+import torch
 
 from osm_renderer_amd import abi, shard, synth
 from osm_renderer_amd.lib import OsmtError
@@ -51,6 +52,15 @@ def test_rccl_tile_count_reduction_single_rank(gpu_ctx):
     shard.comm_init_rank(gpu_ctx, uid, 0, 1)
     assert shard.allreduce_tile_count(gpu_ctx, 1250) == 1250
     assert shard.allreduce_tile_count(gpu_ctx, (1 << 40) + 7) == (1 << 40) + 7
+    # the stream-ordered form bench.py uses per step: queued behind a render, read back once
+    dl = synth.config2(5)
+    scene = gpu_ctx.upload(dl)
+    out = torch.empty((5, 256, 256, 4), dtype=torch.uint8, device=gpu_ctx.device)
+    for k in range(3):
+        gpu_ctx.render(scene, out)
+        shard.allreduce_tile_count_enqueue(gpu_ctx, (1 << 33) + k)
+    assert shard.allreduce_tile_count_result(gpu_ctx) == (1 << 33) + 2
+    scene.free()
     # a grouped local reduction over the same single context
     shard.comm_init_local([gpu_ctx])
     out, cnt = shard.render_batch_multi([gpu_ctx], synth.config2(3))
