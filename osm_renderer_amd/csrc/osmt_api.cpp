@@ -1092,6 +1092,20 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     /* every band scans all of its label's draw_line calls: longest first (ties keep draw order) */
     std::stable_sort(bands.begin(), bands.end(),
                      [&](const osmt_label_band& a, const osmt_label_band& b) { return info[a.label].n_segs > info[b.label].n_segs; });
+    /* workgroup b runs on XCD b mod 8, each with an L2 of its own: the bands of one label (neighbours in the sorted
+     * list, all reading the same draw_line calls) are dealt to ONE residue class, G at a time, so that the calls come
+     * from HBM once and from that XCD's L2 for the other bands */
+    {
+        constexpr size_t G = 16, CH = 8 * G;
+        std::vector<osmt_label_band> dealt(bands.size());
+        const size_t full = bands.size() / CH * CH;
+        for (size_t i = 0; i < full; ++i) {
+            const size_t c = i / CH, j = i % CH;
+            dealt[c * CH + (j % G) * 8 + j / G] = bands[i];
+        }
+        for (size_t i = full; i < bands.size(); ++i) dealt[i] = bands[i];
+        bands.swap(dealt);
+    }
 
     size_t off = 0;
     auto carve = [&](size_t bytes) {
