@@ -372,12 +372,35 @@ def main():
                 _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
                 ts.append(time.perf_counter() - t0)
             png_s = min(ts)
+            # the same call from the reference's server shape (http_server.rs:50-83: a pool of workers, one request each):
+            # W host threads issue PNG batches back to back; one thread's validation / upload overlaps another's kernels
+            import threading
+
+            def workers(n_thr, calls=4):
+                bufs = [ctx.host_alloc((dl.n_jobs * 96 * 1024,)) for _ in range(n_thr)]
+                def run(b):
+                    for _ in range(calls):
+                        ctx.render_batch_png(dl, out=b, as_bytes=False)
+                for b in bufs:
+                    ctx.render_batch_png(dl, out=b, as_bytes=False)
+                th = [threading.Thread(target=run, args=(b,)) for b in bufs]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = time.perf_counter() - t0
+                for b in bufs:
+                    ctx.host_free(b)
+                return n_thr * calls * dl.n_jobs / dt
+            pooled = {str(w): workers(w) for w in (2, 4)}
             result["end_to_end"] = {
                 "what": "wall clock around one osmt_render_batch / osmt_render_batch_png call (validation + H2D of the display lists + all "
                         "kernels + D2H into pinned host memory), best of 3; never `value`",
                 "tiles": dl.n_jobs,
                 "raw_rgba8_pinned_tiles_per_s": dl.n_jobs / raw_s, "raw_rgba8_ms": raw_s * 1e3,
                 "png_files_pinned_tiles_per_s": dl.n_jobs / png_s, "png_ms": png_s * 1e3, "png_bytes_per_tile": float(off[-1]) / dl.n_jobs,
+                "png_files_worker_threads_tiles_per_s": pooled,
             }
             ctx.host_free(pin)
             ctx.host_free(pbuf)
