@@ -364,6 +364,15 @@ def main():
                 ctx.render_batch_host(dl, out=pin)
                 ts.append(time.perf_counter() - t0)
             raw_s = min(ts)
+            pin3 = ctx.host_alloc((dl.n_jobs, dl.dim * dl.dim * 3))
+            ctx.render_batch_rgb(dl, out=pin3)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.render_batch_rgb(dl, out=pin3)
+                ts.append(time.perf_counter() - t0)
+            rgb_s = min(ts)
+            ctx.host_free(pin3)
             pbuf = ctx.host_alloc((dl.n_jobs * 96 * 1024,))
             _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
             ts = []
@@ -399,6 +408,7 @@ def main():
                         "kernels + D2H into pinned host memory), best of 3; never `value`",
                 "tiles": dl.n_jobs,
                 "raw_rgba8_pinned_tiles_per_s": dl.n_jobs / raw_s, "raw_rgba8_ms": raw_s * 1e3,
+                "raw_rgb8_pinned_tiles_per_s": dl.n_jobs / rgb_s, "raw_rgb8_ms": rgb_s * 1e3,
                 "png_files_pinned_tiles_per_s": dl.n_jobs / png_s, "png_ms": png_s * 1e3, "png_bytes_per_tile": float(off[-1]) / dl.n_jobs,
                 "png_files_worker_threads_tiles_per_s": pooled,
             }

@@ -1234,7 +1234,7 @@ int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba,
 }
 
 static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
-                             size_t stride) {
+                             size_t stride, bool rgb = false) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = nullptr; /* the whole call lives on its own stream: concurrent callers overlap on the GPU */
@@ -1254,11 +1254,12 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
         }
     }
     const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
-    const size_t tile_bytes = W * W * 4;
-    if (stride < tile_bytes) {
+    const size_t tile_bytes = W * W * 4;                   /* what k_raster writes */
+    const size_t host_bytes = rgb ? W * W * 3 : tile_bytes; /* what crosses PCIe */
+    if (stride < host_bytes) {
         osmt_scene_free(sc);
         stream_release(ctx, st);
-        return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+        return fail(OSMT_INVALID_ARG, rgb ? "out_tile_stride_bytes < W*H*3" : "out_tile_stride_bytes < W*H*4");
     }
     /* Output in pinned host memory (osmt_host_alloc / hipHostMalloc / a registered range) and a batch worth
      * splitting: kernels of chunk k overlap the D2H copy of chunk k-1 on a second stream. */
@@ -1280,7 +1281,9 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
             e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
         }
+        char* d_rgb = nullptr;
         if (e == hipSuccess) e = dev_alloc(ctx, (void**)&d_out, 2 * (size_t)chunk * tile_bytes);
+        if (e == hipSuccess && rgb) e = dev_alloc(ctx, (void**)&d_rgb, 2 * (size_t)chunk * host_bytes);
         if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "pipeline setup failed: %s", hipGetErrorString(e));
         if (rc == OSMT_OK) rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, s_k);
         uint32_t c = 0;
@@ -1291,13 +1294,19 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
             if (c >= 2) e = hipStreamWaitEvent(s_k, freed[k], 0);
             if (e == hipSuccess) rc = render_impl(ctx, sc, 4u | 16u, dst, tile_bytes, false, s_k, first, cnt);
             if (rc != OSMT_OK) break;
+            const char* src = dst;
+            if (rgb && e == hipSuccess) { /* packed on the device, behind the chunk's raster */
+                char* pk = d_rgb + (size_t)k * chunk * host_bytes;
+                e = osmt_launch_rgba_to_rgb(dst, pk, (size_t)cnt * W * W, s_k);
+                src = pk;
+            }
             if (e == hipSuccess) e = hipEventRecord(done[k], s_k);
             if (e == hipSuccess) e = hipStreamWaitEvent(s_c, done[k], 0);
             if (e == hipSuccess) {
-                if (stride == tile_bytes) /* tightly packed tiles: one linear copy (2D copies are slower) */
-                    e = hipMemcpyAsync(out_rgba + (size_t)first * stride, dst, (size_t)cnt * tile_bytes, hipMemcpyDeviceToHost, s_c);
+                if (stride == host_bytes) /* tightly packed tiles: one linear copy (2D copies are slower) */
+                    e = hipMemcpyAsync(out_rgba + (size_t)first * stride, src, (size_t)cnt * host_bytes, hipMemcpyDeviceToHost, s_c);
                 else
-                    e = hipMemcpy2DAsync(out_rgba + (size_t)first * stride, stride, dst, tile_bytes, tile_bytes, cnt,
+                    e = hipMemcpy2DAsync(out_rgba + (size_t)first * stride, stride, src, host_bytes, host_bytes, cnt,
                                          hipMemcpyDeviceToHost, s_c);
             }
             if (e == hipSuccess) e = hipEventRecord(freed[k], s_c);
@@ -1315,11 +1324,13 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
         }
         osmt_scene_free(sc);
         dev_free(ctx, d_out);
+        dev_free(ctx, d_rgb);
         stream_release(ctx, s_c);
         stream_release(ctx, st);
         return rc;
     }
     void* d_out = nullptr;
+    void* d_rgb = nullptr;
     if (batch->n_jobs) {
         hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * tile_bytes);
         if (e != hipSuccess) {
@@ -1330,19 +1341,32 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
     }
     rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, st);
     if (rc == OSMT_OK && batch->n_jobs) {
-        hipError_t e;
-        if (stride == tile_bytes)
-            e = hipMemcpyAsync(out_rgba, d_out, batch->n_jobs * tile_bytes, hipMemcpyDeviceToHost, st);
-        else
-            e = hipMemcpy2DAsync(out_rgba, stride, d_out, tile_bytes, tile_bytes, batch->n_jobs, hipMemcpyDeviceToHost, st);
+        hipError_t e = hipSuccess;
+        const void* src = d_out;
+        if (rgb) {
+            e = dev_alloc(ctx, &d_rgb, batch->n_jobs * host_bytes);
+            if (e == hipSuccess) e = osmt_launch_rgba_to_rgb(d_out, d_rgb, batch->n_jobs * W * W, st);
+            src = d_rgb;
+        }
+        if (e == hipSuccess) {
+            if (stride == host_bytes)
+                e = hipMemcpyAsync(out_rgba, src, batch->n_jobs * host_bytes, hipMemcpyDeviceToHost, st);
+            else
+                e = hipMemcpy2DAsync(out_rgba, stride, src, host_bytes, host_bytes, batch->n_jobs, hipMemcpyDeviceToHost, st);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
     osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d_out);
+    dev_free(ctx, d_rgb);
     stream_release(ctx, st);
     return rc;
+}
+
+int osmt_render_batch_rgb(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgb, size_t stride) {
+    return guarded([&] { return osmt_render_batch_labels_body(ctx, batch, labels, out_rgb, stride, true); });
 }
 
 int osmt_render_batch_labels(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,

@@ -151,12 +151,12 @@ class TilePixels {
         osmt_tile_job job = make_job(tile, 0, 0);
         osmt_batch b = make_batch(&job, 1, ops_, rings_, points_, dashes_);
         const size_t dim = dimension();
-        std::vector<uint8_t> rgba(dim * dim * 4);
+        std::vector<uint8_t> rgb(dim * dim * 3); /* the reference's triples, packed (std::tuple's own layout is not) */
         const uint32_t off[2] = {0u, (uint32_t)labels_.size()};
         osmt_label_batch lb{labels_.data(), labels_.size(), off, label_segs_.data(), label_segs_.size() / 4};
-        check(osmt_render_batch_labels(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgba.data(), rgba.size()));
+        check(osmt_render_batch_rgb(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgb.data(), rgb.size()));
         RgbTriples out(dim * dim);
-        for (size_t i = 0; i < dim * dim; ++i) out[i] = {rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]};
+        for (size_t i = 0; i < dim * dim; ++i) out[i] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         return out;
     }
 
@@ -377,7 +377,7 @@ class TileBatch {
     }
     std::vector<TileRenderedPixels> render() {
         const size_t dim = TILE_SIZE * scale_;
-        std::vector<uint8_t> rgba(jobs_.size() * dim * dim * 4);
+        std::vector<uint8_t> rgb(jobs_.size() * dim * dim * 3);
         osmt_batch b{};
         b.jobs = jobs_.data();
         b.n_jobs = jobs_.size();
@@ -392,13 +392,13 @@ class TileBatch {
         b.dashes = dashes_.data();
         b.n_dashes = dashes_.size();
         osmt_label_batch lb{labels_.data(), labels_.size(), label_off_.data(), label_segs_.data(), label_segs_.size() / 4};
-        check(osmt_render_batch_labels(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgba.data(), dim * dim * 4));
+        check(osmt_render_batch_rgb(ctx_->raw(), &b, labels_.empty() ? nullptr : &lb, rgb.data(), dim * dim * 3));
         std::vector<TileRenderedPixels> out(jobs_.size());
         for (size_t t = 0; t < jobs_.size(); ++t) {
             out[t].dimension = dim;
             out[t].triples.resize(dim * dim);
-            const uint8_t* p = rgba.data() + t * dim * dim * 4;
-            for (size_t i = 0; i < dim * dim; ++i) out[t].triples[i] = {p[4 * i], p[4 * i + 1], p[4 * i + 2]};
+            const uint8_t* p = rgb.data() + t * dim * dim * 3;
+            for (size_t i = 0; i < dim * dim; ++i) out[t].triples[i] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
         }
         return out;
     }

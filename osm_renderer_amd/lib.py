@@ -20,7 +20,7 @@ EXPORTS = [
     "osmt_create", "osmt_destroy", "osmt_last_error", "osmt_version", "osmt_register_image", "osmt_render_batch",
     "osmt_scene_upload", "osmt_scene_free", "osmt_render_scene", "osmt_render_scene_f64", "osmt_render_scene_stages",
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
-    "osmt_encode_png", "osmt_render_batch_labels", "osmt_scene_set_labels", "osmt_scene_read_label_status",
+    "osmt_encode_png", "osmt_render_batch_labels", "osmt_render_batch_rgb", "osmt_scene_set_labels", "osmt_scene_read_label_status",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
     "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
     "osmt_comm_unique_id", "osmt_comm_init_rank", "osmt_comm_init_local", "osmt_allreduce_tile_count",
@@ -80,6 +80,7 @@ def load():
     L.osmt_composite.argtypes = [vp, dp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
     L.osmt_composite_device.argtypes = [vp, vp, dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.osmt_render_batch_labels.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
+    L.osmt_render_batch_rgb.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_scene_set_labels.argtypes = [vp, vp, C.POINTER(abi.LabelBatch)]
     L.osmt_scene_read_label_status.argtypes = [vp, vp, u8p]
     L.osmt_png_device_bound.argtypes = [C.c_uint32, C.c_uint32]

@@ -165,6 +165,19 @@ class Context:
                                                   dl.dim * dl.dim * 4))
         return out
 
+    def render_batch_rgb(self, dl: DisplayList, labels=None, out=None, stride=None):
+        """osmt_render_batch_rgb: host buffers in, packed RGB8 out (the reference's RgbTriples layout)."""
+        b = dl.as_batch()
+        tight = dl.dim * dl.dim * 3
+        stride = tight if stride is None else stride
+        if out is None:
+            out = np.empty((dl.n_jobs, stride), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size >= dl.n_jobs * stride
+        lb = labels.as_batch() if labels is not None else None
+        check(load().osmt_render_batch_rgb(self._h, C.byref(b), C.byref(lb) if lb is not None else None,
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8)), stride))
+        return out
+
     # -- PNG files from the GPU ----------------------------------------------------
     def encode_png_device(self, rgba, stream=None):
         """osmt_encode_png_device on a uint8 cuda tensor [n, H, W, 4]: (slots uint8 [n, bound], lengths int32 [n])."""

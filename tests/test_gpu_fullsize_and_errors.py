@@ -126,6 +126,38 @@ def test_pinned_output_takes_the_overlapped_chunk_pipeline(gpu_ctx, oracle):
         gpu_ctx.host_free(pin)
 
 
+def test_rgb8_output_is_the_rgba8_output_without_alpha(gpu_ctx):
+    """osmt_render_batch_rgb (the reference's RgbTriples layout, tile_pixels.rs:46,164-181): one-shot and chunk-pipelined
+    paths, tight and padded strides, with and without labels, @2x"""
+    from osm_renderer_amd import abi, labels, synth
+    from osm_renderer_amd.lib import OsmtError
+
+    n = 300
+    dl = synth.make_tiles(synth.config_tiles(n), n_poly=6, n_line=6)
+    pool = labels.make_labels(10, labels_per_tile=5, seed=22)
+    ll = labels.concat_labels([pool.subset([i % 10]) for i in range(n)])
+    tight = dl.dim * dl.dim * 3
+    want = gpu_ctx.render_batch_host(dl)[..., :3].reshape(n, tight)
+    want_l = gpu_ctx.render_batch_host(dl, labels=ll)[..., :3].reshape(n, tight)
+    assert np.array_equal(gpu_ctx.render_batch_rgb(dl), want)  # pageable: one copy
+    assert np.array_equal(gpu_ctx.render_batch_rgb(dl, labels=ll), want_l)
+    stride = tight + 64  # padded tiles: the 2D copy
+    out = np.full((n, stride), 0xAB, dtype=np.uint8)
+    gpu_ctx.render_batch_rgb(dl, out=out, stride=stride)
+    assert np.array_equal(out[:, :tight], want) and (out[:, tight:] == 0xAB).all()
+    pin = gpu_ctx.host_alloc((n, tight))
+    try:
+        pin[:] = 5
+        assert np.array_equal(gpu_ctx.render_batch_rgb(dl, labels=ll, out=pin), want_l)  # pinned, >= 256 tiles: chunks overlap
+    finally:
+        gpu_ctx.host_free(pin)
+    d2 = synth.make_tiles(synth.config_tiles(3), scale=2, n_poly=10, n_line=10)
+    assert np.array_equal(gpu_ctx.render_batch_rgb(d2), gpu_ctx.render_batch_host(d2)[..., :3].reshape(3, -1))
+    with pytest.raises(OsmtError) as e:
+        gpu_ctx.render_batch_rgb(dl, out=np.zeros((n, tight - 1), dtype=np.uint8), stride=tight - 1)
+    assert e.value.code == abi.INVALID_ARG
+
+
 def test_config5_dense_city_at_stated_density(gpu_ctx, oracle):
     """BASELINE configs[4] as stated: 5000 polygons + 4000 polylines (20000 segments) per z=17 tile.  Two tiles
     bit-exact (RGBA8 and f64 canvas) against the oracle, determinism and permutation equivariance on 16 tiles, and
