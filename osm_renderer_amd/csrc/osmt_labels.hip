@@ -101,13 +101,6 @@ __device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
 static_assert(LC_CELLS < 1024, "a parked sum's cell is stripe << 10 | column");
 #define LC_NOCELL 0xFFFFu /* stripe 63, column 1023: no window has it (cols <= OSMT_LABEL_LDS_CELLS < 1024) */
 
-__device__ __forceinline__ double readlane_f64(double v, uint32_t j) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)j);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)j);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-
 /* channel list strides, skewed so that the eight channel lanes reading entry j of their lists hit different banks */
 #define LC_VSTRIDE 65 /* doubles */
 #define LC_KSTRIDE 66 /* uint16 */
