@@ -97,7 +97,7 @@ def pmc_child(name):
     from osm_renderer_amd.renderer import Context
 
     ctx = Context(0)
-    if name in ("composite", "all"):
+    if name.partition(":")[0] in ("composite", "all"):
         planes = synth.composite_planes(64, L=8, dim=512, device=ctx.device)
         cout = torch.empty((64, 512, 512, 4), dtype=torch.uint8, device=ctx.device)
         for _ in range(4):
@@ -106,12 +106,13 @@ def pmc_child(name):
         del planes, cout
         if name == "composite":
             return
+    name, _, n_arg = name.partition(":")  # "config5:64" = the workload with 64 tiles
     if name == "config5":
-        dl = synth.config5(16)
+        dl = synth.config5(int(n_arg) if n_arg else 64)
     elif name == "raster_2x":
-        dl = synth.config3(256)
+        dl = synth.config3(int(n_arg) if n_arg else 256)
     else:
-        dl = synth.config2(1024)
+        dl = synth.config2(int(n_arg) if n_arg else 1024)
     scene = ctx.upload(dl)
     out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=ctx.device)
     for _ in range(4):
@@ -119,6 +120,22 @@ def pmc_child(name):
         ctx.render_stages(scene, abi.STAGE_RASTER, out)
     torch.cuda.synchronize()
     scene.free()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with one rank
+    per GPU on a free local port, pass rank 0's JSON line through, return the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -133,8 +150,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    n_dev = torch.cuda.device_count()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if n_dev < args.gpus:
+        # never a silent N = 1 run under an N-GPU label
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible: refusing to run")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+        # 127.0.0.1), the way the reference deals tiles to its own workers (src/http_server.rs:50-83,105-108)
+        sys.exit(self_launch(args.gpus))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(--nproc-per-node {args.gpus}) or drop the launcher and let bench.py start its own ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -156,6 +184,7 @@ def main():
     # harness needs anyway for its barriers).  Any failure falls back to torch.distributed.all_reduce — also RCCL.
     collective = "none (1 GPU)"
     native_comm = False
+    nranks_seen = 1  # what an all-reduce(sum) of 1 over the path's collective returns
     if dist is not None:
         collective = "torch.distributed.all_reduce (RCCL)"
         # step 1, no collective of the library yet: can EVERY rank load RCCL through the library?  (a rank that cannot
@@ -185,6 +214,12 @@ def main():
             okt = torch.tensor([ok], device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             native_comm = bool(okt.item())
+        if native_comm:
+            nranks_seen = shard.allreduce_tile_count(ctx, 1)
+        else:
+            one = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(one)
+            nranks_seen = int(one.item())
         if native_comm:
             collective = "osmt_allreduce_tile_count_enqueue (library-owned RCCL communicator, ncclAllReduce of one uint64 on the render stream)"
 
@@ -273,6 +308,7 @@ def main():
             "named_config": bool(named),
             "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
             "collective": collective,
+            "rccl_nranks_seen": nranks_seen,
         },
         "roofline": {
             "kernel": "k_raster (fused fill/stroke/blend/to_rgb) — instruction-issue bound by construction, see roofline_issue; "

@@ -314,6 +314,14 @@ void osmt_batch_shard_free(osmt_batch_shard* shard);
  * joined the contexts, summed on the host otherwise; it equals batch->n_jobs on success. */
 int osmt_render_batch_multi(osmt_ctx* const* ctxs, uint32_t n_ctx, const osmt_batch* batch, uint8_t* out_rgba,
                             size_t out_tile_stride_bytes, uint64_t* out_tile_count);
+/* The same with what the reference's workers always do after the areas — Drawer::draw_labels per tile
+ * (drawer.rs:107-125) — and with the reference's own output format: `labels` (may be NULL) is sliced per shard by
+ * job_label_off (tile i's labels travel with tile i, segments re-packed); flags & OSMT_MULTI_RGB8 writes packed RGB8
+ * (out_tile_stride_bytes >= W*H*3, the layout of osmt_render_batch_rgb) instead of RGBA8.  Image ids of the labels /
+ * FILL_IMAGE ops are per context: register the same icons in the same order on every context. */
+#define OSMT_MULTI_RGB8 1u
+int osmt_render_batch_multi_ex(osmt_ctx* const* ctxs, uint32_t n_ctx, const osmt_batch* batch, const osmt_label_batch* labels,
+                               uint32_t flags, uint8_t* out, size_t out_tile_stride_bytes, uint64_t* out_tile_count);
 
 /* RCCL communicators for the tile-count reduction (the path's only collective: 8 bytes, latency-bound).  The library
  * is loaded at the first of these calls (dlopen: an already loaded RCCL — e.g. PyTorch's — is reused).

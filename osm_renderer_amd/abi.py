@@ -11,6 +11,7 @@ MAX_DASHES = 16
 
 OK, INVALID_ARG, OOM, HIP_ERROR, UNSUPPORTED, NO_DEVICE, RCCL_ERROR = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
+MULTI_RGB8 = 1  # osmt_render_batch_multi_ex flags
 
 OP_NONE, OP_FILL_COLOR, OP_FILL_IMAGE, OP_STROKE = 0, 1, 2, 3
 CAP_NONE, CAP_BUTT, CAP_ROUND, CAP_SQUARE = 0, 1, 2, 3

@@ -123,6 +123,7 @@ struct osmt_scene {
     osmt_stroke_aux* d_aux = nullptr;
     uint32_t* d_submask = nullptr;
     uint32_t* d_op_blk = nullptr;
+    uint32_t* d_op_vseg = nullptr; /* op -> its first virtual segment (stroke ops with segments) */
     osmt_blk_bbox* d_blk = nullptr;
     double* d_rden = nullptr;
     uint32_t* d_op_job = nullptr;
@@ -140,7 +141,7 @@ struct osmt_scene {
     uint2* d_skey = nullptr;
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
-    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_job, h_vseg_base, h_stroke_op, h_vseg_blk_slot, h_lab_wide;
+    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_vseg, h_op_job, h_vseg_base, h_stroke_op, h_vseg_blk_slot, h_lab_wide;
     std::vector<osmt_label_band> h_lab_bands;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
@@ -495,6 +496,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.op_aux = sc->d_op_aux;
     a.op_job = sc->d_op_job;
     a.op_blk = sc->d_op_blk;
+    a.op_vseg = sc->d_op_vseg;
     a.vseg_base = sc->d_vseg_base;
     a.stroke_op = sc->d_stroke_op;
     a.vseg_blk_slot = sc->d_vseg_blk_slot;
@@ -710,10 +712,11 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
 
 /* st == nullptr: blocking copies (the public osmt_scene_upload); otherwise stream-ordered on `st`, the caller
  * synchronises the stream before the batch's host arrays go away */
-static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st) {
+/* trusted: the batch was built by the library itself from a batch it has already validated (the shards of osmt_render_batch_multi) */
+static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st, bool trusted = false) {
     if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out_scene = nullptr;
-    int rc = validate_batch(b);
+    int rc = trusted ? OSMT_OK : validate_batch(b);
     if (rc != OSMT_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
 
@@ -724,9 +727,11 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     std::vector<uint32_t>& pt_job = s->h_pt_job;
     std::vector<uint32_t>& op_aux = s->h_op_aux;
     std::vector<uint32_t>& op_blk = s->h_op_blk;
+    std::vector<uint32_t>& op_vseg = s->h_op_vseg;
     pt_job.assign(b->n_pts, 0xFFFFFFFFu);
     op_aux.assign(b->n_ops, 0u);
     op_blk.assign(b->n_ops, 0xFFFFFFFFu);
+    op_vseg.assign(b->n_ops, 0u);
     /* op -> job; stroke slot -> op; first virtual segment (edges + the two cap stubs of Round/Square caps,
      * line.rs:33-57) of every stroke slot: k_stroke_bin runs one thread per virtual segment of the scene */
     std::vector<uint32_t>& op_job = s->h_op_job;
@@ -759,6 +764,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
                 const size_t nv = ne + ((op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE) ? 2u : 0u);
                 if (nv) { /* only ops with segments enter the binning table: 64 consecutive segments then span <= 64 entries */
                     stroke_op.push_back(job.op_off + k);
+                    op_vseg[job.op_off + k] = (uint32_t)n_vsegs;
                     vseg_base.push_back((uint32_t)n_vsegs);
                     n_vsegs += nv;
                 }
@@ -810,20 +816,22 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_ptjob = carve(b->n_pts * 4);
     const size_t o_opaux = carve(b->n_ops * 4);
     const size_t o_opblk = carve(b->n_ops * 4);
+    const size_t o_opvseg = carve(b->n_ops * 4);
     const size_t o_opjob = carve(b->n_ops * 4);
     const size_t o_vsegbase = carve(vseg_base.size() * 4);
     const size_t o_strokeop = carve(((size_t)n_strokes + 1) * 4);
     const size_t o_blkslot = carve((blk_slot.size() + 1) * 4);
     const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
-    const size_t o_trav = carve(b->n_pts * 8);
-    const size_t o_den = carve(b->n_pts * 8);
+    /* per virtual segment (not per point: two stroke ops may share a ring, e.g. a casing and its stroke) */
+    const size_t o_trav = carve((n_vsegs + 1) * 8);
+    const size_t o_den = carve((n_vsegs + 1) * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
-    const size_t o_rden = carve(b->n_pts * 8);
-    const size_t o_candoff = carve(((size_t)b->n_pts + 1) * 4);
+    const size_t o_rden = carve((n_vsegs + 1) * 8);
+    const size_t o_candoff = carve((n_vsegs + 1) * 4);
     const size_t o_cursors = carve(16);
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
@@ -847,6 +855,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
     s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
+    s->d_op_vseg = (uint32_t*)(s->d_base + o_opvseg);
     s->d_blk = (osmt_blk_bbox*)(s->d_base + o_blk);
     s->d_rden = (double*)(s->d_base + o_rden);
     s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
@@ -880,6 +889,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         put(o_ptjob, pt_job.data(), b->n_pts * 4);
         put(o_opaux, op_aux.data(), b->n_ops * 4);
         put(o_opblk, op_blk.data(), b->n_ops * 4);
+        put(o_opvseg, op_vseg.data(), b->n_ops * 4);
         put(o_opjob, op_job.data(), b->n_ops * 4);
         put(o_vsegbase, vseg_base.data(), vseg_base.size() * 4);
         put(o_strokeop, stroke_op.data(), stroke_op.size() * 4);
@@ -911,6 +921,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
+    if (err == hipSuccess) err = up(s->d_op_vseg, op_vseg.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_vseg_base, vseg_base.data(), vseg_base.size() * 4);
     if (err == hipSuccess) err = up(s->d_stroke_op, stroke_op.data(), stroke_op.size() * 4);
@@ -1234,13 +1245,13 @@ int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba,
 }
 
 static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
-                             size_t stride, bool rgb = false) {
+                             size_t stride, bool rgb = false, bool trusted = false) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = nullptr; /* the whole call lives on its own stream: concurrent callers overlap on the GPU */
     HIP_TRY(stream_acquire(ctx, &st));
     osmt_scene* sc = nullptr;
-    int rc = scene_upload_impl(ctx, batch, &sc, st);
+    int rc = scene_upload_impl(ctx, batch, &sc, st, trusted);
     if (rc != OSMT_OK) {
         stream_release(ctx, st);
         return rc;
@@ -1345,16 +1356,21 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
         const void* src = d_out;
         if (rgb) {
             e = dev_alloc(ctx, &d_rgb, batch->n_jobs * host_bytes);
-            if (e == hipSuccess) e = osmt_launch_rgba_to_rgb(d_out, d_rgb, batch->n_jobs * W * W, st);
+            if (e != hipSuccess) {
+                rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(RGB8 output) failed: %s", hipGetErrorString(e));
+                e = hipSuccess;
+            } else {
+                e = osmt_launch_rgba_to_rgb(d_out, d_rgb, batch->n_jobs * W * W, st);
+            }
             src = d_rgb;
         }
-        if (e == hipSuccess) {
+        if (rc == OSMT_OK && e == hipSuccess) {
             if (stride == host_bytes)
                 e = hipMemcpyAsync(out_rgba, src, batch->n_jobs * host_bytes, hipMemcpyDeviceToHost, st);
             else
                 e = hipMemcpy2DAsync(out_rgba, stride, src, host_bytes, host_bytes, batch->n_jobs, hipMemcpyDeviceToHost, st);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (rc == OSMT_OK && e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
@@ -1679,11 +1695,11 @@ void comm_destroy(osmt_ctx* ctx) {
 
 extern "C" {
 
-static int shard_create_body(const osmt_batch* b, uint32_t rank, uint32_t world, osmt_batch_shard** out) {
+static int shard_create_body(const osmt_batch* b, uint32_t rank, uint32_t world, osmt_batch_shard** out, bool trusted = false) {
     if (!out) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out = nullptr;
     if (world == 0 || rank >= world) return fail(OSMT_INVALID_ARG, "rank %u not in 0..%u", rank, world);
-    int rc = validate_batch(b);
+    int rc = trusted ? OSMT_OK : validate_batch(b);
     if (rc != OSMT_OK) return rc;
     osmt_batch_shard* s = new (std::nothrow) osmt_batch_shard();
     if (!s) return fail(OSMT_OOM, "out of host memory");
@@ -1905,33 +1921,85 @@ int osmt_allreduce_tile_count_result(osmt_ctx* ctx, void* stream, uint64_t* out)
     return guarded([&] { return allreduce_result_body(ctx, stream, out); });
 }
 
-static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, uint8_t* out, size_t stride, uint64_t* out_count) {
+/* The labels of one shard: tiles rank, rank + world, ... keep their labels in draw order, segments re-packed. */
+struct label_shard {
+    osmt_label_batch b;
+    std::vector<osmt_label> labels;
+    std::vector<uint32_t> job_label_off;
+    std::vector<double> segs;
+};
+
+static int label_shard_build(const osmt_label_batch* lb, size_t n_jobs, uint32_t rank, uint32_t world, label_shard* out) {
+    if (!lb->labels || !lb->job_label_off || (lb->n_segs && !lb->segs)) return fail(OSMT_INVALID_ARG, "NULL label pool");
+    if (lb->job_label_off[0] != 0 || lb->job_label_off[n_jobs] != lb->n_labels)
+        return fail(OSMT_INVALID_ARG, "job_label_off must run from 0 to n_labels over n_jobs + 1 entries");
+    out->job_label_off.push_back(0u);
+    for (size_t j = rank; j < n_jobs; j += world) {
+        const uint32_t l0 = lb->job_label_off[j], l1 = lb->job_label_off[j + 1];
+        if (l0 > l1 || l1 > lb->n_labels) return fail(OSMT_INVALID_ARG, "job_label_off is not monotonic");
+        for (uint32_t l = l0; l < l1; ++l) {
+            osmt_label lab = lb->labels[l];
+            if (lab.n_segs) {
+                if ((size_t)lab.seg_off + lab.n_segs > lb->n_segs) return fail(OSMT_INVALID_ARG, "label %u: segment range out of bounds", l);
+                const uint32_t old = lab.seg_off;
+                lab.seg_off = (uint32_t)(out->segs.size() / 4);
+                out->segs.insert(out->segs.end(), lb->segs + 4 * (size_t)old, lb->segs + 4 * ((size_t)old + lab.n_segs));
+            }
+            out->labels.push_back(lab);
+        }
+        out->job_label_off.push_back((uint32_t)out->labels.size());
+    }
+    out->b.labels = out->labels.data();
+    out->b.n_labels = out->labels.size();
+    out->b.job_label_off = out->job_label_off.data();
+    out->b.segs = out->segs.empty() ? nullptr : out->segs.data();
+    out->b.n_segs = out->segs.size() / 4;
+    return OSMT_OK;
+}
+
+static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, const osmt_label_batch* labels, uint32_t flags,
+                                   uint8_t* out, size_t stride, uint64_t* out_count) {
     if (!ctxs || n == 0 || !batch) return fail(OSMT_INVALID_ARG, "NULL argument");
     for (uint32_t i = 0; i < n; ++i)
         if (!ctxs[i]) return fail(OSMT_INVALID_ARG, "context %u is NULL", i);
-    int rc = validate_batch(batch);
+    if (flags & ~(uint32_t)OSMT_MULTI_RGB8) return fail(OSMT_INVALID_ARG, "unknown flags 0x%x", flags);
+    const bool rgb = (flags & OSMT_MULTI_RGB8) != 0;
+    int rc = validate_batch(batch); /* ONCE for the whole call: the shards are built from it and trusted */
     if (rc != OSMT_OK) return rc;
     if (batch->n_jobs && !out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
     const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
-    if (stride < W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    if (stride < W * W * (rgb ? 3 : 4)) return fail(OSMT_INVALID_ARG, rgb ? "out_tile_stride_bytes < W*H*3" : "out_tile_stride_bytes < W*H*4");
+    if (labels && labels->n_labels == 0) labels = nullptr;
     /* one host thread per GPU: shard, upload, kernels and read-back of the devices run side by side; shard d writes
      * tiles d, d + n, ... = base out + d * stride with a tile pitch of n * stride */
     std::vector<int> rcs(n, OSMT_OK);
     std::vector<std::string> msgs(n);
     std::vector<uint64_t> counts(n, 0);
-    std::vector<std::thread> th;
+    struct joiner { /* a failed thread start must not leave joinable threads behind (std::terminate) */
+        std::vector<std::thread> th;
+        ~joiner() {
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+        }
+    } pool;
+    pool.th.reserve(n);
     for (uint32_t d = 0; d < n; ++d) {
-        th.emplace_back([&, d] {
+        pool.th.emplace_back([&, d] {
             osmt_batch_shard* sh = nullptr;
-            int r = osmt_batch_shard_create(batch, d, n, &sh);
-            if (r == OSMT_OK && sh->b.n_jobs) r = osmt_render_batch(ctxs[d], &sh->b, out + (size_t)d * stride, (size_t)n * stride);
+            int r = guarded([&] { return shard_create_body(batch, d, n, &sh, true); });
+            label_shard ls;
+            if (r == OSMT_OK && labels) r = guarded([&] { return label_shard_build(labels, batch->n_jobs, d, n, &ls); });
+            if (r == OSMT_OK && sh->b.n_jobs)
+                r = guarded([&] {
+                    return osmt_render_batch_labels_body(ctxs[d], &sh->b, labels ? &ls.b : nullptr, out + (size_t)d * stride, (size_t)n * stride, rgb, true);
+                });
             if (r == OSMT_OK) counts[d] = sh->b.n_jobs;
             if (r != OSMT_OK) msgs[d] = osmt_last_error(); /* thread-local: carry it to the caller's thread */
             rcs[d] = r;
             osmt_batch_shard_free(sh);
         });
     }
-    for (auto& t : th) t.join();
+    for (auto& t : pool.th) t.join();
     for (uint32_t d = 0; d < n; ++d)
         if (rcs[d] != OSMT_OK) return fail(rcs[d], "GPU %u (device %d): %s", d, ctxs[d]->device, msgs[d].c_str());
     uint64_t total = 0;
@@ -1949,7 +2017,12 @@ static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt
 }
 
 int osmt_render_batch_multi(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, uint8_t* out, size_t stride, uint64_t* out_count) {
-    return guarded([&] { return render_batch_multi_body(ctxs, n, batch, out, stride, out_count); });
+    return guarded([&] { return render_batch_multi_body(ctxs, n, batch, nullptr, 0u, out, stride, out_count); });
+}
+
+int osmt_render_batch_multi_ex(osmt_ctx* const* ctxs, uint32_t n, const osmt_batch* batch, const osmt_label_batch* labels, uint32_t flags,
+                               uint8_t* out, size_t stride, uint64_t* out_count) {
+    return guarded([&] { return render_batch_multi_body(ctxs, n, batch, labels, flags, out, stride, out_count); });
 }
 
 static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy, double* out_read) {

@@ -225,6 +225,7 @@ struct osmt_prepass_args {
     const uint32_t* op_aux;   /* op -> stroke slot */
     const uint32_t* op_job;   /* op -> job */
     const uint32_t* op_blk;   /* op -> first 64-edge block bbox (0xFFFFFFFF: none) */
+    const uint32_t* op_vseg;  /* op -> its first virtual segment (stroke ops that have segments) */
     /* binning table of the stroke ops that HAVE virtual segments (edges + cap stubs), in op order */
     const uint32_t* vseg_base; /* [n_strokes + 1]: first virtual segment of every entry; last = n_vsegs */
     const uint32_t* stroke_op; /* [n_strokes]: entry -> op */
@@ -234,13 +235,14 @@ struct osmt_prepass_args {
     uint32_t scale;
     uint32_t sub_rows;
     osmt_opinfo* info;
+    /* per VIRTUAL SEGMENT (index = op_vseg[op] + running edge index), so ops that share rings do not collide */
     double* trav;
     double* den;
     double* rden;
     osmt_stroke_aux* aux;
     osmt_blk_bbox* blk;
     uint32_t* submask;
-    uint32_t* cand_off; /* per point: first slot (relative to the op) of the window of the edge that starts there */
+    uint32_t* cand_off; /* per virtual segment: first slot (relative to the op) of the edge's sub-tile window */
     unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records); zeroed by the launcher */
     uint32_t* fmask;
     osmt_srec* srec;

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     uint32_t seen = 0; /* running edge index + 1 over all rings (point_pairs.rs:36-40) */
     /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
     const uint32_t blk_off = a.op_blk[o];
+    const uint32_t vbase = a.op_vseg[o];
     uint32_t cur_blk = 0xFFFFFFFFu;
     osmt_blk_bbox bb = {INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN};
     /* ONE pass over the points.  A thread walks its op alone, so what it waits for is the latency of its own loads:
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     /* |p2 - p1| is both the traveled increment (line.rs:31) and center_dist_denom
                      * (line.rs:104: sqrt(dy*dy + dx*dx) of the absolute deltas — the same f64) */
                     const double len = point_dist(prev.x, prev.y, p.x, p.y);
-                    const uint32_t e = ring.first_pt + i - 1u;
+                    const uint32_t e = vbase + seen - 1u; /* the edge's virtual segment: private to this op even when rings are shared */
+                    a.trav[e] = traveled; /* traveled BEFORE this edge */
                     a.den[e] = len;
                     a.rden[e] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
                     traveled += len;
@@ -277,7 +279,6 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     }
                 }
             }
-            if (is_stroke) a.trav[ring.first_pt + i] = traveled; /* traveled before the edge that STARTS at point i */
             prev = p;
         }
     }
@@ -870,10 +871,10 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
         const int2 p1 = g_pts[ring.first_pt + e];
         const int2 p2 = g_pts[ring.first_pt + e + 1];
         rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
-        rec.traveled = g_trav[ring.first_pt + e];
-        rec.denom = g_den[ring.first_pt + e];
-        rec.rdenom = g_rden[ring.first_pt + e];
-        cand_off = g_cand_off[ring.first_pt + e];
+        rec.traveled = g_trav[g]; /* per virtual segment (k_opinfo) */
+        rec.denom = g_den[g];
+        rec.rdenom = g_rden[g];
+        cand_off = g_cand_off[g];
     } else {
         const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
         if (!cs.valid) return;

@@ -23,6 +23,7 @@ EXPORTS = [
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_render_batch_rgb", "osmt_scene_set_labels", "osmt_scene_read_label_status",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
     "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
+    "osmt_render_batch_multi_ex",
     "osmt_comm_unique_id", "osmt_comm_init_rank", "osmt_comm_init_local", "osmt_allreduce_tile_count",
     "osmt_allreduce_tile_count_local", "osmt_allreduce_tile_count_enqueue", "osmt_allreduce_tile_count_result", "osmt_hbm_copy_probe",
 ]
@@ -61,6 +62,8 @@ def load():
     L.osmt_batch_shard_free.argtypes = [vp]
     L.osmt_batch_shard_free.restype = None
     L.osmt_render_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(abi.Batch), u8p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.osmt_render_batch_multi_ex.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), C.c_uint32, u8p,
+                                             C.c_size_t, C.POINTER(C.c_uint64)]
     L.osmt_comm_unique_id.argtypes = [u8p]
     L.osmt_comm_init_rank.argtypes = [vp, u8p, C.c_uint32, C.c_uint32]
     L.osmt_comm_init_local.argtypes = [C.POINTER(vp), C.c_uint32]

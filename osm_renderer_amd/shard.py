@@ -45,15 +45,24 @@ def shard_display_list(dl: DisplayList, rank, world) -> DisplayList:
         L.osmt_batch_shard_free(h)
 
 
-def render_batch_multi(contexts, dl: DisplayList, out=None):
-    """osmt_render_batch_multi over `contexts` (one per GPU): (RGBA8 [n, H, W, 4], all-reduced tile count)."""
+def render_batch_multi(contexts, dl: DisplayList, out=None, labels=None, rgb=False):
+    """osmt_render_batch_multi[_ex] over `contexts` (one per GPU): (RGBA8 [n, H, W, 4] — or packed RGB8 [n, H*W*3] with
+    rgb=True —, all-reduced tile count).  `labels`: a LabelList for the whole batch, sliced per shard by the library."""
+    shape = (dl.n_jobs, dl.dim * dl.dim * 3) if rgb else (dl.n_jobs, dl.dim, dl.dim, 4)
     if out is None:
-        out = np.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=np.uint8)
-    assert out.shape == (dl.n_jobs, dl.dim, dl.dim, 4) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+        out = np.empty(shape, dtype=np.uint8)
+    assert out.shape == shape and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
     b = dl.as_batch()
     hs = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     cnt = C.c_uint64(0)
-    check(load().osmt_render_batch_multi(hs, len(contexts), C.byref(b), out.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 4, C.byref(cnt)))
+    outp = out.ctypes.data_as(C.POINTER(C.c_uint8))
+    stride = dl.dim * dl.dim * (3 if rgb else 4)
+    if labels is None and not rgb:
+        check(load().osmt_render_batch_multi(hs, len(contexts), C.byref(b), outp, stride, C.byref(cnt)))
+    else:
+        lb = labels.as_batch() if labels is not None else None
+        check(load().osmt_render_batch_multi_ex(hs, len(contexts), C.byref(b), C.byref(lb) if lb is not None else None,
+                                                abi.MULTI_RGB8 if rgb else 0, outp, stride, C.byref(cnt)))
     return out, int(cnt.value)
 
 

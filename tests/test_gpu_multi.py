@@ -5,6 +5,7 @@ import torch
 
 from osm_renderer_amd import abi, shard, synth
 from osm_renderer_amd.lib import OsmtError
+from osm_renderer_amd.lib import load as load_lib
 from osm_renderer_amd.renderer import Context
 
 pytestmark = pytest.mark.gpu
@@ -100,3 +101,75 @@ def test_comm_errors(gpu_ctx):
 def test_hbm_copy_probe(gpu_ctx):
     cp, rd = gpu_ctx.hbm_copy_probe(1 << 28, 5)
     assert 500.0 < cp < 8000.0 and 500.0 < rd < 8000.0, (cp, rd)
+
+
+def _contexts_for_all_devices(gpu_ctx, at_least=2):
+    """One context per visible GPU (the driver's multi-GPU tier); on a one-GPU box several contexts on device 0, so
+    the sharding / interleaved-slice code of osmt_render_batch_multi still runs with n > 1."""
+    n = torch.cuda.device_count()
+    if n >= 2:
+        return [gpu_ctx] + [Context(d) for d in range(1, n)], True
+    return [gpu_ctx] + [Context(0) for _ in range(at_least - 1)], False
+
+
+def test_config4_batch_of_10000_tiles_round_robin(gpu_ctx, oracle):
+    """BASELINE configs[3]: the 10 000-tile z=15 batch (x = 19000 + i mod 100, y = 10000 + i / 100), tile i -> GPU
+    i mod G through osmt_render_batch_multi over every visible device (http_server.rs:50-83,105-108 deals tiles to its
+    workers the same way).  Count = 10 000 (RCCL all-reduce when the devices are distinct), the run is deterministic,
+    a 32-tile sample equals the oracle, and no tile of the one buffer is left unwritten."""
+    n_tiles = 10000
+    dl = synth.make_tiles(synth.config_tiles(n_tiles), zoom=15, scale=1, n_poly=50, n_line=40)
+    assert dl.n_jobs == n_tiles
+    ctxs, distinct = _contexts_for_all_devices(gpu_ctx, at_least=3)
+    pin = gpu_ctx.host_alloc((n_tiles, dl.dim, dl.dim, 4))
+    try:
+        if distinct:
+            shard.comm_init_local(ctxs)
+        pin[:] = 0  # A = 255 everywhere after a complete render
+        got, cnt = shard.render_batch_multi(ctxs, dl, out=pin)
+        assert cnt == n_tiles
+        assert (got[:, 0, 0, 3] == 255).all() and (got[:, -1, -1, 3] == 255).all(), "a tile slice was never written"
+        rng = np.random.default_rng(4)
+        pick = sorted(set([0, 1, len(ctxs), n_tiles - 1] + rng.integers(0, n_tiles, size=28).tolist()))
+        np.testing.assert_array_equal(got[pick], oracle.render_batch(dl.subset(pick), threads=8))
+        # determinism: a per-tile checksum of the whole batch, twice
+        def checksum(a):
+            return a.reshape(n_tiles, -1).astype(np.uint64)[:, ::7].sum(axis=1)
+        c1 = checksum(got)
+        pin[:] = 0
+        got2, cnt2 = shard.render_batch_multi(ctxs, dl, out=pin)
+        assert cnt2 == n_tiles
+        np.testing.assert_array_equal(checksum(got2), c1)
+    finally:
+        gpu_ctx.host_free(pin)
+        for c in ctxs[1:]:
+            c.close()
+
+
+def test_render_batch_multi_ex_labels_and_rgb8(gpu_ctx, oracle):
+    """osmt_render_batch_multi_ex: the label pass of every tile travels with its shard (drawer.rs:107-125), and the
+    RGB8 flag gives the packed triples of osmt_render_batch_rgb."""
+    from osm_renderer_amd import labels as labels_mod
+
+    dl = synth.make_tiles(synth.config_tiles(11), n_poly=10, n_line=8)
+    ll = labels_mod.make_labels(11, labels_per_tile=9, seed=12)
+    ctxs, _ = _contexts_for_all_devices(gpu_ctx, at_least=3)
+    try:
+        want = oracle.render_batch(dl, labels=ll, threads=8)
+        got, cnt = shard.render_batch_multi(ctxs, dl, labels=ll)
+        assert cnt == 11
+        np.testing.assert_array_equal(got, want)
+        rgb, cnt = shard.render_batch_multi(ctxs, dl, labels=ll, rgb=True)
+        assert cnt == 11
+        np.testing.assert_array_equal(rgb.reshape(11, dl.dim, dl.dim, 3), want[..., :3])
+        plain, _ = shard.render_batch_multi(ctxs, dl, rgb=True)  # no labels, RGB8
+        np.testing.assert_array_equal(plain.reshape(11, dl.dim, dl.dim, 3), oracle.render_batch(dl, threads=8)[..., :3])
+        import ctypes as C
+
+        hs = (C.c_void_p * 1)(gpu_ctx._h)
+        b = dl.as_batch()
+        rc = load_lib().osmt_render_batch_multi_ex(hs, 1, C.byref(b), None, 0x80, plain.ctypes.data_as(C.POINTER(C.c_uint8)), dl.dim * dl.dim * 3, None)
+        assert rc == abi.INVALID_ARG  # unknown flag
+    finally:
+        for c in ctxs[1:]:
+            c.close()

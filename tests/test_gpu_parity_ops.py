@@ -306,3 +306,29 @@ def test_long_ways_and_multipolygons_use_the_block_path(gpu_ctx, oracle):
     tb2.fill([[(x * 2 - 300, y * 2 + 40) for x, y in ring_a]], (250, 200, 10), 0.5)
     assert_parity(gpu_ctx, oracle, dl1, msg="long ops")
     assert_parity(gpu_ctx, oracle, tb2.build(), msg="long ops @2x")
+
+
+def test_two_stroke_ops_share_one_ring(gpu_ctx, oracle):
+    """A casing and its stroke drawn from the SAME ring (what a host that does not duplicate a way's points per pass
+    emits; drawer.rs:186-215 draws both passes from one entity): the per-edge tables of the pre-pass are keyed by
+    (op, edge), not by point, so the two ops' sub-tile windows (which depend on each op's width) do not collide."""
+    tb = TileBuilder(canvas=(250, 250, 240))
+    way = [(20, 30), (90, 60), (150, 40), (200, 120), (120, 200), (40, 170)]
+    tb.fill([(10, 10), (240, 20), (230, 240), (20, 230), (10, 10)], (200, 220, 200), 0.8)
+    tb.stroke(way, 11.0, (90, 60, 30), 1.0, cap=abi.CAP_ROUND)                       # casing
+    tb.stroke(way, 6.0, (250, 240, 120), 0.9, dashes=[9.0, 5.0], cap=abi.CAP_BUTT)   # stroke, other width, dashed
+    tb.stroke(way, 1.0, (0, 0, 0), 0.5)                                              # centre line
+    dl = tb.build()
+    ring_of_casing = int(dl.ops["ring_off"][1])
+    dl.ops["ring_off"][2] = ring_of_casing  # share: ops 2 and 3 now reference the casing's ring
+    dl.ops["ring_off"][3] = ring_of_casing
+    assert_parity(gpu_ctx, oracle, dl, msg="shared ring")
+    # and a multi-ring stroke op that shares its rings with a single-ring one (traveled differs per op)
+    tb = TileBuilder(canvas=None)
+    tb.stroke(way[:3], 5.0, (255, 0, 0), 1.0, dashes=[6.0, 4.0], cap=abi.CAP_ROUND, use_caps_for_dashes=True)
+    tb.stroke(way[3:], 5.0, (0, 255, 0), 1.0, dashes=[6.0, 4.0])
+    tb.stroke(way[3:], 3.0, (0, 0, 255), 0.7, dashes=[6.0, 4.0])
+    dl = tb.build()
+    dl.ops["n_rings"][2] = 2  # op 2 = rings 0 and 1 in one draw_lines call: traveled runs on across the rings
+    dl.ops["ring_off"][2] = 0
+    assert_parity(gpu_ctx, oracle, dl, msg="shared rings, multi-ring op")
