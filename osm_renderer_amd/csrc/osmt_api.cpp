@@ -132,7 +132,12 @@ struct osmt_scene {
     uint32_t* d_vseg_blk_slot = nullptr;
     uint32_t n_bin_slots = 0;
     uint32_t* d_cand_off = nullptr;
-    unsigned long long* d_cursors = nullptr;
+    unsigned long long* d_cursors = nullptr; /* 4 words; the per-sub-tile list counts follow (one memset) */
+    uint32_t* d_cnt = nullptr;
+    uint2* d_hdr = nullptr;
+    osmt_ent* d_ent = nullptr;
+    unsigned long long ent_cap = 0;
+    uint32_t n_fill_ops = 0;
     uint32_t n_vsegs = 0;
     /* the two arenas of the pre-pass (fill coverage words, stroke records + keys): one allocation, sized at upload */
     char* d_arena = nullptr;
@@ -513,6 +518,10 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.submask = sc->d_submask;
     a.cand_off = sc->d_cand_off;
     a.cursors = sc->d_cursors;
+    a.cnt = sc->d_cnt;
+    a.hdr = sc->d_hdr;
+    a.ent = sc->d_ent;
+    a.ent_cap = sizing ? 0ull : sc->ent_cap;
     a.fmask = sc->d_fmask;
     a.srec = sc->d_srec;
     a.skey = sc->d_skey;
@@ -575,10 +584,12 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.jobs = sc->d_jobs + first_job;
         a.n_jobs = n_render;
         a.scale = sc->scale;
-        a.info = sc->d_info;
         a.aux = sc->d_aux;
-        a.submask = sc->d_submask;
-        a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
+        {
+            const uint32_t Wt = OSMT_TILE_SIZE * sc->scale;
+            a.hdr = sc->d_hdr + (size_t)first_job * (Wt / OSMT_SUB_W) * (Wt / OSMT_SUB_H);
+        }
+        a.ent = sc->d_ent;
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
@@ -673,7 +684,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     const size_t W = (size_t)OSMT_TILE_SIZE * s->scale;
     const size_t nsub = (W / OSMT_SUB_W) * (W / OSMT_SUB_H);
     unsigned long long groups = (unsigned long long)n_fills * nsub, recs = (unsigned long long)s->n_vsegs * nsub;
-    const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 8ull);
+    const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 8ull) + ((unsigned long long)n_fills + s->n_strokes) * nsub * sizeof(osmt_ent);
     if (worst_bytes > ((unsigned long long)32 << 20)) {
         hipStream_t st = s->own_stream;
         if (s->coord_kind != OSMT_COORD_POINT_I32)
@@ -694,9 +705,14 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
         off = align_up(off + bytes, 256);
         return o;
     };
+    /* list entries: one per (op, sub-tile the op draws into) — at most one per fill group / stroke slot, and never more
+     * than every op in every sub-tile */
+    unsigned long long ents = std::min<unsigned long long>(groups + recs, ((unsigned long long)n_fills + s->n_strokes) * nsub);
+    if (ents >= 0xFFFFFFFFull) return fail(OSMT_UNSUPPORTED, "scene needs %llu list entries (> 2^32): split the batch", ents);
     const size_t o_f = carve((size_t)(groups + 1) * 64);
     const size_t o_r = carve((size_t)(recs + 1) * sizeof(osmt_srec));
     const size_t o_k = carve((size_t)(recs + 1) * 8);
+    const size_t o_e = carve((size_t)(ents + 1) * sizeof(osmt_ent));
     hipError_t e = dev_alloc(ctx, (void**)&s->d_arena, off + 256);
     if (e != hipSuccess) {
         s->d_arena = nullptr;
@@ -705,6 +721,8 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     s->d_fmask = (uint32_t*)(s->d_arena + o_f);
     s->d_srec = (osmt_srec*)(s->d_arena + o_r);
     s->d_skey = (uint2*)(s->d_arena + o_k);
+    s->d_ent = (osmt_ent*)(s->d_arena + o_e);
+    s->ent_cap = ents + 1;
     s->fmask_cap = groups + 1; /* never 0: 0 means "sizing pass" to the kernels */
     s->srec_cap = recs + 1;
     return OSMT_OK;
@@ -832,7 +850,9 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     const size_t o_rden = carve((n_vsegs + 1) * 8);
     const size_t o_candoff = carve((n_vsegs + 1) * 4);
-    const size_t o_cursors = carve(16);
+    const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
+    const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
+    const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
     s->bytes = off + 256;
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     if (e != hipSuccess) {
@@ -865,6 +885,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->n_bin_slots = (uint32_t)stroke_op.size();
     s->d_cand_off = (uint32_t*)(s->d_base + o_candoff);
     s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
+    s->d_cnt = (uint32_t*)(s->d_base + o_cursors + 32);
+    s->d_hdr = (uint2*)(s->d_base + o_hdr);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;

@@ -22,6 +22,7 @@
 struct osmt_dash_seg {
     double start_from, start_to, end_from, end_to, opacity_mul;
     double orig_a, orig_b; /* original_endpoints (valid when table.has_orig) */
+    double r_start, r_end; /* RN(1 / (start_to - start_from)), RN(1 / (end_to - end_from)): the two ramp divisions as osmt_div_exact */
 };
 
 /* OpacityCalculator minus half_line_width/traveled (opacity_calculator.rs:3-8) */
@@ -29,6 +30,7 @@ struct osmt_dash_table {
     int32_t n_segs;
     int32_t has_orig; /* line cap is Round: original_endpoints = Some(..) */
     double total_len;
+    double r_total;   /* RN(1 / total_len): quotient estimate of the exact `dist_rem % total_len` */
     osmt_dash_seg segs[OSMT_MAX_DASH_SEGS];
 };
 
@@ -101,6 +103,22 @@ static_assert(sizeof(osmt_srec) == 64, "osmt_srec is one 64-byte line: four 16-b
 struct osmt_blk_bbox {
     int32_t x0, y0, x1, y1; /* over the end points of the block's edges (empty block: x0 > x1) */
 };
+
+/* ---- per-sub-tile display lists (k_sublist -> k_raster) -----------------------------------------------------------
+ * After the binning kernels have set the exact "op draws into sub-tile" bits, k_sublist turns them round: for every
+ * (tile, sub-tile) the ops that draw there, in display-list order (= generation order, drawer.rs:218), each with what
+ * k_raster needs to start on it resolved for THAT sub-tile.  k_raster then streams its own short list instead of
+ * scanning the op bits of the whole tile (config 5: 9000 bits for ~100 drawing ops) and never touches osmt_opinfo. */
+struct alignas(16) osmt_ent {
+    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first slot of the op */
+    uint32_t kind_color; /* kind | r << 8 | g << 16 | b << 24 */
+    double opacity;
+    uint32_t aux;        /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
+    uint32_t nv;         /* STROKE: slots of the op in the stroke arena (rec_cap) */
+    uint32_t stage;      /* k_raster's own use while the entry sits in LDS */
+    uint32_t _pad;
+};
+static_assert(sizeof(osmt_ent) == 32, "osmt_ent is two 16-byte loads");
 
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
@@ -197,10 +215,9 @@ struct osmt_raster_args {
     const osmt_tile_job* jobs;
     uint32_t n_jobs;
     uint32_t scale;
-    const osmt_opinfo* info;
     const osmt_stroke_aux* aux;
-    const uint32_t* submask; /* [n_ops][sub_rows]: bit sx of word sy = the op draws into sub-tile (sx, sy) (exact) */
-    uint32_t sub_rows;       /* W / OSMT_SUB_H */
+    const uint2* hdr;        /* [n_jobs][nsub]: (first entry, entry count) of the sub-tile's list (k_sublist) */
+    const osmt_ent* ent;     /* the lists */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
     const uint2* skey;       /* per stroke slot: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
@@ -243,7 +260,11 @@ struct osmt_prepass_args {
     osmt_blk_bbox* blk;
     uint32_t* submask;
     uint32_t* cand_off; /* per virtual segment: first slot (relative to the op) of the edge's sub-tile window */
-    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records); zeroed by the launcher */
+    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries; zeroed by the launcher */
+    uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
+    uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */
+    osmt_ent* ent;      /* list arena */
+    unsigned long long ent_cap;
     uint32_t* fmask;
     osmt_srec* srec;
     uint2* skey;

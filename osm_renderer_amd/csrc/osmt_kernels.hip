@@ -128,11 +128,14 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
         s.end_from = fmax(end - 0.5, midpoint);
         s.end_to = fmax(end + 0.5, midpoint + 1.0);
         s.opacity_mul = fmin(end - start, 1.0);
+        s.r_start = 1.0 / (s.start_to - s.start_from); /* both ramps are 1 px long up to a rounding: finite */
+        s.r_end = 1.0 / (s.end_to - s.end_from);
         t->segs[n++] = s;
     }
     t->n_segs = n;
     t->has_orig = (cap == OSMT_CAP_ROUND) ? 1 : 0;
     t->total_len = len_before;
+    t->r_total = 1.0 / len_before; /* used only when total_len > 0 */
 }
 
 /* Sub-tiles a virtual segment (an edge or a cap stub) can draw into: every pixel it sets lies within t_extra pixels
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
             sa->main.n_segs = 0;
             sa->main.has_orig = 0;
             sa->main.total_len = 0.0;
+            sa->main.r_total = 0.0;
         }
         const double zero = 0.0;
         compute_segments(hw, &zero, 1, op.cap, &sa->caps);
@@ -458,22 +462,21 @@ constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before th
 #endif
 /* One compacted list entry of a chunk: everything the sequential per-op loop needs, staged in LDS by the lane that
  * owns the op, so the loop itself never waits for global memory. */
-struct OpEntry {
-    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first slot of the op */
-    uint32_t kind_color; /* kind | r << 8 | g << 16 | b << 24 */
-    double opacity;
-    uint32_t aux;        /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
-    uint8_t nv;          /* STROKE: slots of the op, 255 = more than 64 (own filter passes); 0: a fill */
-    uint8_t stage;       /* FILL: index of the staged coverage words; STROKE: index of the staged constants; 255: not staged */
-    uint8_t _pad[2];
-};
-static_assert(sizeof(OpEntry) == 24, "OpEntry layout");
+typedef osmt_ent OpEntry; /* as k_sublist wrote it; .stage = FILL: index of the staged coverage words; STROKE: index of the staged
+                           * constants; 255: not staged */
 /* per-op constants of the un-dashed / cap_dist == 0 across test (osmt_stroke_aux), staged with the entry */
 struct StrokeConst {
     double ff0, ft0, fd0, rfd0, mul0;
-    uint32_t plain_main; /* the main calculator has no dash segments */
+    uint32_t flags; /* STROKE_* */
     uint32_t _pad;
 };
+constexpr uint32_t STROKE_PLAIN_MAIN = 1u; /* the main calculator has no dash segments */
+constexpr uint32_t STROKE_UNIT_FD = 2u;    /* feather_dist == 1.0 exactly */
+constexpr uint32_t STROKE_TINY_MUL = 4u;   /* opacity_mul below 1e-100 (or NaN): no shortcut may assume mul0 * v > 0 */
+__device__ __forceinline__ uint32_t stroke_flags(const osmt_stroke_aux* __restrict__ sa) {
+    return (sa->main.n_segs == 0 ? STROKE_PLAIN_MAIN : 0u) | (sa->fd0 == 1.0 ? STROKE_UNIT_FD : 0u) |
+           (sa->mul0 >= 1e-100 ? 0u : STROKE_TINY_MUL);
+}
 #ifndef OSMT_V_STAGECAP
 #define OSMT_V_STAGECAP 8
 #endif
@@ -488,6 +491,7 @@ struct RasterShared {
     OpEntry ent[OPCHUNK];           /* ops of the chunk that draw into this sub-tile, in order */
     uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
     StrokeConst sconst[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
+    uint32_t farena[STAGECAP];      /* first coverage word of the staged fills */
     uint8_t grp_base[OPCHUNK + 1];  /* first record lane of every list entry of a group */
     uint8_t s_ent[OPCHUNK];         /* group-local index of the k-th STROKE entry of the group */
 #ifdef OSMT_V_LDSPAD
@@ -515,104 +519,213 @@ __device__ __forceinline__ void blend_rgb(double* acc, double sr, double sg, dou
     acc[2] = sb + k * acc[2];
 }
 
-/* One perpendicular run (line.rs:108-137).  PLAIN = the calculator has no dash segments
- * (get_opacity_by_start_distance returns (1.0, None) without looking at the distance,
- * opacity_calculator.rs:50-55), so long_start_dist / short_start_dist are dead values and
- * the feather terms are the per-op constants of osmt_stroke_aux. */
-__device__ __forceinline__ void walk_perpendicular(const bool PLAIN, const osmt_seg& s, const StrokeConst& kc,
-                                                   const osmt_stroke_aux* __restrict__ sa,
-                                                   const osmt_dash_table* __restrict__ tab, double traveled,
-                                                   double initial_opacity, int32_t mn, int32_t mx, int32_t p_error,
-                                                   int32_t mul, const SubRect& rc,
-                                                   unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
-    int32_t p_mn = mx;
-    int32_t p_mx = mn;
-    int32_t err = mul * p_error;
-    const int32_t two_a = 2 * s.a, two_b = 2 * s.b;
-    int32_t px = s.swap ? p_mn : p_mx;
-    int32_t py = s.swap ? p_mx : p_mn;
-    /* center_dist_raw (line.rs:116-117) kept incrementally: exact int64 arithmetic */
-    int64_t raw = s.numer_const + ((int64_t)s.sdy * (int64_t)px - (int64_t)s.sdx * (int64_t)py);
-    const int32_t step_mx = mul * s.mn_inc;  /* p_mx += */
-    const int32_t step_mn = -mul * s.mx_inc; /* p_mn += (when corrected) */
-    const int64_t raw_step = (int64_t)(s.swap ? -s.sdx * step_mx : s.sdy * step_mx); /* steps are +-1: 32-bit products */
-    const int64_t raw_corr = (int64_t)(s.swap ? s.sdy * step_mn : -s.sdx * step_mn);
-    const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
-    for (;;) {
-        OSMT_DBG(++dbg_iters;)
-        const double cd = osmt_div_exact(fabs((double)raw), s.denom, s.rdenom); /* == fabs(raw) / denom (line.rs:116-118) */
-        double op;
-        bool in_line;
-        if (PLAIN) {
-            /* opacity_calculator.rs:171-185 with half_line_width = sqrt(h*h - 0*0); branch-free: the feather
-             * quotient (ft0 - cd) / fd0 is taken exactly from the pre-computed reciprocal and selected afterwards */
-            const double q = osmt_div_exact(ft0 - cd, fd0, rfd0);
-            double v = cd < ff0 ? 1.0 : q;
-            v = cd < ft0 ? v : 0.0;
-            const double cdop = mul0 * v;
-            op = fmin(1.0, cdop);
-            in_line = cdop > 0.0;
-        } else {
-            const double ld = point_dist(px, py, s.p1x, s.p1y);
-            const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));
-            in_line = opacity_calculate(tab, sa, traveled, cd, sd, &op);
-        }
-        if (!in_line) break;
-        if ((uint32_t)(px - rc.x0) < (uint32_t)SUB && (uint32_t)(py - rc.y0) < (uint32_t)SUBH) {
-            const double alpha = initial_opacity * op;
-            /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118);
-             * alpha >= +0, so the u64 order of the bit pattern is the f64 order */
-            atomicMax(&plane[(py - rc.y0) * PLANE_STRIDE + (px - rc.x0)], (unsigned long long)__double_as_longlong(alpha));
-            OSMT_DBG(++dbg_set;)
-        }
-        /* update_error (line.rs:91-100) */
-        if (err + two_a > s.b) {
-            err -= two_b;
-            if (s.swap) px += step_mn; else py += step_mn;
-            raw += raw_corr;
-        }
-        err += two_a;
-        if (s.swap) py += step_mx; else px += step_mx;
-        raw += raw_step;
-    }
-}
+/* ---- perpendicular runs (line.rs:108-137) --------------------------------------------------------------------------
+ * State of one run, set up from a record and an item index (walk_setup): the pixel in sub-tile coordinates, the error
+ * term, and center_dist_raw (line.rs:116-117) as an f64 that is updated by ADDITIONS only.  That is exact: raw is an
+ * integer, a run starts within ~2 px of the ideal line (|raw| < 2^33) and continues only while the pixel is in the
+ * line (|raw| < feather_to * len < 2^47), so every value the additions produce is an integer below 2^53 — the same
+ * number the reference converts from its i64 for every pixel. */
+struct RunState {
+    int32_t rx, ry;         /* pixel - sub-tile origin */
+    int32_t err;            /* perpendicular error term (line.rs:111,128-131) */
+    int32_t sx, sy, cx, cy; /* pixel step of every iteration / extra step of a correction */
+    int32_t two_a, two_b, b;
+    double raw, raw_step, raw_corr;
+    double denom, rdenom;
+    int32_t d1x, d1y;       /* pixel - p1 (dashed runs: dist(pixel, p1), line.rs:119) */
+};
 
-/* One item of a segment record = one perpendicular run (line.rs:108-137): items [0, k_n0 + k_n1)
- * are the main perpendiculars of steps on side +1 then -1, the rest are the extra perpendiculars
- * of line.rs:152-154, located directly by osmt_extra_event. */
-template <bool PLAIN>
-__device__ __forceinline__ void walk_item(const osmt_srec& r, uint32_t local, const bool use_caps, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
-                                          double initial_opacity, const SubRect& rc,
-                                          unsigned long long* __restrict__ plane OSMT_DBG(, uint32_t& dbg_iters, uint32_t& dbg_set)) {
-    osmt_seg s;
-    osmt_seg_setup(&s, r.p1x, r.p1y, r.p2x, r.p2y, r.denom, r.rdenom);
-    const uint32_t n_main = (uint32_t)(r.k_n0 + r.k_n1);
+/* One item of a segment record = one perpendicular run: items [0, k_n0 + k_n1) are the main perpendiculars of steps on
+ * side +1 then -1, the rest the extra perpendiculars of line.rs:152-154, located directly by osmt_extra_event.
+ * *skip_first: the run is the -1 side of a MAIN step — its first pixel is the Bresenham centre the +1 side of the
+ * same step starts on as well (line.rs:139-141 calls both from the same point); see walk_plain. */
+__device__ __forceinline__ void walk_setup(RunState& st, const osmt_srec& r, uint32_t local, const SubRect& rc, bool* skip_first) {
+    const int32_t dxs = r.p2x - r.p1x, dys = r.p2y - r.p1y; /* sdx, sdy (line.rs:102-103) */
+    const int32_t adx = abs(dxs), ady = abs(dys);
+    const bool swap = adx > ady; /* x is the major axis */
+    const int32_t a = swap ? ady : adx, b = swap ? adx : ady;
+    const int32_t incx = r.p1x <= r.p2x ? 1 : -1, incy = r.p1y <= r.p2y ? 1 : -1;
+    const int32_t mn_inc = swap ? incy : incx, mx_inc = swap ? incx : incy;
+    const uint32_t n_main = (uint32_t)r.k_n0 + (uint32_t)r.k_n1;
     int32_t k, c, pe, mul;
     if (local < n_main) {
         const bool side1 = local >= (uint32_t)r.k_n0;
         k = side1 ? r.k_lo1 + (int32_t)(local - (uint32_t)r.k_n0) : r.k_lo0 + (int32_t)local;
         mul = side1 ? -1 : 1;
-        osmt_stroke_main(s.a, s.b, k, &c, &pe);
+        *skip_first = side1;
+        osmt_stroke_main(a, b, k, &c, &pe);
     } else {
         const uint32_t x = local - n_main;
         const bool side1 = x >= (uint32_t)r.n_x0;
         const int32_t m = side1 ? r.m_lo1 + (int32_t)(x - (uint32_t)r.n_x0) : r.m_lo0 + (int32_t)x;
         mul = side1 ? -1 : 1;
-        osmt_extra_event(s.a, s.b, m, &c, &k, &pe);
+        *skip_first = false;
+        osmt_extra_event(a, b, m, &c, &k, &pe);
     }
-    const int32_t mx = s.mx0 + k * s.mx_inc;
-    const int32_t mn = s.mn0 + c * s.mn_inc;
-    /* seg_ranges only lists runs whose start lies within reach of the sub-tile on both axes */
-    walk_perpendicular(PLAIN, s, kc, sa, use_caps ? &sa->caps : &sa->main, r.traveled, initial_opacity, mn, mx, pe, mul, rc, plane OSMT_DBG(, dbg_iters, dbg_set));
+    /* start (p_mn, p_mx) = (mx, mn) of the main loop (line.rs:109-110), un-swapped (line.rs:113) */
+    const int32_t mxo = k * mx_inc, mno = c * mn_inc; /* offsets from p1 along the major / minor axis */
+    st.d1x = swap ? mxo : mno;
+    st.d1y = swap ? mno : mxo;
+    st.rx = r.p1x + st.d1x - rc.x0;
+    st.ry = r.p1y + st.d1y - rc.y0;
+    st.err = mul * pe;
+    const int32_t step_mx = mul * mn_inc;  /* p_mx += (every iteration): moves the pixel along the MINOR axis of the segment */
+    const int32_t step_mn = -mul * mx_inc; /* p_mn -= mul * mx_inc (when corrected): along the major axis */
+    st.sx = swap ? 0 : step_mx;
+    st.sy = swap ? step_mx : 0;
+    st.cx = swap ? step_mn : 0;
+    st.cy = swap ? 0 : step_mn;
+    st.two_a = 2 * a;
+    st.two_b = 2 * b;
+    st.b = b;
+    /* raw = numer_const + sdy*px - sdx*py (line.rs:116-117) = sdy*(px - p1x) - sdx*(py - p1y): the constant cancels at p1 */
+    const int64_t raw0 = (int64_t)dys * (int64_t)st.d1x - (int64_t)dxs * (int64_t)st.d1y;
+    st.raw = (double)raw0;
+    st.raw_step = (double)(dys * st.sx - dxs * st.sy); /* steps are 0 / +-1: 32-bit products */
+    st.raw_corr = (double)(dys * st.cx - dxs * st.cy);
+    st.denom = r.denom;
+    st.rdenom = r.rdenom;
+}
+
+/* update_error (line.rs:91-100) + the pixel move of one iteration (line.rs:128-134) */
+__device__ __forceinline__ void walk_advance(RunState& st) {
+    const bool corr = st.err + st.two_a > st.b;
+    st.err += st.two_a - (corr ? st.two_b : 0);
+    st.rx += st.sx + (corr ? st.cx : 0);
+    st.ry += st.sy + (corr ? st.cy : 0);
+    st.d1x += st.sx + (corr ? st.cx : 0);
+    st.d1y += st.sy + (corr ? st.cy : 0);
+    st.raw += corr ? st.raw_step + st.raw_corr : st.raw_step; /* integers below 2^53: exact in either order */
+}
+
+__device__ __forceinline__ void plane_max(unsigned long long* __restrict__ plane, const RunState& st, double alpha) {
+    /* set_pixel inside one generation keeps the larger alpha (tile_pixels.rs:114-118); alpha >= +0, so the u64 order of
+     * the bit pattern is the f64 order */
+    if ((((uint32_t)st.rx & ~(uint32_t)(SUB - 1)) | ((uint32_t)st.ry & ~(uint32_t)(SUBH - 1))) == 0u)
+        atomicMax(&plane[st.ry * PLANE_STRIDE + st.rx], (unsigned long long)__double_as_longlong(alpha));
+}
+
+/* A run of a calculator WITHOUT dash segments (get_opacity_by_start_distance returns (1.0, None) without looking at
+ * the distance, opacity_calculator.rs:50-55): half_line_width = sqrt(h*h - 0*0) and the feather terms are the per-op
+ * constants of osmt_stroke_aux.  With mul0 > 0 (the caller skips ops whose mul0 is not comfortably positive):
+ *   is_in_line = cdop > 0  <=>  cd < feather_to   (cd < ft0 makes (ft0 - cd) / fd0 > 0, times mul0 > 0);
+ *   opacity = min(1.0, cdop) = cdop               (v <= 1: fl(ft0 - cd) <= fl(ft0 - ff0) = fd0 for cd >= ff0; mul0 <= 1).
+ * UNIT_FD: feather_dist == 1.0 exactly (every width whose +-0.5 is exact): x / 1.0 == x.
+ * skip_first: the -1 side of a main step starts on the centre pixel the +1 side has just set to the same alpha
+ * (max-alpha: a no-op), and that pixel is ALWAYS in the line — it lies within half a pixel of the ideal line along
+ * the minor axis, i.e. at distance <= 0.5 < 1.0 <= feather_to — so the run goes on from it without evaluating it.
+ * osmt_seg_ranges lists the +1 run of a step for every sub-tile its start can touch, so the centre pixel is never lost. */
+template <bool UNIT_FD>
+__device__ __forceinline__ void walk_plain(RunState& st, const StrokeConst& kc, double initial_opacity, bool skip_first,
+                                           unsigned long long* __restrict__ plane) {
+    const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
+    if (!UNIT_FD && (kc.flags & STROKE_TINY_MUL)) {
+        /* opacity_mul so small (|width| < 1e-100) that mul0 * v may underflow to 0: the literal rule, no shortcuts (cold) */
+        for (;;) {
+            const double cd = osmt_div_exact(fabs(st.raw), st.denom, st.rdenom);
+            const double cdop = mul0 * (cd < ff0 ? 1.0 : (cd < ft0 ? (ft0 - cd) / fd0 : 0.0));
+            if (!(cdop > 0.0)) break;
+            plane_max(plane, st, initial_opacity * fmin(1.0, cdop));
+            walk_advance(st);
+        }
+        return;
+    }
+    if (skip_first) walk_advance(st);
+    for (;;) {
+        const double cd = osmt_div_exact(fabs(st.raw), st.denom, st.rdenom); /* == fabs(raw) / denom (line.rs:116-118) */
+        if (!(cd < ft0)) break;
+        const double num = ft0 - cd;
+        const double q = UNIT_FD ? num : osmt_div_exact(num, fd0, rfd0);
+        const double cdop = mul0 * (cd < ff0 ? 1.0 : q);
+        plane_max(plane, st, initial_opacity * cdop);
+        walk_advance(st);
+    }
+}
+
+/* A run of a calculator WITH dash segments — a dashed edge, or a cap stub (opacity_calculator_for_outer_caps,
+ * line.rs:22) — opacity_calculator.rs:32-80 in full.  `t` is wave-uniform (edges and stubs are walked in separate
+ * passes), so the table is read with scalar loads. */
+__device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc, const osmt_dash_table* __restrict__ t,
+                                            double half_width, double traveled, double initial_opacity,
+                                            unsigned long long* __restrict__ plane) {
+    const int n = t->n_segs;
+    const bool has_orig = t->has_orig != 0;
+    const double total = t->total_len, r_total = t->r_total;
+    const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
+    for (;;) {
+        const double cd = osmt_div_exact(fabs(st.raw), st.denom, st.rdenom);
+        /* without original_endpoints cap_dist is 0 for every pixel: the across test is the per-op one, and a pixel
+         * beyond feather_to ends the run before any of the along-the-line arithmetic */
+        if (!has_orig && !(cd < ft0)) break;
+        const double ddx = (double)st.d1x, ddy = (double)st.d1y;
+        const double ld = sqrt(ddx * ddx + ddy * ddy);          /* dist(pixel, p1), line.rs:119 */
+        const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0));    /* line.rs:120 */
+        double dist_rem = traveled + sd;
+        if (total > 0.0) { /* dist_rem >= 0: exact `%` (opacity_calculator.rs:57-60), quotient estimated with RN(1 / total) */
+            double nq = trunc(dist_rem * r_total);
+            double rr = fma(-nq, total, dist_rem);
+            if (rr < 0.0) {
+                nq -= 1.0;
+                rr = fma(-nq, total, dist_rem);
+            } else if (rr >= total) {
+                nq += 1.0;
+                rr = fma(-nq, total, dist_rem);
+            }
+            dist_rem = rr;
+        }
+        double sd_op = 0.0, dic = 0.0;
+        bool has = false;
+        for (int i = 0; i < n; ++i) {
+            const osmt_dash_seg* __restrict__ s = &t->segs[i];
+            if (dist_rem < s->start_from || dist_rem > s->end_to) continue; /* :145-157 */
+            double base;
+            if (dist_rem <= s->start_to) {
+                const double d = s->start_to - s->start_from, x = dist_rem - s->start_from;
+                base = d == 1.0 ? x : osmt_div_exact(x, d, s->r_start);
+            } else if (dist_rem < s->end_from) {
+                base = 1.0;
+            } else {
+                const double d = s->end_to - s->end_from, x = s->end_to - dist_rem;
+                base = d == 1.0 ? x : osmt_div_exact(x, d, s->r_end);
+            }
+            sd_op = fmax(sd_op, s->opacity_mul * base);
+            if (has_orig) { /* :159-169 */
+                const double dd = dist_rem < s->orig_a ? s->orig_a - dist_rem : (dist_rem <= s->orig_b ? 0.0 : dist_rem - s->orig_b);
+                if (!has || dd < dic) {
+                    has = true;
+                    dic = dd;
+                }
+            }
+        }
+        const double cap_dist = has ? dic : 0.0;
+        double cdop;
+        if (cap_dist == 0.0) {
+            const double num = ft0 - cd;
+            const double q = fd0 == 1.0 ? num : osmt_div_exact(num, fd0, rfd0);
+            const double v = cd < ff0 ? 1.0 : (cd < ft0 ? q : 0.0);
+            cdop = mul0 * v;
+        } else {
+            cdop = opacity_by_center_distance(cd, sqrt(half_width * half_width - cap_dist * cap_dist));
+        }
+        if (!(cdop > 0.0)) break;
+        plane_max(plane, st, initial_opacity * fmin(sd_op, cdop));
+        walk_advance(st);
+    }
 }
 
 /* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of one op, lanes packed: the record of item
- * `it` is the first slot whose inclusive item prefix exceeds it (bisection over the LDS prefix).  PLAIN: every one
- * of these records belongs to an un-dashed edge (no start-distance terms, per-op feather constants). */
-template <bool PLAIN, class Shared>
+ * `it` is the first slot whose inclusive item prefix exceeds it (bisection over the LDS prefix).  MODE 0 / 1: records
+ * of un-dashed edges (feather_dist == 1.0 / any); MODE 2: `tab` is the calculator of these records. */
+template <int MODE, class Shared>
 __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t slot0, uint32_t nslot, uint32_t item_base,
-                                           uint32_t it_lo, uint32_t it_hi, const StrokeConst& kc, const osmt_stroke_aux* __restrict__ sa,
-                                           double initial_opacity, const SubRect& rc) {
+                                           uint32_t it_lo, uint32_t it_hi, const StrokeConst& kc, const osmt_dash_table* __restrict__ tab,
+                                           double half_width, double initial_opacity, const SubRect& rc) {
+#if defined(OSMT_ABL) && OSMT_ABL == 7
+    if (MODE == 2) return; /* ablation: dashed / cap-stub runs are not walked */
+#endif
+#if defined(OSMT_ABL) && OSMT_ABL == 8
+    if (MODE != 2) return; /* ablation: plain runs are not walked */
+#endif
     for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
         uint32_t lo_s = slot0, n = nslot;
         while (n > 1u) {
@@ -622,14 +735,17 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
             n = right ? n - half : half;
         }
         const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
-        OSMT_DBG(uint32_t dbg_iters = 0, dbg_set = 0;)
-        walk_item<PLAIN>(sh.seg[lo_s], it - base_items, !PLAIN && sh.seg_cap[lo_s] != 0u, kc, sa, initial_opacity, rc, sh.plane OSMT_DBG(, dbg_iters, dbg_set));
-        OSMT_DBG(atomicAdd(&sh.dbg[2], 1u); atomicAdd(&sh.dbg[3], dbg_iters); atomicAdd(&sh.dbg[6], dbg_set); atomicMax(&sh.dbg[7], dbg_iters);)
+        const osmt_srec& r = sh.seg[lo_s];
+        RunState st;
+        bool skip_first;
+        walk_setup(st, r, it - base_items, rc, &skip_first);
+        if (MODE == 0)
+            walk_plain<true>(st, kc, initial_opacity, skip_first, sh.plane);
+        else if (MODE == 1)
+            walk_plain<false>(st, kc, initial_opacity, skip_first, sh.plane);
+        else
+            walk_dashed(st, kc, tab, half_width, r.traveled, initial_opacity, sh.plane);
     }
-    OSMT_DBG(for (uint32_t it0 = it_lo; it0 < it_hi; it0 += 64u) {
-        __syncthreads();
-        if (lane == 0) { sh.dbg[1] += 1u; }
-    })
 }
 
 /* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
@@ -721,7 +837,8 @@ __device__ __forceinline__ void fill_rows_body(FillRowsShared& sh, const uint32_
                                                const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
                                                const int2* __restrict__ g_pts, const uint32_t* __restrict__ g_op_blk,
                                                const osmt_blk_bbox* __restrict__ g_blk, uint32_t* __restrict__ g_submask,
-                                               uint32_t sub_rows, uint32_t* __restrict__ g_fmask) {
+                                               uint32_t sub_rows, uint32_t* __restrict__ g_fmask, uint32_t* __restrict__ g_cnt_tile,
+                                               uint32_t n_sub_x) {
     const osmt_opinfo* __restrict__ oi = &g_info[o];
     const uint32_t kind = oi->kind;
     if (kind != OSMT_OP_FILL_COLOR && kind != OSMT_OP_FILL_IMAGE) return;
@@ -817,6 +934,14 @@ __device__ __forceinline__ void fill_rows_body(FillRowsShared& sh, const uint32_
             if (srb + 2u < sr0 + nsr) sm[2] = hit2;
             if (srb + 3u < sr0 + nsr) sm[3] = hit3;
         }
+        /* one more op for the list of every sub-tile hit (k_sublist sizes its lists from these counts): lane = column */
+        if (lane < n_sub_x) {
+            uint32_t* ct = g_cnt_tile + (size_t)srb * n_sub_x + lane;
+            if ((hit0 >> lane) & 1u) atomicAdd(ct, 1u);
+            if ((hit1 >> lane) & 1u) atomicAdd(ct + n_sub_x, 1u);
+            if ((hit2 >> lane) & 1u) atomicAdd(ct + 2u * n_sub_x, 1u);
+            if ((hit3 >> lane) & 1u) atomicAdd(ct + 3u * n_sub_x, 1u);
+        }
     }
 }
 
@@ -835,7 +960,8 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
                                                 const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_vseg_blk_slot,
                                                 const uint32_t* __restrict__ g_stroke_op, uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale,
                                                 uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
-                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey) {
+                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
+                                                uint32_t* __restrict__ g_cnt) {
     /* slot of every lane's segment: the block's first segment lies in slot s0 (host table), the other 63 in the next
      * <= 63 slots — one coalesced load of their bases, then a bisection in LDS */
     const uint32_t g = blk * 64u + lane;
@@ -912,7 +1038,15 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
             g_skey[(size_t)oi.arena_off + slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (is_cap << 31));
             rowbits |= 1u << sx;
         }
-        if (rowbits) atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
+        if (rowbits) {
+            /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
+            uint32_t fresh = rowbits & ~atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
+            uint32_t* ct = g_cnt + ((size_t)g_op_job[o] * sub_rows + (uint32_t)sy) * (uint32_t)n_sub_x;
+            while (fresh) {
+                atomicAdd(ct + (uint32_t)__builtin_ctz(fresh), 1u);
+                fresh &= fresh - 1u;
+            }
+        }
     }
 }
 
@@ -928,14 +1062,132 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
                                                const uint32_t* __restrict__ g_stroke_op, uint32_t n_bin_slots, uint32_t n_vsegs, uint32_t n_vblk,
                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
-                                               osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey) {
+                                               osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
+                                               uint32_t* __restrict__ g_cnt) {
     __shared__ FillRowsShared sh;
     const uint32_t b = blockIdx.x;
     if (b < n_vblk)
         stroke_bin_body(reinterpret_cast<uint32_t*>(&sh.xmin[0][0]), b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
-                        g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey);
-    else if (b - n_vblk < n_ops)
-        fill_rows_body(sh, b - n_vblk, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, g_submask, sub_rows, g_fmask);
+                        g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey,
+                        g_op_job, g_cnt);
+    else if (b - n_vblk < n_ops) {
+        const uint32_t o = b - n_vblk;
+        const uint32_t n_sub_x = OSMT_TILE_SIZE * scale / SUB;
+        fill_rows_body(sh, o, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, g_submask, sub_rows, g_fmask,
+                       g_cnt + (size_t)g_op_job[o] * sub_rows * n_sub_x, n_sub_x);
+    }
+}
+
+/* ---- k_sublist: the op bits turned round — one ordered list per (tile, sub-tile) ------------------------------------
+ * One workgroup per TILE.  The binning kernels left the length of every sub-tile's list (cnt); the workgroup turns
+ * the tile's counts into offsets (exclusive scan in LDS) and reserves the tile's total with ONE atomicAdd (131 072
+ * waves bumping one cursor cost 1.5 ms; 1024 workgroups do not show).  Then one wave per sub-tile ROW scans the
+ * tile's op words of that row 64 ops at a time — one load serves all columns of the row, the op's record is fetched
+ * once — and, column by column, the lanes whose op draws there are compacted in order (ballot + popcount: order is
+ * semantics, `over` is not commutative) and write the op's entry, arena position resolved for that sub-tile, at
+ * their rank. */
+constexpr uint32_t SUBLIST_THREADS = 1024;
+constexpr uint32_t SUBLIST_MAX_SUB = (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_W) * (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_H);
+__global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job* __restrict__ g_jobs, uint32_t g_scale,
+                                                             const osmt_opinfo* __restrict__ g_info, const uint32_t* __restrict__ g_submask,
+                                                             uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
+                                                             unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
+                                                             osmt_ent* __restrict__ g_ent, unsigned long long ent_cap) {
+    __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
+    __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t W = OSMT_TILE_SIZE * g_scale;
+    const uint32_t nsx = W / SUB;
+    const uint32_t nsub = nsx * g_sub_rows;
+    const uint32_t* __restrict__ cnt = g_cnt + (size_t)tile * nsub;
+    for (uint32_t i = tid; i < nsub; i += SUBLIST_THREADS) s_off[i] = cnt[i];
+    __syncthreads();
+    if (wave == 0u) {
+        /* lane l owns the contiguous piece [l*per, (l+1)*per): serial inside, wave scan across */
+        const uint32_t per = (nsub + 63u) / 64u;
+        const uint32_t i0 = min(lane * per, nsub), i1 = min(i0 + per, nsub);
+        uint32_t sum = 0;
+        for (uint32_t i = i0; i < i1; ++i) sum += s_off[i];
+        uint32_t incl = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        uint32_t run = incl - sum;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const uint32_t c = s_off[i];
+            s_off[i] = run;
+            run += c;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 0u) {
+            const unsigned long long first = total ? atomicAdd(g_cursor, (unsigned long long)total) : 0ull;
+            s_base[0] = (uint32_t)first;
+            s_base[1] = (first + total <= ent_cap) ? 1u : 0u; /* always: the arena holds every (op, sub-tile) pair the binning can produce */
+        }
+    }
+    __syncthreads();
+    const uint32_t base = s_base[0];
+    const bool fits = s_base[1] != 0u;
+    const osmt_tile_job job = g_jobs[tile];
+    const uint32_t n_ops = job.n_ops;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    for (uint32_t sy = wave; sy < g_sub_rows; sy += SUBLIST_THREADS / 64u) {
+        /* lane sx keeps the write cursor of column sx */
+        uint32_t cur = 0u, row_n = 0u;
+        if (lane < nsx) {
+            const uint32_t c = cnt[sy * nsx + lane];
+            cur = base + s_off[sy * nsx + lane];
+            row_n = fits ? c : 0u;
+            g_hdr[(size_t)tile * nsub + sy * nsx + lane] = make_uint2(cur, row_n);
+        }
+        if (__ballot(row_n != 0u) == 0ull) continue; /* nothing draws into this row (or the reservation failed) */
+        auto load_bits = [&](uint32_t b0) -> uint32_t {
+            const uint32_t i = b0 + lane;
+            return (i < n_ops) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sy] : 0u;
+        };
+        uint32_t bits_next = load_bits(0);
+        for (uint32_t b0 = 0; b0 < n_ops; b0 += 64u) {
+            const uint32_t w = bits_next;
+            if (b0 + 64u < n_ops) bits_next = load_bits(b0 + 64u);
+            if (__ballot(w != 0u) == 0ull) continue;
+            osmt_ent e = {};
+            uint32_t geom = 0u, arena0 = 0u;
+            bool is_stroke = false;
+            if (w != 0u) {
+                const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + b0 + lane];
+                const uint32_t kind = hi->kind;
+                is_stroke = kind == OSMT_OP_STROKE;
+                arena0 = hi->arena_off;
+                geom = hi->fill_geom;
+                e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
+                e.opacity = hi->opacity;
+                e.aux = is_stroke ? hi->aux : hi->image_id;
+                e.nv = is_stroke ? hi->rec_cap : 0u;
+            }
+            const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
+            for (uint32_t sx = 0; sx < nsx; ++sx) {
+                const bool hit = (w >> sx) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (bal == 0ull) continue;
+                const uint32_t col_cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)sx);
+                const uint32_t col_left = (uint32_t)__builtin_amdgcn_readlane((int)row_n, (int)sx);
+                const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
+                if (hit && pos < col_left) {
+                    /* FILL: word index of this sub-tile's 16 rows; STROKE: the op's first slot */
+                    e.arena = is_stroke ? arena0 : (arena0 + (sy - sr0) * ncols + (sx - c0)) * SUBH;
+                    g_ent[(size_t)col_cur + pos] = e;
+                }
+                const uint32_t took = min((uint32_t)__popcll(bal), col_left);
+                if (lane == sx) {
+                    cur += took;
+                    row_n -= took;
+                }
+            }
+        }
+    }
 }
 
 /* Scenes are rendered by waves that each own one 32x16 sub-tile for the whole display list: the premultiplied f64
@@ -948,8 +1200,8 @@ template <bool OUT_F64, bool LABELS>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* separate __restrict__ const pointers (not a struct): lets the compiler prove the tables are
      * read-only and fetch wave-uniform records with scalar loads */
-    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const osmt_opinfo* OSMT_R g_info,
-    const osmt_stroke_aux* OSMT_R g_aux, const uint32_t* OSMT_R g_submask, uint32_t g_sub_rows,
+    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const uint2* OSMT_R g_hdr, const osmt_ent* OSMT_R g_ent,
+    const osmt_stroke_aux* OSMT_R g_aux,
     const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint2* OSMT_R g_skey,
     const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
     uint32_t g_n_images, void* OSMT_R g_out, size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab,
@@ -1005,52 +1257,35 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
     OSMT_DBG(if (lane < 8) sh.dbg[lane] = 0u; __syncthreads();)
-    const uint32_t n_ops = job.n_ops;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    /* the sub-tile bits of the NEXT chunk are fetched while the current one is processed */
-    auto load_bits = [&](uint32_t base) -> uint32_t {
-        const uint32_t i = base + lane;
-        return (i < n_ops) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sub_y] : 0u;
+    /* this sub-tile's own list (k_sublist): the ops that draw here, in order, 64 at a time; the NEXT chunk's entries are
+     * fetched while the current one is processed */
+    const uint2 hdr = g_hdr[(size_t)tile * nsub + sub];
+    const uint32_t n_ent = hdr.y;
+    const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
+    auto load_ent = [&](uint32_t base) -> OpEntry {
+        OpEntry e_ = {};
+        if (base + lane < n_ent) e_ = my_ent[base + lane];
+        return e_;
     };
-    uint32_t bits_next = n_ops ? load_bits(0) : 0u;
+    OpEntry e_next = load_ent(0);
 
-    for (uint32_t base = 0; base < n_ops; base += OPCHUNK) {
-        /* ---- ordered compaction of the ops that draw into this sub-tile (exact bits from the binning kernels) ---- */
-        const bool hit = (bits_next >> sub_x) & 1u;
-        if (base + OPCHUNK < n_ops) bits_next = load_bits(base + OPCHUNK);
-        const unsigned long long bal = __ballot(hit);
-        const uint32_t total = (uint32_t)__popcll(bal);
-        if (total == 0u) continue;
-        /* the lane that owns a hit op stages its entry: 48 bytes of osmt_opinfo, one round trip for the whole chunk */
-        uint32_t my_nv = 0;
-        bool is_stroke = false;
-        OpEntry e;
-        uint32_t geom = 0;
-        if (hit) {
-            const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + base + lane];
-            const uint32_t kind = hi->kind;
-            is_stroke = kind == OSMT_OP_STROKE;
-            my_nv = is_stroke ? min(hi->rec_cap, 255u) : 0u;
-            geom = hi->fill_geom;
-            e.arena = hi->arena_off;
-            e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
-            e.opacity = hi->opacity;
-            e.aux = is_stroke ? hi->aux : hi->image_id;
-            e.nv = (uint8_t)(my_nv > (uint32_t)SEGCAP ? 255u : my_nv);
-            e._pad[0] = e._pad[1] = 0;
-        }
-        const unsigned long long sbal = __ballot(hit && is_stroke), fbal = bal & ~sbal;
-        const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
+    for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
+        const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
+        const bool hit = lane < total;
+        const unsigned long long bal = (total >= 64u) ? ~0ull : ((1ull << total) - 1ull);
+        OpEntry e = e_next;
+        if (base + OPCHUNK < n_ent) e_next = load_ent(base + OPCHUNK);
+        const bool is_stroke = hit && (e.kind_color & 255u) == OSMT_OP_STROKE;
+        const unsigned long long sbal = __ballot(is_stroke), fbal = bal & ~sbal;
+        const uint32_t pos = lane;
         const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & lanes_below);
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
-            if (!is_stroke) {
-                const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
-                e.arena = (e.arena + (sub_y - sr0) * ncols + (sub_x - c0)) * SUBH; /* word index of this sub-tile's 16 rows */
-            }
-            e.stage = (uint8_t)(my_stage < (uint32_t)STAGECAP ? my_stage : 255u);
+            e.stage = my_stage < (uint32_t)STAGECAP ? my_stage : 255u;
             sh.ent[pos] = e;
+            if (!is_stroke && my_stage < (uint32_t)STAGECAP) sh.farena[my_stage] = e.arena;
             if (is_stroke && my_stage < (uint32_t)STAGECAP) {
                 /* constants of the across test (second round trip, in parallel for all strokes of the chunk) */
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[e.aux];
@@ -1060,7 +1295,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 kc.fd0 = sa->fd0;
                 kc.rfd0 = sa->rfd0;
                 kc.mul0 = sa->mul0;
-                kc.plain_main = sa->main.n_segs == 0 ? 1u : 0u;
+                kc.flags = stroke_flags(sa);
                 kc._pad = 0;
                 sh.sconst[my_stage] = kc;
             }
@@ -1076,12 +1311,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const uint32_t n_fill_staged = min((uint32_t)__popcll(fbal), (uint32_t)STAGECAP);
             for (uint32_t i = lane; i < n_fill_staged * SUBH; i += NTHREADS) {
                 const uint32_t f = i / SUBH, row = i % SUBH;
-                /* the f-th fill of the chunk is the entry at the position of the f-th set bit of fbal among bal */
-                unsigned long long m = fbal;
-                for (uint32_t k = 0; k < f; ++k) m &= m - 1ull;
-                const uint32_t fl = (uint32_t)__builtin_ctzll(m);
-                const uint32_t fpos = (uint32_t)__popcll(bal & ((1ull << fl) - 1ull));
-                sh.fmask[f][row] = g_fmask[(size_t)sh.ent[fpos].arena + row];
+                sh.fmask[f][row] = g_fmask[(size_t)sh.farena[f] + row];
             }
         }
         __syncthreads();
@@ -1097,7 +1327,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             gend = total; /* fills only: one group, nothing to lay out */
         } else {
             for (; gend < total; ++gend) {
-                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.ent[gend].nv);
+                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.ent[gend].nv); /* 0: a fill */
                 if (nv > (uint32_t)SEGCAP) {
                     if (gend == g0) {
                         big = true;
@@ -1127,6 +1357,15 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const double op_opacity = en.opacity;
             const double cr = k_u8_over_255[(kc_ >> 8) & 255u], cg = k_u8_over_255[(kc_ >> 16) & 255u], cb = k_u8_over_255[kc_ >> 24];
             const uint32_t stage = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.stage);
+#if defined(OSMT_ABL) && OSMT_ABL == 3
+            if (kind == OSMT_OP_STROKE) continue; /* ablation: no stroke work at all */
+#endif
+#if defined(OSMT_ABL) && OSMT_ABL == 6
+            if (kind != 77u) continue; /* ablation: lists are staged, nothing is drawn */
+#endif
+#if defined(OSMT_ABL) && (OSMT_ABL == 2 || OSMT_ABL == 4)
+            if (kind != OSMT_OP_STROKE) continue; /* ablation: no fill work */
+#endif
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
                 OSMT_DBG(if (lane == 0) sh.dbg[0] += 1u;)
@@ -1142,16 +1381,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     kc.fd0 = sa->fd0;
                     kc.rfd0 = sa->rfd0;
                     kc.mul0 = sa->mul0;
-                    kc.plain_main = sa->main.n_segs == 0 ? 1u : 0u;
+                    kc.flags = stroke_flags(sa);
                     kc._pad = 0;
                 }
-                const bool plain_main = __builtin_amdgcn_readfirstlane((int)kc.plain_main) != 0;
+                const uint32_t sflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.flags);
                 uint32_t n_rounds = 1u, big_cap = 0u;
                 if (big) {
-                    /* the op's slot count: the staged nv saturates at 255, the exact value is one scalar load away */
-                    unsigned long long m = bal; /* entry li of the chunk is the li-th set bit of bal */
-                    for (uint32_t k = 0; k < li; ++k) m &= m - 1ull;
-                    big_cap = g_info[job.op_off + base + (uint32_t)__builtin_ctzll(m)].rec_cap;
+                    big_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
                     n_rounds = (big_cap + (uint32_t)SEGCAP - 1u) / (uint32_t)SEGCAP;
                 }
                 for (uint32_t round = 0; round < n_rounds; ++round) {
@@ -1209,21 +1445,26 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         if (nslot) {
                             const uint32_t item_lo = slot0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 - 1u]) : 0u;
                             const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + nslot - 1u]);
-#if defined(OSMT_ABL) && OSMT_ABL == 1
+#if defined(OSMT_ABL) && (OSMT_ABL == 1 || OSMT_ABL == 4)
                             (void)item_lo; (void)item_hi;
 #else
-                            if (plain_main) {
-                                /* slots are in segment order: the edges' records first, the cap stubs' (which need the
-                                 * start-distance terms of opacity_calculator_for_outer_caps, line.rs:22) last — two
-                                 * passes, so the plain runs never execute the dash / cap arithmetic */
-                                const uint32_t n_edge = (uint32_t)__popcll(gbal & ~cbal & lanes_ab);
-                                const uint32_t item_mid = n_edge ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + n_edge - 1u]) : item_lo;
-                                if (n_edge) walk_items<true>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, sa, op_opacity, rc);
-                                if (nslot > n_edge)
-                                    walk_items<false>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, kc, sa, op_opacity, rc);
-                            } else {
-                                walk_items<false>(sh, lane, slot0, nslot, item_lo, item_lo, item_hi, kc, sa, op_opacity, rc);
+                            /* slots are in segment order: the edges' records first, the cap stubs' (which need the
+                             * start-distance terms of opacity_calculator_for_outer_caps, line.rs:22) last — separate
+                             * passes, so a pass has ONE calculator (scalar table loads) and the plain runs never
+                             * execute the dash / cap arithmetic */
+                            const uint32_t n_edge = (uint32_t)__popcll(gbal & ~cbal & lanes_ab);
+                            const uint32_t item_mid = n_edge ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + n_edge - 1u]) : item_lo;
+                            const double half_width = sa->half_width;
+                            if (n_edge) {
+                                if ((sflags & (STROKE_PLAIN_MAIN | STROKE_UNIT_FD | STROKE_TINY_MUL)) == (STROKE_PLAIN_MAIN | STROKE_UNIT_FD))
+                                    walk_items<0>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, nullptr, half_width, op_opacity, rc);
+                                else if (sflags & STROKE_PLAIN_MAIN)
+                                    walk_items<1>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, nullptr, half_width, op_opacity, rc);
+                                else
+                                    walk_items<2>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, &sa->main, half_width, op_opacity, rc);
                             }
+                            if (nslot > n_edge)
+                                walk_items<2>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, kc, &sa->caps, half_width, op_opacity, rc);
 #endif
                         }
                     }
@@ -1493,15 +1734,20 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
 }
 
 hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.cursors, 0, 2 * sizeof(unsigned long long), st);
+    /* the three cursors and, right behind them, the per-sub-tile list counts */
+    const uint32_t Wt = OSMT_TILE_SIZE * a.scale;
+    const size_t n_cnt = (a.fmask_cap || a.srec_cap) ? (size_t)a.n_jobs * (Wt / SUB) * (Wt / SUBH) : 0;
+    hipError_t e = hipMemsetAsync(a.cursors, 0, 4 * sizeof(unsigned long long) + n_cnt * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    if (a.n_ops == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
+    if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
-    hipLaunchKernelGGL(k_prebin, dim3(n_vblk + a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden, a.aux,
+    if (a.n_ops) hipLaunchKernelGGL(k_prebin, dim3(n_vblk + a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden, a.aux,
                        a.op_blk, a.blk, a.vseg_base, a.vseg_blk_slot, a.stroke_op, a.n_strokes, a.n_vsegs, n_vblk, a.scale, a.sub_rows,
-                       a.submask, a.cand_off, a.fmask, a.srec, a.skey);
+                       a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
+    if (a.n_jobs) /* also without a single op: k_raster reads the (empty) list headers */
+        hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap);
     return hipGetLastError();
 }
 
@@ -1512,8 +1758,8 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
 #define OSMT_LAUNCH_RASTER(F64, LAB)                                                                                   \
-    hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.info, a.aux, a.submask, \
-                       a.sub_rows, a.fmask, a.srec, a.skey, a.images, a.image_pool, a.n_images, a.out,          \
+    hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.hdr, a.ent, a.aux, \
+                       a.fmask, a.srec, a.skey, a.images, a.image_pool, a.n_images, a.out,          \
                        a.out_tile_stride, a.labels.info, a.labels.job_label_off, a.labels.tile_labels,                    \
                        a.labels.tile_label_cnt, a.labels.plane)
     if (out_f64) /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
