@@ -38,6 +38,20 @@ __device__ __forceinline__ int32_t f64_as_i32(double v) {
  * covers every case in two instructions before the conversion. */
 __device__ __forceinline__ uint32_t f64_as_u8(double v) { return (uint32_t)(int32_t)fmin(fmax(v, 0.0), 255.0); }
 
+/* Inclusive prefix sum over the 64 lanes of a wave on the DPP network: shifts inside the rows of 16 lanes (a lane
+ * whose source falls outside the row adds 0), then the row totals broadcast to the following rows (row_bcast:15 into
+ * rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six VALU adds — no LDS permutes to wait for, no lane masks held in
+ * scalar registers. */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); /* row_bcast:15 -> rows 1, 3 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2, 3 */
+    return x;
+}
+
 /* ------------------------------------------------------------------------- */
 /* tile.rs:88-106 + point.rs:11-19 */
 __device__ __forceinline__ void project_point(double lat, double lon, uint32_t zoom, uint32_t tx, uint32_t ty,
@@ -806,7 +820,7 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 }
 
 #ifndef OSMT_V_WAVES
-#define OSMT_V_WAVES 0
+#define OSMT_V_WAVES 4
 #endif
 #if OSMT_V_WAVES > 0
 /* waves per SIMD the register allocator must leave room for */
@@ -1109,12 +1123,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
         const uint32_t i0 = min(lane * per, nsub), i1 = min(i0 + per, nsub);
         uint32_t sum = 0;
         for (uint32_t i = i0; i < i1; ++i) sum += s_off[i];
-        uint32_t incl = sum;
-#pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d);
-            if (lane >= d) incl += y;
-        }
+        const uint32_t incl = wave_incl_scan(sum);
         uint32_t run = incl - sum;
         for (uint32_t i = i0; i < i1; ++i) {
             const uint32_t c = s_off[i];
@@ -1196,17 +1205,43 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
  * of perpendicular-run ranges per (segment, sub-tile) (k_stroke_bin).  What is left here is the part that needs the
  * pixels: walking the runs of a generation into the LDS alpha plane (set_pixel keeps the larger alpha,
  * tile_pixels.rs:114-118) and blending generation after generation in order (tile_pixels.rs:205-223). */
+/* The kernel's own argument block, re-read from the kernel-argument segment at the point of use: the empty asm makes
+ * the pointer opaque, so the compiler can neither hoist the (invariant) loads to the top of the kernel nor keep their
+ * results alive across the loops in between. */
+__device__ __forceinline__ const osmt_raster_args* late_args() {
+    const osmt_raster_args* p = (const osmt_raster_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+/* Filler::Image (fill.rs:36-40): icon.get(x % w, y % h) for the covered pixels of one lane (pixel j = column x, row
+ * y0 + ROWSTEP * j), opacity ignored.  Deliberately NOT inlined: see the call. */
+__device__ __attribute__((noinline)) void fill_image_cold(double (*a)[3], uint32_t cov, const double4* __restrict__ ipx, uint32_t w, uint32_t h,
+                                                          uint32_t x, uint32_t y0) {
+    const uint32_t ix = x % w;
+    for (uint32_t j = 0; j < (uint32_t)PXT; ++j) {
+        if ((cov >> j) & 1u) {
+            const uint32_t iy = (y0 + j * (uint32_t)ROWSTEP) % h;
+            const double4 c = ipx[(size_t)iy * w + ix];
+            blend_rgb(a[j], c.x, c.y, c.z, c.w);
+        }
+    }
+}
+
 template <bool OUT_F64, bool LABELS>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
-    /* separate __restrict__ const pointers (not a struct): lets the compiler prove the tables are
-     * read-only and fetch wave-uniform records with scalar loads */
-    const osmt_tile_job* OSMT_R g_jobs, uint32_t g_n_jobs, uint32_t g_scale, const uint2* OSMT_R g_hdr, const osmt_ent* OSMT_R g_ent,
-    const osmt_stroke_aux* OSMT_R g_aux,
-    const uint32_t* OSMT_R g_fmask, const osmt_srec* OSMT_R g_srec, const uint2* OSMT_R g_skey,
-    const osmt_image_desc* OSMT_R g_images, const double4* OSMT_R g_image_pool,
-    uint32_t g_n_images, void* OSMT_R g_out, size_t g_out_tile_stride, const osmt_labelinfo* OSMT_R g_lab,
-    const uint32_t* OSMT_R g_job_label_off, const osmt_tile_label* OSMT_R g_tl, const uint32_t* OSMT_R g_tl_cnt,
-    const double* OSMT_R g_lab_plane) {
+    /* ONE by-value argument block.  The tables of the hot loops (lists, coverage words, stroke records, calculator
+     * constants) are taken from it once and live in SGPRs; everything that is needed only at one point — the job record
+     * and list header at the start, the icon pool of a rare image fill, the label tables and the output pointer of the
+     * epilogue — is re-read from the kernel-argument segment WHERE it is used (late()): 20 pointers held across the
+     * whole kernel cost 61-87 SGPR spills (v_writelane / v_readlane traffic in every loop level). */
+    const osmt_raster_args a) {
+    const osmt_ent* OSMT_R g_ent = a.ent;
+    const osmt_stroke_aux* OSMT_R g_aux = a.aux;
+    const uint32_t* OSMT_R g_fmask = a.fmask;
+    const osmt_srec* OSMT_R g_srec = a.srec;
+    const uint2* OSMT_R g_skey = a.skey;
+    const uint32_t g_scale = a.scale;
     __shared__ RasterShared sh;
 
     const uint32_t tid = threadIdx.x;
@@ -1222,9 +1257,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint32_t rest = b >> 3;
     const uint32_t tile = (rest / nsub) * 8u + xcd;
     const uint32_t sub = rest % nsub;
-    if (tile >= g_n_jobs) return;
+    if (tile >= a.n_jobs) return;
 
-    const osmt_tile_job job = g_jobs[tile];
+    const osmt_tile_job job = a.jobs[tile];
     SubRect rc;
     const uint32_t sub_x = sub % subs_per_row, sub_y = sub / subs_per_row;
     rc.x0 = (int32_t)(sub_x * SUB);
@@ -1261,7 +1296,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
 
     /* this sub-tile's own list (k_sublist): the ops that draw here, in order, 64 at a time; the NEXT chunk's entries are
      * fetched while the current one is processed */
-    const uint2 hdr = g_hdr[(size_t)tile * nsub + sub];
+    const uint2 hdr = a.hdr[(size_t)tile * nsub + sub];
     const uint32_t n_ent = hdr.y;
     const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
     auto load_ent = [&](uint32_t base) -> OpEntry {
@@ -1302,7 +1337,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         const bool any_stroke = sbal != 0ull;
         if (any_stroke && !plane_clean) {
-            for (uint32_t i = tid; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i] = 0ull;
+            static_assert((PLANE_STRIDE * SUBH) % NTHREADS == 0, "the plane is cleared in whole wave strides");
+#pragma unroll
+            for (uint32_t i = 0; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i + tid] = 0ull;
             plane_clean = true;
         }
         __syncthreads();
@@ -1416,12 +1453,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         }
                         gbal = __ballot(cnt > 0u);
                         cbal = __ballot(cnt > 0u && is_cap != 0u);
-                        uint32_t incl = cnt; /* inclusive prefix of the item counts over the lanes */
-#pragma unroll
-                        for (uint32_t d = 1; d < 64u; d <<= 1) {
-                            const uint32_t y = __shfl_up(incl, d);
-                            if (lane >= d) incl += y;
-                        }
+                        const uint32_t incl = wave_incl_scan(cnt); /* inclusive prefix of the item counts over the lanes */
                         if (cnt > 0u) {
                             const uint32_t slot = (uint32_t)__popcll(gbal & lanes_below);
                             sh.seg[slot] = g_srec[ridx];
@@ -1495,26 +1527,38 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 if (kind == OSMT_OP_FILL_COLOR) {
                     const double o_ = op_opacity;
                     const double sr = o_ * cr, sg = o_ * cg, sb = o_ * cb;
-                    /* branch-free: an uncovered pixel blends the transparent colour, 0 + (1 - 0)*old == old exactly */
+                    /* blend_pixel (tile_pixels.rs:209-219) for every pixel, kept where the pixel is covered: the op's colour is
+                     * wave-uniform, so new = s + (1 - a) * old costs two instructions per channel and a select */
+                    const double k_ = 1.0 - o_;
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
                         const bool c_ = (cov >> j) & 1u;
-                        blend_rgb(acc[j], c_ ? sr : 0.0, c_ ? sg : 0.0, c_ ? sb : 0.0, c_ ? o_ : 0.0);
+                        const double nr = sr + k_ * acc[j][0], ng = sg + k_ * acc[j][1], nb = sb + k_ * acc[j][2];
+                        acc[j][0] = c_ ? nr : acc[j][0];
+                        acc[j][1] = c_ ? ng : acc[j][1];
+                        acc[j][2] = c_ ? nb : acc[j][2];
                     }
                 } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
                     const uint32_t img = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.aux);
-                    if (img < g_n_images) {
-                        const osmt_image_desc im = g_images[img];
-                        const double4* __restrict__ ipx = g_image_pool + im.offset;
+                    const osmt_raster_args* la = late_args();
+                    if (img < la->n_images) {
+                        const osmt_image_desc im = la->images[img];
+                        const double4* __restrict__ ipx = la->image_pool + im.offset;
+                        /* out of line, on a COPY of the accumulators in scratch: inlined, the eight icon addresses and loads
+                         * in flight cost the whole kernel ~45 registers — a wave per SIMD — for a rare op */
+                        double tmp[PXT][3];
 #pragma unroll
                         for (int j = 0; j < PXT; ++j) {
-                            if ((cov >> j) & 1u) {
-                                const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
-                                const uint32_t ix = (uint32_t)(rc.x0 + (int32_t)lx) % im.width;
-                                const uint32_t iy = (uint32_t)(rc.y0 + (int32_t)row) % im.height;
-                                const double4 c = ipx[(size_t)iy * im.width + ix];
-                                blend_rgb(acc[j], c.x, c.y, c.z, c.w);
-                            }
+                            tmp[j][0] = acc[j][0];
+                            tmp[j][1] = acc[j][1];
+                            tmp[j][2] = acc[j][2];
+                        }
+                        fill_image_cold(tmp, cov, ipx, im.width, im.height, (uint32_t)rc.x0 + lx, (uint32_t)rc.y0 + ly0);
+#pragma unroll
+                        for (int j = 0; j < PXT; ++j) {
+                            acc[j][0] = tmp[j][0];
+                            acc[j][1] = tmp[j][1];
+                            acc[j][2] = tmp[j][2];
                         }
                     }
                 }
@@ -1531,8 +1575,12 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * order of the loop does not matter.  Inside one label the text's pixels (total > 0) were
      * written after the icon's and replace them (labeler.rs:29-31). */
     if (LABELS) {
-        const osmt_tile_label* OSMT_R tl = g_tl + g_job_label_off[tile];
-        const uint32_t n_tl = g_tl_cnt[tile];
+        const osmt_raster_args* la = late_args();
+        const osmt_labelinfo* OSMT_R g_lab = la->labels.info;
+        const double* OSMT_R g_lab_plane = la->labels.plane;
+        const double4* OSMT_R g_image_pool = la->image_pool;
+        const osmt_tile_label* OSMT_R tl = la->labels.tile_labels + la->labels.job_label_off[tile];
+        const uint32_t n_tl = la->labels.tile_label_cnt[tile];
         /* the tile's survivors are tested against the sub-tile 64 at a time (one load, one ballot): only the few
          * that reach into it are walked */
         for (uint32_t kb = 0; kb < n_tl; kb += 64u) {
@@ -1575,6 +1623,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     }
 
     /* ---- to_rgb_triples (tile_pixels.rs:164-181) / raw canvas ---------------- */
+    void* const g_out = late_args()->out;
+    const size_t g_out_tile_stride = late_args()->out_tile_stride;
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
@@ -1757,11 +1807,7 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
-#define OSMT_LAUNCH_RASTER(F64, LAB)                                                                                   \
-    hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a.jobs, a.n_jobs, a.scale, a.hdr, a.ent, a.aux, \
-                       a.fmask, a.srec, a.skey, a.images, a.image_pool, a.n_images, a.out,          \
-                       a.out_tile_stride, a.labels.info, a.labels.job_label_off, a.labels.tile_labels,                    \
-                       a.labels.tile_label_cnt, a.labels.plane)
+#define OSMT_LAUNCH_RASTER(F64, LAB) hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a)
     if (out_f64) /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
         OSMT_LAUNCH_RASTER(true, false);
     else if (a.labels.info)
