@@ -122,6 +122,86 @@ def pmc_child(name):
     scene.free()
 
 
+def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35):
+    """p50 / p99 of osmt_render_batch_rgb (validation + upload + kernels + RGB8 read-back into pinned memory) for small
+    batches from several worker threads on one context."""
+    import ctypes as C
+    import threading
+
+    import numpy as np
+
+    from osm_renderer_amd import synth
+    from osm_renderer_amd.lib import load
+
+    L = load()
+    out = {"what": "wall clock (us) around one osmt_render_batch_rgb call: B config-2 tiles per call, W worker threads on ONE "
+                   "osmt_ctx calling back to back (the reference's server shape: one tile per request per worker, "
+                   "src/http_server.rs:50-83,134-181); tiles_per_s = all threads together",
+           "cases": {}}
+    max_w, max_b = max(workers), max(batches)
+    pool = [synth.make_tiles(synth.config_tiles(max_b, x0=19000 + 7 * w, y0=10000 + 3 * w), zoom=15, scale=args.scale, n_poly=args.n_poly,
+                             n_line=args.n_line) for w in range(max_w)]
+    bufs = [ctx.host_alloc((max_b, pool[0].dim * pool[0].dim * 3)) for _ in range(max_w)]
+    try:
+        for bsz in batches:
+            lists = [p.subset(range(bsz)) for p in pool]
+            structs = [dl.as_batch() for dl in lists]
+            stride = lists[0].dim * lists[0].dim * 3
+            for nw in workers:
+                lat = [[] for _ in range(nw)]
+                errs = []
+                start = threading.Barrier(nw + 1)
+
+                def run(w):
+                    ptr = bufs[w].ctypes.data_as(C.POINTER(C.c_uint8))
+                    b = C.byref(structs[w])
+                    try:
+                        for _ in range(3):
+                            if L.osmt_render_batch_rgb(ctx._h, b, None, ptr, stride) != 0:
+                                raise RuntimeError(L.osmt_last_error().decode())
+                        start.wait()
+                        t_end = time.perf_counter() + seconds
+                        while True:
+                            t0 = time.perf_counter()
+                            rc = L.osmt_render_batch_rgb(ctx._h, b, None, ptr, stride)
+                            t1 = time.perf_counter()
+                            if rc != 0:
+                                raise RuntimeError(L.osmt_last_error().decode())
+                            lat[w].append(t1 - t0)
+                            if t1 >= t_end:
+                                break
+                    except Exception as e:  # noqa: BLE001
+                        errs.append(repr(e))
+                        try:
+                            start.abort()
+                        except Exception:  # noqa: BLE001
+                            pass
+
+                th = [threading.Thread(target=run, args=(w,)) for w in range(nw)]
+                for t in th:
+                    t.start()
+                try:
+                    start.wait()
+                except threading.BrokenBarrierError:
+                    pass
+                t0 = time.perf_counter()
+                for t in th:
+                    t.join()
+                wall = time.perf_counter() - t0
+                if errs:
+                    out["cases"][f"batch{bsz}_workers{nw}"] = {"error": errs[0]}
+                    continue
+                allv = np.sort(np.concatenate([np.asarray(v) for v in lat])) * 1e6
+                out["cases"][f"batch{bsz}_workers{nw}"] = {
+                    "calls": int(allv.size), "p50_us": float(allv[allv.size // 2]), "p99_us": float(allv[min(allv.size - 1, int(allv.size * 0.99))]),
+                    "mean_us": float(allv.mean()), "tiles_per_s": float(allv.size * bsz / wall),
+                }
+    finally:
+        for b in bufs:
+            ctx.host_free(b)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with one rank
     per GPU on a free local port, pass rank 0's JSON line through, return the launcher's exit code."""
@@ -450,6 +530,11 @@ def main():
             }
             ctx.host_free(pin)
             ctx.host_free(pbuf)
+            # ---- small-batch latency: what a drop-in behind the reference's server lives on --------------------
+            # http_server.rs:134-181 renders ONE tile per request per worker; W workers share one Drawer (:50-83).  Here:
+            # W host threads on ONE context, each issuing osmt_render_batch_rgb calls of B tiles back to back (its own
+            # display list, its own pinned RGB8 buffer); per-call wall clock around the C call only.
+            result["end_to_end"]["latency"] = latency_leg(ctx, args)
         except Exception as e:  # noqa: BLE001
             result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -649,8 +734,12 @@ def main():
                       "Rust CPU path incl. its 3x3-tile canvas, NOT the Rust binary; persistent pool, one canvas per worker allocated before "
                       "the timer, output pre-allocated, tiles round-robin; best point reported as value",
             "single_thread_tiles_per_s": 1.0 / per_tile,
+            "single_tile_us": per_tile * 1e6,
             "gpu_matches_oracle_on_sample": match,
         }
+
+    if "cpu_baseline" in result and isinstance(result.get("end_to_end"), dict) and "latency" in result["end_to_end"]:
+        result["end_to_end"]["latency"]["oracle_single_tile_us"] = result["cpu_baseline"]["single_tile_us"]
 
     # ---- counters of THIS run: child rocprofv3 passes over the same step (N = 1 only) ------------------
     if solo and not args.no_pmc and named and args.tiles == 1024 and args.scale == 1 and not strong:

@@ -1,4 +1,4 @@
-"""A short run of the randomised differential fuzzer (tools/fuzz_parity.py): adversarial widths, dashes,
+"""A one-minute run (each) of the randomised differential fuzzer (tools/fuzz_parity.py): adversarial widths, dashes,
 caps, directions, huge coordinates, multi-ring fills, scales 1..3 — GPU vs oracle, bit-exact.
 (Round 1, longer runs on the GPU box: 4380 tiles of area ops and 6612 tiles with random label passes, 0 mismatches.)"""
 import pytest
@@ -9,13 +9,13 @@ pytestmark = pytest.mark.gpu
 def test_fuzz_short(gpu_ctx, oracle):
     from tools import fuzz_parity
 
-    tiles, bad = fuzz_parity.run(budget=8.0, seed=2026, ctx=gpu_ctx, dump=False)
-    assert tiles >= 12 and bad == 0
+    tiles, bad = fuzz_parity.run(budget=60.0, seed=2026, ctx=gpu_ctx, dump=False)
+    assert tiles >= 60 and bad == 0
 
 
 def test_fuzz_short_with_labels(gpu_ctx, oracle):
     """the same with a random label pass per tile: adversarial draw_line calls, icons, collisions, wide windows"""
     from tools import fuzz_parity
 
-    tiles, bad = fuzz_parity.run(budget=8.0, seed=77, ctx=gpu_ctx, dump=False, with_labels=True)
-    assert tiles >= 12 and bad == 0
+    tiles, bad = fuzz_parity.run(budget=60.0, seed=77, ctx=gpu_ctx, dump=False, with_labels=True)
+    assert tiles >= 60 and bad == 0

@@ -53,7 +53,7 @@ def make_tile(scale):
             if rnd.random() < 0.5:
                 nd = int(rnd.integers(1, 7))
                 d = [float(rnd.choice([0.3, 1.0, 2.0, 3.0, 5.5, 8.0, 13.0, 40.0])) * scale for _ in range(nd)]
-            w = float(rnd.choice([0.0, 0.05, 0.2, 0.5, 0.99, 1.0, 1.01, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 12.5, 25.0, 40.0])) * scale
+            w = float(rnd.choice([0.0, 0.05, 0.2, 0.5, 0.99, 1.0, 1.01, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 12.5, 25.0, 40.0, -3.0, 1.3, 2e-101, 0.7])) * scale
             tb.stroke(rand_pts(int(rnd.integers(2, 9)), W, int(rnd.choice([3, 30, 90, 300]))), w, col, op, dashes=d,
                       cap=CAPS[int(rnd.integers(0, 4))], use_caps_for_dashes=bool(rnd.integers(0, 2)))
     return tb.build()
