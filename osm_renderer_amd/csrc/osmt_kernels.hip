@@ -834,127 +834,272 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 #define OSMT_R __restrict__
 #endif
 
-/* ---- k_fill_rows: fill_contour's coverage, once per op and row (fill.rs:16-104) ------------------------------
- * One wave per FILL op; a pass handles the 64 rows of four sub-tile rows, lane = row.  Every lane walks the op's
- * edges (wave-uniform loop, points fetched once per wave) and evaluates the closed form of the Zingl-Bresenham walk
- * for ITS row (osmt_fill_row_extent: the un-poisoned Edge{x_min, x_max} of fill.rs:79-87); records go to the lane's
- * column of an LDS table in edge order, are ordered by x_min with a stable insertion sort (= sort_by_key of records
- * inserted in edge order, fill.rs:24-25), paired (0,1),(2,3).. and the spans OR-ed into one 32-bit word per sub-tile
- * column.  k_raster then reads 16 words per (op, sub-tile) instead of re-deriving the rows in every column it
- * crosses.  The exact "draws something here" bits of the op's sub-tile mask fall out of the same words. */
-struct FillRowsShared {
-    int32_t xmin[ROWCAP][64];
-    int32_t xmax[ROWCAP][64];
+/* ---- k_fillrows: fill_contour's coverage, once per op and row (fill.rs:16-104) ------------------------------------
+ * The unit of work is a CROSSING — an (edge, row) pair on which the edge leaves an un-poisoned record (fill.rs:66-87)
+ * — not an (edge, row) combination: only a third of the combinations of a polygon's bounding rows cross, and a
+ * polygon a few rows tall would leave most of a wave idle.
+ *   pass     64 rows = four slots of 16; a slot is one sub-tile row of one FILL op.  A wave owns FILL_GROUP consecutive
+ *            ops and deals their sub-tile rows to the slots in order: four rows of one tall polygon, or the rows of
+ *            up to four small ones.
+ *   step 1   lane = edge (64 per round; ops with more: further rounds, 64-edge blocks whose box misses the rows are
+ *            skipped): rows of the pass the edge crosses -> a compact edge list with the running crossing count, and a
+ *            difference array over the rows (+1 on the first row, -1 behind the last).
+ *   step 1b  lane = row: scans of the difference array give every row's crossing count and its segment of the record
+ *            buffer.
+ *   step 2   lane = crossing (bisection of the edge list): closed form of the Zingl-Bresenham walk for that row
+ *            (osmt_fill_row_extent: Edge{x_min, x_max}), appended to the row's segment.
+ *   step 3   lane = row: insertion sort by (x_min, running edge index) = sort_by_key of records inserted in edge order
+ *            (fill.rs:24-25), pairs (0,1),(2,3).. OR-ed into one 32-bit word per sub-tile column; the exact "draws
+ *            here" bits of the op's sub-tile mask and the list counts of k_sublist fall out of the same words.
+ * A window of rows with more crossing edges / crossings than the buffers hold is halved until it fits; a single row
+ * beyond them streams its records storage-free (fill_row_streaming, cold). */
+constexpr uint32_t FILL_GROUP = 4;
+constexpr uint32_t FILL_EMAX = 128;
+constexpr uint32_t FILL_RMAX = 512;
+struct FillShared {
+    int32_t r_xmin[FILL_RMAX];
+    int32_t r_xmax[FILL_RMAX];
+    uint32_t r_key[FILL_RMAX];
+    int2 e_p1[FILL_EMAX], e_p2[FILL_EMAX];
+    int32_t e_y0[FILL_EMAX];     /* first crossed row */
+    uint32_t e_lane0[FILL_EMAX]; /* its lane in the pass */
+    uint32_t e_pre[FILL_EMAX];   /* inclusive crossing count up to this edge */
+    uint32_t e_key[FILL_EMAX];   /* running edge index inside the op (fill.rs:19) */
+    int32_t diff[65];
+    uint32_t rowfill[64];
+    uint32_t rowstart[64];
 };
 
-__device__ __forceinline__ void fill_rows_body(FillRowsShared& sh, const uint32_t o, const uint32_t lane, const osmt_op* __restrict__ g_ops,
-                                               const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
+__device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t group, const uint32_t lane, const osmt_op* __restrict__ g_ops,
+                                               uint32_t n_ops, const osmt_opinfo* __restrict__ g_info, const osmt_ring* __restrict__ g_rings,
                                                const int2* __restrict__ g_pts, const uint32_t* __restrict__ g_op_blk,
-                                               const osmt_blk_bbox* __restrict__ g_blk, uint32_t* __restrict__ g_submask,
-                                               uint32_t sub_rows, uint32_t* __restrict__ g_fmask, uint32_t* __restrict__ g_cnt_tile,
-                                               uint32_t n_sub_x) {
-    const osmt_opinfo* __restrict__ oi = &g_info[o];
-    const uint32_t kind = oi->kind;
-    if (kind != OSMT_OP_FILL_COLOR && kind != OSMT_OP_FILL_IMAGE) return;
-    const uint32_t geom = oi->fill_geom;
-    const uint32_t nsr = geom >> 24;
-    if (nsr == 0u) return;
-    const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
-    const uint32_t arena = oi->arena_off;
-    const osmt_op* __restrict__ op = &g_ops[o];
-    const uint32_t ring_off = op->ring_off, n_rings = op->n_rings;
-    const uint32_t blk_off = g_op_blk[o];
-    for (uint32_t pass = 0; pass * 4u < nsr; ++pass) {
-        const uint32_t srb = sr0 + pass * 4u;          /* first sub-tile row of the pass */
-        const int32_t ybase = (int32_t)(srb * SUBH);
-        const int32_t y = ybase + (int32_t)lane;
-        const uint32_t sr = srb + (lane >> OSMT_SUB_H_LOG2);
-        const bool row_valid = sr < sr0 + nsr;
-        uint32_t cnt = 0;
-        uint32_t e_base = 0;
-        for (uint32_t r = 0; r < n_rings; ++r) {
-            const osmt_ring ring = g_rings[ring_off + r];
-            if (ring.n_pts < 2u) continue;
-            const uint32_t ne = ring.n_pts - 1u;
-            for (uint32_t e = 0; e < ne; ++e) {
-                if (blk_off != 0xFFFFFFFFu && ((e_base + e) & 63u) == 0u) {
-                    /* long op: skip the 64-edge block when none of its edges has a record on this pass's rows
-                     * (rows carrying records of an edge: ytop < y <= ybot) */
-                    const osmt_blk_bbox bb = g_blk[blk_off + ((e_base + e) >> 6)];
-                    if (bb.y1 < ybase || bb.y0 >= ybase + 63) {
-                        const uint32_t skip = min(64u, ne - e);
-                        e += skip - 1u;
-                        continue;
-                    }
-                }
-                const int2 p1 = g_pts[ring.first_pt + e];
-                const int2 p2 = g_pts[ring.first_pt + e + 1];
-                if (max(p1.y, p2.y) < ybase || min(p1.y, p2.y) >= ybase + 63) continue; /* wave-uniform */
-                int32_t xmn, xmx;
-                if (osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, y, &xmn, &xmx)) {
-                    if (cnt < (uint32_t)ROWCAP) {
-                        sh.xmin[cnt][lane] = xmn;
-                        sh.xmax[cnt][lane] = xmx;
-                    }
-                    ++cnt;
-                }
-            }
-            e_base += ne;
-        }
-        if (cnt <= (uint32_t)ROWCAP) {
-            /* stable insertion sort by x_min: equal keys keep edge order (fill.rs:24-25) */
-            for (uint32_t i = 1; i < cnt; ++i) {
-                const int32_t kx = sh.xmin[i][lane], km = sh.xmax[i][lane];
-                int32_t j = (int32_t)i - 1;
-                while (j >= 0 && sh.xmin[j][lane] > kx) {
-                    sh.xmin[j + 1][lane] = sh.xmin[j][lane];
-                    sh.xmax[j + 1][lane] = sh.xmax[j][lane];
-                    --j;
-                }
-                sh.xmin[j + 1][lane] = kx;
-                sh.xmax[j + 1][lane] = km;
+                                               const osmt_blk_bbox* __restrict__ g_blk, uint32_t scale, uint32_t sub_rows,
+                                               uint32_t* __restrict__ g_submask, uint32_t* __restrict__ g_fmask,
+                                               const uint32_t* __restrict__ g_op_job, uint32_t* __restrict__ g_cnt) {
+    const uint32_t o_first = group * FILL_GROUP;
+    const uint32_t n_sub_x = OSMT_TILE_SIZE * scale / SUB;
+    /* the group's ops and their sub-tile rows: slot t of the group = (op k, sub-tile row sr0_k + t - base_k) */
+    uint32_t g_geom[FILL_GROUP], g_arena[FILL_GROUP], g_base[FILL_GROUP + 1];
+    g_base[0] = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < FILL_GROUP; ++k) {
+        uint32_t geom = 0u, arena = 0u;
+        if (o_first + k < n_ops) {
+            const osmt_opinfo* __restrict__ oi = &g_info[o_first + k];
+            const uint32_t kind = oi->kind;
+            if (kind == OSMT_OP_FILL_COLOR || kind == OSMT_OP_FILL_IMAGE) {
+                geom = oi->fill_geom; /* nsr == 0: no covered row inside the tile */
+                arena = oi->arena_off;
             }
         }
-        uint32_t hit0 = 0u, hit1 = 0u, hit2 = 0u, hit3 = 0u; /* per sub-tile row of the pass: columns with coverage */
-        for (uint32_t c = 0; c < ncols; ++c) {
-            const int32_t x0 = (int32_t)((c0 + c) * SUB), x1 = x0 + SUB - 1;
-            uint32_t m = 0u;
-            if (cnt <= (uint32_t)ROWCAP) {
-                for (uint32_t k = 0; k + 1u < cnt; k += 2u) { /* fill.rs:27-45: pairs; an odd trailing record is ignored */
-                    const int32_t from = max(sh.xmin[k][lane], x0);
-                    const int32_t to = min(sh.xmax[k + 1u][lane], x1);
-                    if (from <= to) {
-                        const uint32_t len = (uint32_t)(to - from + 1);
-                        const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                        m |= bits << (uint32_t)(from - x0);
+        g_geom[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom);
+        g_arena[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)arena);
+        g_base[k + 1] = g_base[k] + (g_geom[k] >> 24);
+    }
+    const uint32_t n_slots = g_base[FILL_GROUP];
+    if (n_slots == 0u) return;
+    sh.rowfill[lane] = 0u;
+    sh.diff[lane] = 0;
+    if (lane == 0u) sh.diff[64] = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_slots; t0 += 4u) {
+        /* ---- this lane's row: slot t0 + lane / 16 ---- */
+        const uint32_t t = t0 + (lane >> OSMT_SUB_H_LOG2);
+        const bool row_valid = t < n_slots;
+        uint32_t my_k = 0u;
+#pragma unroll
+        for (uint32_t k = 1; k < FILL_GROUP; ++k)
+            if (t >= g_base[k] && g_base[k] < n_slots) my_k = k;
+        uint32_t geom = g_geom[0], arena = g_arena[0], base = g_base[0];
+#pragma unroll
+        for (uint32_t k = 1; k < FILL_GROUP; ++k)
+            if (my_k == k) {
+                geom = g_geom[k];
+                arena = g_arena[k];
+                base = g_base[k];
+            }
+        const uint32_t my_o = o_first + my_k;
+        const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = row_valid ? (geom >> 16) & 255u : 0u;
+        const uint32_t sr = sr0 + (t - base);
+        const int32_t y = (int32_t)(sr * SUBH + (lane & (SUBH - 1u)));
+        uint32_t row_hit = 0u; /* absolute columns in which this row has coverage */
+
+        /* ---- windows of rows [w0, w0 + ww): halved while the buffers overflow ---- */
+        uint32_t w0 = 0u, ww = 64u;
+        while (w0 < 64u) {
+            const bool in_win = lane >= w0 && lane < w0 + ww;
+            /* ---- step 1: crossing edges of the ops that own rows of the window ---- */
+            uint32_t n_list = 0u, n_cross = 0u;
+            bool overflow = false;
+#pragma unroll 1
+            for (uint32_t k = 0; k < FILL_GROUP; ++k) {
+                /* slots of op k inside this pass and window -> lanes [la, lb) */
+                const uint32_t s_lo = max(g_base[k], t0), s_hi = min(g_base[k + 1], t0 + 4u);
+                if (s_lo >= s_hi) continue;
+                const uint32_t la = max((s_lo - t0) * SUBH, w0), lb = min((s_hi - t0) * SUBH, w0 + ww);
+                if (la >= lb) continue;
+                const uint32_t o = o_first + k;
+                /* row of lane l of this op: (sr0_k + t0 + l / 16 - base_k) * 16 + l % 16 = ybase + l */
+                const int32_t ybase = ((int32_t)(g_geom[k] & 255u) + (int32_t)t0 - (int32_t)g_base[k]) * SUBH;
+                const int32_t ya = ybase + (int32_t)la, yb = ybase + (int32_t)lb - 1;
+                const osmt_op* __restrict__ op = &g_ops[o];
+                const uint32_t ring_off = op->ring_off, n_rings = op->n_rings;
+                const uint32_t blk_off = g_op_blk[o];
+                uint32_t ring_cur = 0u, e_base = 0u; /* rings before ring_cur lie entirely behind the current round */
+                for (uint32_t R0 = 0; ring_cur < n_rings; R0 += 64u) {
+                    /* the point of running edge R0 + lane: walk the rings that overlap [R0, R0 + 64) */
+                    const uint32_t E = R0 + lane;
+                    uint32_t pt = 0xFFFFFFFFu;
+                    while (ring_cur < n_rings) {
+                        const osmt_ring ring = g_rings[ring_off + ring_cur];
+                        const uint32_t ne = ring.n_pts >= 2u ? ring.n_pts - 1u : 0u;
+                        if (E >= e_base && E < e_base + ne) pt = ring.first_pt + (E - e_base);
+                        if (e_base + ne > R0 + 64u) break; /* the ring goes on in the next round */
+                        e_base += ne;
+                        ++ring_cur;
+                    }
+                    if (blk_off != 0xFFFFFFFFu) {
+                        const osmt_blk_bbox bb = g_blk[blk_off + (R0 >> 6)];
+                        if (bb.y1 < ya || bb.y0 >= yb) continue; /* rows with records of an edge: ytop < y <= ybot */
+                    }
+                    uint32_t cnt = 0u;
+                    int32_t first = 0;
+                    int2 p1 = make_int2(0, 0), p2 = p1;
+                    if (pt != 0xFFFFFFFFu) {
+                        p1 = g_pts[pt];
+                        p2 = g_pts[pt + 1u];
+                        const int32_t ytop = min(p1.y, p2.y), ybot = max(p1.y, p2.y);
+                        first = max(ytop + 1, ya);
+                        const int32_t last = min(ybot, yb);
+                        cnt = last >= first ? (uint32_t)(last - first + 1) : 0u;
+                    }
+                    const unsigned long long has = __ballot(cnt != 0u);
+                    if (has == 0ull) continue;
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    const uint32_t pos = n_list + (uint32_t)__popcll(has & ((1ull << lane) - 1ull));
+                    n_list += (uint32_t)__popcll(has);
+                    const uint32_t n_before = n_cross;
+                    n_cross += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (n_list > FILL_EMAX || n_cross > FILL_RMAX) {
+                        overflow = true;
+                        continue; /* keep walking the rings (cheap); nothing more is stored */
+                    }
+                    if (cnt != 0u && !overflow) {
+                        sh.e_p1[pos] = p1;
+                        sh.e_p2[pos] = p2;
+                        sh.e_y0[pos] = first;
+                        const uint32_t l0 = la + (uint32_t)(first - ya);
+                        sh.e_lane0[pos] = l0;
+                        sh.e_pre[pos] = n_before + incl;
+                        sh.e_key[pos] = E;
+                        atomicAdd(&sh.diff[l0], 1);
+                        atomicAdd(&sh.diff[l0 + cnt], -1);
                     }
                 }
-            } else {
-                /* more than ROWCAP crossings on this row: storage-free streaming (cold, out of line) */
-                m = fill_row_streaming(g_rings, g_pts, ring_off, n_rings, y, x0, x1);
             }
-            if (row_valid) g_fmask[((size_t)arena + (size_t)(sr - sr0) * ncols + c) * SUBH + (lane & (SUBH - 1u))] = m;
-            const unsigned long long bal = __ballot(row_valid && m != 0u);
-            const uint32_t bit = 1u << (c0 + c);
-            if (bal & 0x000000000000FFFFull) hit0 |= bit;
-            if (bal & 0x00000000FFFF0000ull) hit1 |= bit;
-            if (bal & 0x0000FFFF00000000ull) hit2 |= bit;
-            if (bal & 0xFFFF000000000000ull) hit3 |= bit;
+            __syncthreads();
+            /* ---- step 1b: crossings per row and the rows' segments of the record buffer ---- */
+            const int32_t d = sh.diff[lane];
+            sh.diff[lane] = 0;
+            if (lane == 0u) sh.diff[64] = 0;
+            if (overflow) {
+                __syncthreads(); /* the cleared array before the next step 1 */
+                if (ww > 1u) {
+                    ww >>= 1; /* too many for the buffers: the window's first half, then the rest */
+                    continue;
+                }
+                /* a single row beyond the buffers: storage-free streaming (cold) */
+                if (in_win && row_valid) {
+                    const osmt_op* __restrict__ op = &g_ops[my_o];
+                    for (uint32_t c = 0; c < ncols; ++c) {
+                        const int32_t x0 = (int32_t)((c0 + c) * SUB);
+                        const uint32_t m = fill_row_streaming(g_rings, g_pts, op->ring_off, op->n_rings, y, x0, x0 + SUB - 1);
+                        g_fmask[((size_t)arena + (size_t)(sr - sr0) * ncols + c) * SUBH + (lane & (SUBH - 1u))] = m;
+                        if (m) row_hit |= 1u << (c0 + c);
+                    }
+                }
+            }
+            if (!overflow) {
+                const uint32_t rc_incl = wave_incl_scan((uint32_t)d); /* running sum of the difference array = crossings of the row */
+                const uint32_t rowcnt = in_win ? rc_incl : 0u;
+                const uint32_t rowstart = wave_incl_scan(rowcnt) - rowcnt;
+                sh.rowstart[lane] = rowstart;
+                __syncthreads();
+                /* ---- step 2: one closed form per crossing ---- */
+                for (uint32_t i = lane; i < n_cross; i += 64u) {
+                    uint32_t lo = 0u, n = n_list;
+                    while (n > 1u) { /* first edge whose inclusive count exceeds i */
+                        const uint32_t half = n >> 1;
+                        const bool right = sh.e_pre[lo + half - 1u] <= i;
+                        lo = right ? lo + half : lo;
+                        n = right ? n - half : half;
+                    }
+                    const uint32_t kk = i - (lo ? sh.e_pre[lo - 1u] : 0u);
+                    const int2 p1 = sh.e_p1[lo], p2 = sh.e_p2[lo];
+                    const uint32_t L = sh.e_lane0[lo] + kk;
+                    int32_t xmn = 0, xmx = 0;
+                    osmt_fill_row_extent(p1.x, p1.y, p2.x, p2.y, sh.e_y0[lo] + (int32_t)kk, &xmn, &xmx); /* crosses by construction */
+                    const uint32_t at = sh.rowstart[L] + atomicAdd(&sh.rowfill[L], 1u);
+                    sh.r_xmin[at] = xmn;
+                    sh.r_xmax[at] = xmx;
+                    sh.r_key[at] = sh.e_key[lo];
+                }
+                __syncthreads();
+                sh.rowfill[lane] = 0u;
+                if (in_win && row_valid) {
+                    /* ---- step 3: stable order of the row's records (fill.rs:24-25): by x_min, ties by edge index ---- */
+                    for (uint32_t i = 1; i < rowcnt; ++i) {
+                        const int32_t kx = sh.r_xmin[rowstart + i], km = sh.r_xmax[rowstart + i];
+                        const uint32_t ke = sh.r_key[rowstart + i];
+                        int32_t j = (int32_t)i - 1;
+                        while (j >= 0) {
+                            const int32_t jx = sh.r_xmin[rowstart + (uint32_t)j];
+                            const uint32_t je = sh.r_key[rowstart + (uint32_t)j];
+                            if (!(jx > kx || (jx == kx && je > ke))) break;
+                            sh.r_xmin[rowstart + (uint32_t)j + 1u] = jx;
+                            sh.r_xmax[rowstart + (uint32_t)j + 1u] = sh.r_xmax[rowstart + (uint32_t)j];
+                            sh.r_key[rowstart + (uint32_t)j + 1u] = je;
+                            --j;
+                        }
+                        sh.r_xmin[rowstart + (uint32_t)(j + 1)] = kx;
+                        sh.r_xmax[rowstart + (uint32_t)(j + 1)] = km;
+                        sh.r_key[rowstart + (uint32_t)(j + 1)] = ke;
+                    }
+                    for (uint32_t c = 0; c < ncols; ++c) {
+                        const int32_t x0 = (int32_t)((c0 + c) * SUB), x1 = x0 + SUB - 1;
+                        uint32_t m = 0u;
+                        for (uint32_t k2 = 0; k2 + 1u < rowcnt; k2 += 2u) { /* fill.rs:27-45: pairs; an odd trailing record is ignored */
+                            const int32_t from = max(sh.r_xmin[rowstart + k2], x0);
+                            const int32_t to = min(sh.r_xmax[rowstart + k2 + 1u], x1);
+                            if (from <= to) {
+                                const uint32_t len = (uint32_t)(to - from + 1);
+                                const uint32_t bits = (len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                                m |= bits << (uint32_t)(from - x0);
+                            }
+                        }
+                        g_fmask[((size_t)arena + (size_t)(sr - sr0) * ncols + c) * SUBH + (lane & (SUBH - 1u))] = m;
+                        if (m) row_hit |= 1u << (c0 + c);
+                    }
+                }
+                __syncthreads(); /* the record buffer and the edge list are rewritten by the next window */
+            }
+            w0 += ww;
+            while (ww < 64u && (w0 & (2u * ww - 1u)) == 0u) ww <<= 1; /* both halves done: the wider window again */
         }
-        if (lane == 0u) {
-            uint32_t* sm = g_submask + (size_t)o * sub_rows + srb;
-            sm[0] = hit0;
-            if (srb + 1u < sr0 + nsr) sm[1] = hit1;
-            if (srb + 2u < sr0 + nsr) sm[2] = hit2;
-            if (srb + 3u < sr0 + nsr) sm[3] = hit3;
-        }
-        /* one more op for the list of every sub-tile hit (k_sublist sizes its lists from these counts): lane = column */
-        if (lane < n_sub_x) {
-            uint32_t* ct = g_cnt_tile + (size_t)srb * n_sub_x + lane;
-            if ((hit0 >> lane) & 1u) atomicAdd(ct, 1u);
-            if ((hit1 >> lane) & 1u) atomicAdd(ct + n_sub_x, 1u);
-            if ((hit2 >> lane) & 1u) atomicAdd(ct + 2u * n_sub_x, 1u);
-            if ((hit3 >> lane) & 1u) atomicAdd(ct + 3u * n_sub_x, 1u);
+        /* ---- the slot's sub-tile bits: OR over its 16 rows (DPP shifts inside the row of 16 lanes) ---- */
+        uint32_t hm = row_hit;
+        hm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0x111, 0xF, 0xF, false);
+        hm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0x112, 0xF, 0xF, false);
+        hm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0x114, 0xF, 0xF, false);
+        hm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0x118, 0xF, 0xF, false);
+        if (row_valid && (lane & (SUBH - 1u)) == SUBH - 1u) {
+            g_submask[(size_t)my_o * sub_rows + sr] = hm;
+            /* one more op for the list of every sub-tile hit (k_sublist sizes its lists from these counts) */
+            uint32_t* ct = g_cnt + ((size_t)g_op_job[my_o] * sub_rows + sr) * n_sub_x;
+            while (hm) {
+                atomicAdd(ct + (uint32_t)__builtin_ctz(hm), 1u);
+                hm &= hm - 1u;
+            }
         }
     }
 }
@@ -1064,9 +1209,9 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
     }
 }
 
-/* Both binning kernels in ONE launch: blocks [0, n_vblk) bin 64 stroke segments each (latency-bound: bisection, a chain
- * of dependent loads, scattered 80-byte stores), blocks [n_vblk, n_vblk + n_ops) build the coverage rows of one fill op
- * each (issue-bound) — the two kinds overlap on the machine instead of running back to back. */
+/* Both binning jobs in ONE launch: blocks [0, n_vblk) bin 64 stroke segments each (latency-bound: a bisection, a chain
+ * of dependent loads, scattered 72-byte stores), the rest build the coverage rows of FILL_GROUP ops each (issue-bound) —
+ * the two kinds overlap on the machine instead of running back to back. */
 __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
@@ -1078,18 +1223,21 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
                                                uint32_t* __restrict__ g_cnt) {
-    __shared__ FillRowsShared sh;
+    __shared__ FillShared sh;
     const uint32_t b = blockIdx.x;
+#if defined(OSMT_ABL) && OSMT_ABL == 9
+    if (b < n_vblk) return; /* ablation: no stroke binning */
+#endif
+#if defined(OSMT_ABL) && OSMT_ABL == 10
+    if (b >= n_vblk) return; /* ablation: no fill rows */
+#endif
     if (b < n_vblk)
-        stroke_bin_body(reinterpret_cast<uint32_t*>(&sh.xmin[0][0]), b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
+        stroke_bin_body(reinterpret_cast<uint32_t*>(&sh.r_xmin[0]), b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
                         g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey,
                         g_op_job, g_cnt);
-    else if (b - n_vblk < n_ops) {
-        const uint32_t o = b - n_vblk;
-        const uint32_t n_sub_x = OSMT_TILE_SIZE * scale / SUB;
-        fill_rows_body(sh, o, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, g_submask, sub_rows, g_fmask,
-                       g_cnt + (size_t)g_op_job[o] * sub_rows * n_sub_x, n_sub_x);
-    }
+    else
+        fill_rows_body(sh, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
+                       g_op_job, g_cnt);
 }
 
 /* ---- k_sublist: the op bits turned round — one ordered list per (tile, sub-tile) ------------------------------------
@@ -1792,9 +1940,10 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
     if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
-    if (a.n_ops) hipLaunchKernelGGL(k_prebin, dim3(n_vblk + a.n_ops), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts, a.trav, a.den, a.rden, a.aux,
-                       a.op_blk, a.blk, a.vseg_base, a.vseg_blk_slot, a.stroke_op, a.n_strokes, a.n_vsegs, n_vblk, a.scale, a.sub_rows,
-                       a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
+    if (a.n_ops)
+        hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
+                           a.trav, a.den, a.rden, a.aux, a.op_blk, a.blk, a.vseg_base, a.vseg_blk_slot, a.stroke_op, a.n_strokes, a.n_vsegs, n_vblk,
+                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
     if (a.n_jobs) /* also without a single op: k_raster reads the (empty) list headers */
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
                            a.cursors + 2, a.hdr, a.ent, a.ent_cap);
