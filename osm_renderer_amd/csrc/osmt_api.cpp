@@ -394,7 +394,30 @@ hipError_t scene_wait_idle(osmt_scene* sc) {
     return first;
 }
 
-int validate_batch(const osmt_batch* b) {
+/* the coordinate scan of validate_batch: independent of everything else, O(n_pts) — big uploads run it on a helper thread
+ * beside the host-table building and the copies (validate_coords_range is what the thread calls on its slice) */
+int validate_coords_range(const osmt_batch* b, size_t lo, size_t hi) {
+    if (b->coord_kind == OSMT_COORD_POINT_I32) {
+        for (size_t i = 2 * lo; i < 2 * hi; ++i)
+            if (b->points[i] > OSMT_COORD_LIMIT || b->points[i] < -OSMT_COORD_LIMIT)
+                return fail(OSMT_UNSUPPORTED, "point %zu: |coordinate| > 2^28", i / 2);
+    } else {
+        /* The closed forms and the Bresenham state of the kernels need |pixel coordinate| <= 2^28 (osmt_geom.h); with
+         * zoom <= 18 and scale <= 4 that holds for every (lat, lon) of the Web-Mercator square.  Outside it (or for a
+         * NaN / infinity) Point::from_node saturates (point.rs:11-19) and the integer walks would overflow. */
+        const double* ll = b->coord_kind == OSMT_COORD_NODE_REF ? b->nodes : b->latlon;
+        for (size_t i = lo; i < hi; ++i) {
+            const double lat = ll[2 * i], lon = ll[2 * i + 1];
+            if (!(std::fabs(lat) <= OSMT_MAX_ABS_LAT) || !(std::fabs(lon) <= 180.0))
+                return fail(OSMT_UNSUPPORTED, "point %zu: (lat, lon) = (%g, %g) outside the Web-Mercator square (|lat| <= %g, |lon| <= 180)", i, lat,
+                            lon, OSMT_MAX_ABS_LAT);
+        }
+    }
+    return OSMT_OK;
+}
+size_t coord_count(const osmt_batch* b) { return b->coord_kind == OSMT_COORD_NODE_REF ? b->n_nodes : b->n_pts; }
+
+int validate_batch(const osmt_batch* b, bool with_coords = true) {
     if (!b) return fail(OSMT_INVALID_ARG, "batch is NULL");
     if (b->scale < 1 || b->scale > OSMT_MAX_SCALE) return fail(OSMT_INVALID_ARG, "scale %u not in 1..%u", b->scale, OSMT_MAX_SCALE);
     if (b->coord_kind != OSMT_COORD_LATLON_F64 && b->coord_kind != OSMT_COORD_POINT_I32 && b->coord_kind != OSMT_COORD_NODE_REF)
@@ -467,23 +490,7 @@ int validate_batch(const osmt_batch* b) {
             }
         }
     }
-    if (b->coord_kind == OSMT_COORD_POINT_I32) {
-        for (size_t i = 0; i < 2 * b->n_pts; ++i)
-            if (b->points[i] > OSMT_COORD_LIMIT || b->points[i] < -OSMT_COORD_LIMIT)
-                return fail(OSMT_UNSUPPORTED, "point %zu: |coordinate| > 2^28", i / 2);
-    } else {
-        /* The closed forms and the Bresenham state of the kernels need |pixel coordinate| <= 2^28 (osmt_geom.h); with
-         * zoom <= 18 and scale <= 4 that holds for every (lat, lon) of the Web-Mercator square.  Outside it (or for a
-         * NaN / infinity) Point::from_node saturates (point.rs:11-19) and the integer walks would overflow. */
-        const double* ll = b->coord_kind == OSMT_COORD_NODE_REF ? b->nodes : b->latlon;
-        const size_t n = b->coord_kind == OSMT_COORD_NODE_REF ? b->n_nodes : b->n_pts;
-        for (size_t i = 0; i < n; ++i) {
-            const double lat = ll[2 * i], lon = ll[2 * i + 1];
-            if (!(std::fabs(lat) <= OSMT_MAX_ABS_LAT) || !(std::fabs(lon) <= 180.0))
-                return fail(OSMT_UNSUPPORTED, "point %zu: (lat, lon) = (%g, %g) outside the Web-Mercator square (|lat| <= %g, |lon| <= 180)", i, lat,
-                            lon, OSMT_MAX_ABS_LAT);
-        }
-    }
+    if (with_coords) return validate_coords_range(b, 0, coord_count(b));
     return OSMT_OK;
 }
 
@@ -734,9 +741,46 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
 static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st, bool trusted = false) {
     if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out_scene = nullptr;
-    int rc = trusted ? OSMT_OK : validate_batch(b);
+    /* Big uploads: the O(n_pts) coordinate scan runs on helper threads while this one builds the index tables and feeds
+     * the copies (they do not depend on it); the verdict is collected before the first kernel can be launched. */
+    const bool big = b && coord_count(b) >= ((size_t)1 << 16);
+    int rc = trusted ? OSMT_OK : validate_batch(b, !big);
     if (rc != OSMT_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    struct coord_check {
+        std::vector<std::thread> th;
+        std::vector<int> rc;
+        std::vector<std::string> msg;
+        int join() { /* first failing slice wins: the message names the lowest point index */
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+            for (size_t i = 0; i < rc.size(); ++i)
+                if (rc[i] != OSMT_OK) return fail(rc[i], "%s", msg[i].c_str());
+            return OSMT_OK;
+        }
+        ~coord_check() {
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+        }
+    } cc;
+    if (big && !trusted) {
+        const size_t n = coord_count(b);
+        const unsigned n_thr = n >= ((size_t)1 << 19) ? 2u : 1u;
+        cc.rc.assign(n_thr, OSMT_OK);
+        cc.msg.resize(n_thr);
+        for (unsigned t = 0; t < n_thr; ++t) {
+            const size_t lo = n * t / n_thr, hi = n * (t + 1) / n_thr;
+            try {
+                cc.th.emplace_back([&cc, b, t, lo, hi] {
+                    cc.rc[t] = guarded([&] { return validate_coords_range(b, lo, hi); });
+                    if (cc.rc[t] != OSMT_OK) cc.msg[t] = osmt_last_error();
+                });
+            } catch (...) { /* no thread to be had: scan here */
+                cc.rc[t] = validate_coords_range(b, lo, hi);
+                if (cc.rc[t] != OSMT_OK) cc.msg[t] = osmt_last_error();
+            }
+        }
+    }
 
     osmt_scene* s = new (std::nothrow) osmt_scene();
     if (!s) return fail(OSMT_OOM, "out of host memory");
@@ -746,7 +790,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     std::vector<uint32_t>& op_aux = s->h_op_aux;
     std::vector<uint32_t>& op_blk = s->h_op_blk;
     std::vector<uint32_t>& op_vseg = s->h_op_vseg;
-    pt_job.assign(b->n_pts, 0xFFFFFFFFu);
+    const bool host_pt_job = !big; /* big uploads fill point -> job on the device (k_ptjob): no 4 B/point host loop and copy */
+    if (host_pt_job) pt_job.assign(b->n_pts, 0xFFFFFFFFu);
     op_aux.assign(b->n_ops, 0u);
     op_blk.assign(b->n_ops, 0xFFFFFFFFu);
     op_vseg.assign(b->n_ops, 0u);
@@ -763,7 +808,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     size_t n_vsegs = 0, n_fills = 0;
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
-        for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
+        if (host_pt_job)
+            for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
         for (uint32_t k = 0; k < job.n_ops; ++k) {
             const osmt_op& op = b->ops[job.op_off + k];
             op_job[job.op_off + k] = (uint32_t)j;
@@ -908,7 +954,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         if (nr) put(o_refs, b->node_refs, b->n_pts * 4);
         if (!ll && !nr) put(o_pts, b->points, b->n_pts * 8);
         put(o_dashes, b->dashes, b->n_dashes * 8);
-        put(o_ptjob, pt_job.data(), b->n_pts * 4);
+        if (host_pt_job) put(o_ptjob, pt_job.data(), b->n_pts * 4);
         put(o_opaux, op_aux.data(), b->n_ops * 4);
         put(o_opblk, op_blk.data(), b->n_ops * 4);
         put(o_opvseg, op_vseg.data(), b->n_ops * 4);
@@ -918,13 +964,15 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         put(o_blkslot, blk_slot.data(), blk_slot.size() * 4);
         s->h_stage = stage;
         err = hipMemcpyAsync(s->d_base, stage, front_bytes, hipMemcpyHostToDevice, st);
+        if (err == hipSuccess && !host_pt_job) err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st);
         if (err != hipSuccess) {
             stage_release(ctx, stage);
             dev_free(ctx, s->d_base);
             scene_delete(s);
             return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
         }
-        rc = scene_size_arenas(ctx, s, n_fills);
+        rc = cc.join(); /* no kernel has seen the coordinates yet */
+        if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
         if (rc != OSMT_OK) {
             osmt_scene_free(s);
             return rc;
@@ -940,7 +988,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess && nr) err = up(s->d_node_refs, b->node_refs, b->n_pts * 4);
     if (err == hipSuccess && !ll && !nr) err = up(s->d_pts, b->points, b->n_pts * 8);
     if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
-    if (err == hipSuccess) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
+    if (err == hipSuccess && host_pt_job) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
+    if (err == hipSuccess && !host_pt_job) err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st ? st : nullptr);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_vseg, op_vseg.data(), b->n_ops * 4);
@@ -953,7 +1002,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
-    rc = scene_size_arenas(ctx, s, n_fills);
+    rc = cc.join(); /* no kernel has seen the coordinates yet */
+    if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
     if (rc != OSMT_OK) {
         osmt_scene_free(s);
         return rc;
@@ -1450,6 +1500,10 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
     return guarded([&] { return osmt_encode_png_device_body(ctx, d_rgba, tile_stride, n, W, H, d_png, png_stride, d_len, stream); });
 }
 
+/* One call, its own pipeline.  The pre-pass runs once for the whole batch; then the tiles go through raster -> PNG
+ * encode -> file lengths in CHUNKS on the call's stream, all enqueued up front.  The host walks the chunks behind the
+ * GPU: as soon as a chunk's lengths are back it sums the file offsets and queues that chunk's compaction and read-back
+ * on a second stream — the PCIe transfer of chunk c runs under the kernels of chunk c + 1. */
 static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off) {
     if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
@@ -1466,8 +1520,21 @@ static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, co
     const uint32_t n = (uint32_t)batch->n_jobs;
     const uint32_t W = OSMT_TILE_SIZE * batch->scale;
     const size_t tile_bytes = (size_t)W * W * 4, slot = osmt_png_device_bound(W, W);
+    /* the encoder is one workgroup per tile: below ~2 workgroups per CU it is latency-bound and a chunk costs more than
+     * its overlap brings (measured on 1024 tiles: 1 chunk 4.21 ms, 2 chunks 4.10, 4 chunks 4.82, 8 chunks 7.07) */
+    const uint32_t min_chunk = std::max<uint32_t>(1u, 512u / (batch->scale * batch->scale));
+    uint32_t chunk = n;
+    if (n >= 2u * min_chunk) chunk = std::max<uint32_t>(min_chunk, (n + 1u) / 2u);
+    if (const char* ev_chunks = getenv("OSMT_PNG_CHUNKS")) { /* diagnostic: force the number of chunks */
+        const uint32_t k = (uint32_t)std::max(1, atoi(ev_chunks));
+        chunk = std::max<uint32_t>(1u, (n + k - 1u) / k);
+    }
+    const uint32_t n_chunks = n ? (n + chunk - 1u) / chunk : 0u;
     char* d = nullptr;
-    size_t o_rgba = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0, total = 0;
+    uint32_t* h_len = nullptr;       /* pinned: lengths come back asynchronously, offsets go out */
+    size_t o_rgba = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0;
+    hipStream_t s_c = nullptr;
+    std::vector<hipEvent_t> ev(n_chunks, nullptr);
     if (rc == OSMT_OK && n) {
         size_t off = 0;
         auto carve = [&](size_t bytes) {
@@ -1475,38 +1542,85 @@ static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, co
             off = align_up(off + bytes, 256);
             return o;
         };
-        o_rgba = carve(n * tile_bytes);
-        o_png = carve(n * slot);
-        o_len = carve(n * 4);
-        o_off = carve(n * 8);
-        o_blob = o_rgba; /* the framebuffers are dead once encoded, and a PNG slot (<= 0.85 x RGBA8) never outgrows them */
+        o_rgba = carve((size_t)std::min<uint32_t>(2u, n_chunks) * chunk * tile_bytes); /* two chunks of framebuffers, alternating */
+        o_png = carve((size_t)n * slot);
+        o_len = carve((size_t)n * 4);
+        o_off = carve((size_t)n * 8);
+        o_blob = carve((size_t)n * slot);
         hipError_t e = dev_alloc(ctx, (void**)&d, off);
         if (e != hipSuccess) rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+        if (rc == OSMT_OK) {
+            h_len = (uint32_t*)stage_acquire(ctx, (size_t)n * 12 + 16);
+            if (!h_len) rc = fail(OSMT_OOM, "pinned staging for %u file lengths", n);
+        }
+        if (rc == OSMT_OK && n_chunks > 1u) {
+            e = stream_acquire(ctx, &s_c);
+            if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "stream: %s", hipGetErrorString(e));
+        }
+        for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
+            e = hipEventCreateWithFlags(&ev[c], hipEventDisableTiming);
+            if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "event: %s", hipGetErrorString(e));
+        }
     }
-    std::vector<uint32_t> len(n);
-    std::vector<unsigned long long> offs(n + 1, 0ull);
-    if (rc == OSMT_OK && n) rc = render_impl(ctx, sc, 7u, d + o_rgba, tile_bytes, false, st);
-    if (rc == OSMT_OK && n) rc = osmt_encode_png_device(ctx, d + o_rgba, tile_bytes, n, W, W, d + o_png, slot, (uint32_t*)(d + o_len), st);
+    std::vector<unsigned long long> offs((size_t)n + 1, 0ull);
+    unsigned long long* const h_off = h_len ? reinterpret_cast<unsigned long long*>(h_len + ((n + 1u) & ~1u)) : nullptr; /* chunk-relative offsets */
+    hipStream_t s_copy = s_c ? s_c : st;
+    hipError_t e = hipSuccess;
     if (rc == OSMT_OK && n) {
-        hipError_t e = hipMemcpyAsync(len.data(), d + o_len, n * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + len[i];
-        total = (size_t)offs[n];
-        if (e == hipSuccess && total > out_capacity) {
-            rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %zu bytes of PNG data", out_capacity, total);
-        } else {
-            if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, offs.data(), n * 8, hipMemcpyHostToDevice, st);
+        /* ---- everything the GPU has to do, queued at once ---- */
+        rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, st);
+        for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
+            const uint32_t first = c * chunk, cnt = std::min(chunk, n - first);
+            char* rgba = d + o_rgba + (size_t)(c & 1u) * chunk * tile_bytes;
+            rc = render_impl(ctx, sc, 4u | 16u, rgba, tile_bytes, false, st, first, cnt);
+            if (rc == OSMT_OK)
+                rc = osmt_encode_png_device(ctx, rgba, tile_bytes, cnt, W, W, d + o_png + (size_t)first * slot, slot, (uint32_t*)(d + o_len) + first, st);
+            if (rc == OSMT_OK) {
+                e = hipMemcpyAsync(h_len + first, d + o_len + (size_t)first * 4, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipEventRecord(ev[c], st);
+                if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
+            }
+        }
+        /* ---- the host follows chunk by chunk ---- */
+        bool fits = true;
+        for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
+            const uint32_t first = c * chunk, cnt = std::min(chunk, n - first);
+            e = hipEventSynchronize(ev[c]);
+            if (e != hipSuccess) {
+                rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
+                break;
+            }
+            for (uint32_t i = 0; i < cnt; ++i) {
+                h_off[first + i] = offs[first + i] - offs[first];
+                offs[first + i + 1] = offs[first + i] + h_len[first + i];
+            }
+            const size_t c_bytes = (size_t)(offs[first + cnt] - offs[first]);
+            if (offs[first + cnt] > out_capacity) fits = false; /* keep summing: the caller learns the size it needs */
+            if (!fits || c_bytes == 0) continue;
+            char* blob = d + o_blob + (size_t)first * slot;
+            e = hipMemcpyAsync(d + o_off + (size_t)first * 8, h_off + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s_copy);
             if (e == hipSuccess)
-                e = osmt_launch_png_compact(d + o_png, slot, (const uint32_t*)(d + o_len), (const unsigned long long*)(d + o_off), n, d + o_blob, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(out_png, d + o_blob, total, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
+                e = osmt_launch_png_compact(d + o_png + (size_t)first * slot, slot, (const uint32_t*)(d + o_len) + first,
+                                            (const unsigned long long*)(d + o_off) + first, cnt, blob, s_copy);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_png + offs[first], blob, c_bytes, hipMemcpyDeviceToHost, s_copy);
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
         }
+        if (s_c) {
+            e = hipStreamSynchronize(s_c);
+            if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
+        }
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
+        if (rc == OSMT_OK && !fits) rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %llu bytes of PNG data", out_capacity, offs[n]);
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
+    for (hipEvent_t v : ev)
+        if (v) (void)hipEventDestroy(v);
     osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d);
+    if (h_len) stage_release(ctx, h_len);
+    if (s_c) stream_release(ctx, s_c);
     stream_release(ctx, st);
     return rc;
 }

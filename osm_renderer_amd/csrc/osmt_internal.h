@@ -273,6 +273,8 @@ struct osmt_prepass_args {
 
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
                                uint32_t n_pts, double scale, int32_t* pts, hipStream_t st);
+/* point -> job table on the device: pt_job[i] = j for the points of job j, 0xFFFFFFFF for points no job owns */
+hipError_t osmt_launch_ptjob(const osmt_tile_job* jobs, uint32_t n_jobs, uint32_t* pt_job, uint32_t n_pts, hipStream_t st);
 hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
                                       double scale, int32_t* pts, hipStream_t st);
 /* k_opinfo -> k_fill_rows -> k_stroke_bin on `st` (sizing pass: k_opinfo only) */

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(256) void k_project(const osmt_tile_job* __restrict
     pts[i] = make_int2(x, y);
 }
 
+/* point -> job (big uploads build the table here instead of on the host): one block per job */
+__global__ __launch_bounds__(256) void k_ptjob(const osmt_tile_job* __restrict__ jobs, uint32_t* __restrict__ pt_job) {
+    const osmt_tile_job job = jobs[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < job.n_pts; i += 256u) pt_job[job.pt_off + i] = blockIdx.x;
+}
+
 /* One point, explicit tile (osmt_project). */
 __global__ __launch_bounds__(256) void k_project_single(const double2* __restrict__ latlon, uint32_t n, uint32_t zoom,
                                                         uint32_t tx, uint32_t ty, double scale,
@@ -1920,6 +1926,14 @@ hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job
     if (n_pts == 0) return hipSuccess;
     hipLaunchKernelGGL(k_project, dim3((n_pts + 255u) / 256u), dim3(256), 0, st, jobs, pt_job,
                        reinterpret_cast<const double2*>(latlon), refs, n_pts, scale, reinterpret_cast<int2*>(pts));
+    return hipGetLastError();
+}
+
+hipError_t osmt_launch_ptjob(const osmt_tile_job* jobs, uint32_t n_jobs, uint32_t* pt_job, uint32_t n_pts, hipStream_t st) {
+    if (n_pts == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(pt_job, 0xFF, (size_t)n_pts * 4, st);
+    if (e != hipSuccess) return e;
+    if (n_jobs) hipLaunchKernelGGL(k_ptjob, dim3(n_jobs), dim3(256), 0, st, jobs, pt_job);
     return hipGetLastError();
 }
 

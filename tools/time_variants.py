@@ -39,8 +39,13 @@ def run(name, dl, reps):
 run("config2", synth.config2(1024), 10)
 run("raster_2x", synth.config3(256), 5)
 run("config5", synth.config5(64), 3)
+if %r:
+    run("config5_256", synth.config5(256), 3)
 print(json.dumps(res))
 '''
+
+
+BIG = bool(os.environ.get("OSMT_TIME_BIG"))
 
 
 def main():
@@ -51,7 +56,7 @@ def main():
             continue
         env = dict(os.environ, OSMT_LIB=lib)
         try:
-            r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, BIG)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             line = r.stdout.decode().strip().splitlines()[-1] if r.stdout.strip() else ""
             d = json.loads(line)
             print(v, " ".join(f"{k}: pre {x['prepass_ms']:.3f} ras {x['raster_ms']:.3f} ms ({x['tiles_per_s']:.0f} t/s, sum {x['checksum']})" for k, x in d.items()), flush=True)
