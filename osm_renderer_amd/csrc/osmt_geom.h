@@ -160,22 +160,22 @@ OSMT_HD int osmt_fill_row_extent(int32_t p1x, int32_t p1y, int32_t p2x, int32_t 
     int64_t i0, i1;
     if (a < 2048 && b < 2048) {
         /* short edge: (2j+1)a + 2b - 1 < 2^24 and every quotient is <= a < 2^11: both divisions share the f32
-         * reciprocal of 2b and need one correction round (osmt_udiv24r_small) */
+         * reciprocal of 2b and need one correction round (osmt_udiv24r_small).  Branch-free in the edge's slope — the
+         * lanes of a wave hold different edges, and a branch on x-major / y-major would run both sides for all:
+         *   first = floor(N0 / 2b),  N0 = x-major ? (2j-1)a + 2b - 1  (= ceil((2j-1)a / 2b), 0 for j = 0)
+         *                                         : 2ja + b
+         *   last  = j == b ? a : ceil((2j+1)a / 2b) - 1, and not below `first` for a y-major edge. */
         const int32_t a32 = (int32_t)a, b32 = (int32_t)b, j32 = (int32_t)j;
         const float r2b = osmt_rcp24(2 * b32);
-        int32_t q0, q1;
-        if (a32 >= b32) {
-            q0 = (j32 == 0) ? 0 : osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 - 1, a32), 2 * b32, r2b);
-            q1 = (j32 == b32) ? a32 : osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 + 1, a32), 2 * b32, r2b) - 1;
-        } else {
-            q0 = osmt_udiv24r_small(OSMT_MUL24(2 * j32, a32) + b32, 2 * b32, r2b);
-            if (j32 == b32) {
-                q1 = a32;
-            } else {
-                q1 = osmt_ceil_div_pos24r_small(OSMT_MUL24(2 * j32 + 1, a32), 2 * b32, r2b) - 1;
-                if (q1 < q0) q1 = q0;
-            }
-        }
+        const int32_t xmajor = a32 >= b32;
+        const int32_t ja2 = OSMT_MUL24(2 * j32, a32);
+        int32_t n0 = xmajor ? ja2 - a32 + 2 * b32 - 1 : ja2 + b32;
+        if (xmajor && ja2 - a32 <= 0) n0 = 0; /* osmt_ceil_div_pos: a non-positive numerator gives 0 (j = 0, or a = 0) */
+        const int32_t q0 = osmt_udiv24r_small(n0, 2 * b32, r2b);
+        const int32_t n1 = ja2 + a32; /* (2j+1)a >= 0 */
+        int32_t q1 = (n1 <= 0 ? 0 : osmt_udiv24r_small(n1 + 2 * b32 - 1, 2 * b32, r2b)) - 1;
+        if (!xmajor && q1 < q0) q1 = q0;
+        if (j32 == b32) q1 = a32;
         i0 = q0;
         i1 = q1;
     } else if (a >= b) {

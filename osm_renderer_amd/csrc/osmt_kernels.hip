@@ -1032,6 +1032,9 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
                 sh.rowstart[lane] = rowstart;
                 __syncthreads();
                 /* ---- step 2: one closed form per crossing ---- */
+#if defined(OSMT_ABL) && OSMT_ABL == 11
+                if (false)
+#endif
                 for (uint32_t i = lane; i < n_cross; i += 64u) {
                     uint32_t lo = 0u, n = n_list;
                     while (n > 1u) { /* first edge whose inclusive count exceeds i */
@@ -1052,7 +1055,11 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
                 }
                 __syncthreads();
                 sh.rowfill[lane] = 0u;
+#if defined(OSMT_ABL) && (OSMT_ABL == 11 || OSMT_ABL == 12)
+                if (false) {
+#else
                 if (in_win && row_valid) {
+#endif
                     /* ---- step 3: stable order of the row's records (fill.rs:24-25): by x_min, ties by edge index ---- */
                     for (uint32_t i = 1; i < rowcnt; ++i) {
                         const int32_t kx = sh.r_xmin[rowstart + i], km = sh.r_xmax[rowstart + i];
@@ -1117,7 +1124,24 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
  * op's slice of the stroke arena and sets the op's bit for that sub-tile.  k_raster's waves then only FILTER the
  * records of the ops they meet (one coalesced key load per 64 records) instead of each re-deriving the ranges of
  * every segment of every op that comes near: the work is done once per (segment, sub-tile), with full lanes. */
-__device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /* 65 words of LDS */, const uint32_t blk, const uint32_t lane,
+/* what a segment's lane leaves in LDS for the lanes that work on its (segment, sub-tile) pairs */
+struct StrokeBinSeg {
+    osmt_srec rec;      /* end points, traveled, length, reciprocal (the ranges are filled per pair) */
+    double ft;          /* feather_to of the op: max(|half_width| + 0.5, 1.0) */
+    int32_t sx0, sy0;   /* first sub-tile of the window */
+    uint32_t ncols;     /* window width in sub-tiles */
+    uint32_t slot0;     /* absolute arena slot of the window's first sub-tile */
+    uint32_t op, job;
+    uint32_t is_cap;
+    uint32_t _pad;
+};
+struct StrokeBinShared {
+    uint32_t base[65];
+    uint32_t incl[64]; /* inclusive pair count over the block's segments */
+    StrokeBinSeg seg[64];
+};
+
+__device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint32_t blk, const uint32_t lane,
                                                 const osmt_op* __restrict__ g_ops, const osmt_opinfo* __restrict__ g_info,
                                                 const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
                                                 const double* __restrict__ g_trav, const double* __restrict__ g_den,
@@ -1127,91 +1151,115 @@ __device__ __forceinline__ void stroke_bin_body(uint32_t* __restrict__ sh_base /
                                                 uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
                                                 osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
                                                 uint32_t* __restrict__ g_cnt) {
-    /* slot of every lane's segment: the block's first segment lies in slot s0 (host table), the other 63 in the next
-     * <= 63 slots — one coalesced load of their bases, then a bisection in LDS */
+    /* ---- step A, lane = virtual segment: its op, end points, sub-tile window.  The block's first segment lies in
+     * slot s0 of the host's binning table, the other 63 in the next <= 63 slots: one coalesced load of their bases,
+     * then a bisection in LDS. ---- */
     const uint32_t g = blk * 64u + lane;
     const uint32_t s0 = g_vseg_blk_slot[blk];
-    sh_base[lane] = g_vseg_base[min(s0 + lane, n_strokes)];
-    if (lane == 0u) sh_base[64] = g_vseg_base[min(s0 + 64u, n_strokes)];
+    sh.base[lane] = g_vseg_base[min(s0 + lane, n_strokes)];
+    if (lane == 0u) sh.base[64] = g_vseg_base[min(s0 + 64u, n_strokes)];
     __syncthreads();
-    if (g >= n_vsegs) return;
-    /* largest j in 0..64 with base[j] <= g: holds for j = 0; entries past the table hold n_vsegs (> g); every slot of
-     * the (compressed) table owns at least one segment, so 64 consecutive segments span at most 64 slots */
-    uint32_t lo = 0u, hi = 65u;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (sh_base[mid] <= g) lo = mid; else hi = mid;
-    }
-    const uint32_t v = g - sh_base[lo];
-    lo += s0;
-    const uint32_t o = g_stroke_op[lo];
-    const osmt_opinfo oi = g_info[o];
-    osmt_srec rec;
-    uint32_t is_cap = 0u;
-    rec.traveled = 0.0;
-    uint32_t cand_off;
-    if (v < oi.n_edges) {
-        /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
-        const osmt_op* __restrict__ op = &g_ops[o];
-        uint32_t r = 0, e = v;
-        osmt_ring ring = g_rings[op->ring_off];
-        while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < op->n_rings) {
-            if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
-            ring = g_rings[op->ring_off + ++r];
-        }
-        const int2 p1 = g_pts[ring.first_pt + e];
-        const int2 p2 = g_pts[ring.first_pt + e + 1];
-        rec.p1x = p1.x; rec.p1y = p1.y; rec.p2x = p2.x; rec.p2y = p2.y;
-        rec.traveled = g_trav[g]; /* per virtual segment (k_opinfo) */
-        rec.denom = g_den[g];
-        rec.rdenom = g_rden[g];
-        cand_off = g_cand_off[g];
-    } else {
-        const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
-        if (!cs.valid) return;
-        rec.p1x = cs.p1x; rec.p1y = cs.p1y; rec.p2x = cs.p2x; rec.p2y = cs.p2y;
-        rec.denom = cs.denom;
-        rec.rdenom = 1.0 / cs.denom;
-        is_cap = 1u;
-        cand_off = cs.cand_off;
-    }
-    if (rec.p1x == rec.p2x && rec.p1y == rec.p2y) return; /* line.rs:73-75 */
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
     const int32_t n_sub_x = W / SUB, n_sub_y = (int32_t)sub_rows;
-    const double ft = stroke_ft(g_aux[oi.aux].half_width);
-    const SubWindow w = vseg_window(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, ft, n_sub_x, n_sub_y);
-    /* one slot per sub-tile of the window, row-major: the record, or a hole */
-    uint32_t slot = cand_off;
-    if ((unsigned long long)cand_off + window_count(w) > oi.rec_cap) return; /* never: k_opinfo reserved this very window */
-    for (int32_t sy = w.sy0; sy <= w.sy1; ++sy) {
-        uint32_t rowbits = 0u;
-        for (int32_t sx = w.sx0; sx <= w.sx1; ++sx, ++slot) {
-            SubRect rc;
-            rc.x0 = sx * SUB;
-            rc.y0 = sy * SUBH;
-            rc.x1 = rc.x0 + SUB - 1;
-            rc.y1 = rc.y0 + SUBH - 1;
-            osmt_item_ranges ir;
-            const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, ft, rc.x0, rc.y0, rc.x1, rc.y1, &ir);
-            if (cnt == 0u) {
-                g_skey[(size_t)oi.arena_off + slot] = make_uint2(0xFFFFFFFFu, 0u);
-                continue;
-            }
-            rec.k_lo0 = ir.k_lo0; rec.k_n0 = (uint16_t)ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = (uint16_t)ir.k_n1;
-            rec.m_lo0 = ir.m_lo0; rec.n_x0 = (uint16_t)ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = (uint16_t)ir.n_x1;
-            g_srec[(size_t)oi.arena_off + slot] = rec;
-            g_skey[(size_t)oi.arena_off + slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (is_cap << 31));
-            rowbits |= 1u << sx;
+    uint32_t n_pairs = 0u;
+    if (g < n_vsegs) {
+        /* largest j in 0..64 with base[j] <= g: holds for j = 0; entries past the table hold n_vsegs (> g); every slot of
+         * the (compressed) table owns at least one segment, so 64 consecutive segments span at most 64 slots */
+        uint32_t lo = 0u, hi = 65u;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sh.base[mid] <= g) lo = mid; else hi = mid;
         }
-        if (rowbits) {
-            /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
-            uint32_t fresh = rowbits & ~atomicOr(&g_submask[(size_t)o * sub_rows + (uint32_t)sy], rowbits);
-            uint32_t* ct = g_cnt + ((size_t)g_op_job[o] * sub_rows + (uint32_t)sy) * (uint32_t)n_sub_x;
-            while (fresh) {
-                atomicAdd(ct + (uint32_t)__builtin_ctz(fresh), 1u);
-                fresh &= fresh - 1u;
+        const uint32_t v = g - sh.base[lo];
+        lo += s0;
+        const uint32_t o = g_stroke_op[lo];
+        const osmt_opinfo oi = g_info[o];
+        StrokeBinSeg sg;
+        sg.rec.traveled = 0.0;
+        sg.is_cap = 0u;
+        uint32_t cand_off = 0u;
+        bool valid = true;
+        if (v < oi.n_edges) {
+            /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
+            const osmt_op* __restrict__ op = &g_ops[o];
+            uint32_t r = 0, e = v;
+            osmt_ring ring = g_rings[op->ring_off];
+            while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < op->n_rings) {
+                if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
+                ring = g_rings[op->ring_off + ++r];
+            }
+            const int2 p1 = g_pts[ring.first_pt + e];
+            const int2 p2 = g_pts[ring.first_pt + e + 1];
+            sg.rec.p1x = p1.x; sg.rec.p1y = p1.y; sg.rec.p2x = p2.x; sg.rec.p2y = p2.y;
+            sg.rec.traveled = g_trav[g]; /* per virtual segment (k_opinfo) */
+            sg.rec.denom = g_den[g];
+            sg.rec.rdenom = g_rden[g];
+            cand_off = g_cand_off[g];
+        } else {
+            const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
+            valid = cs.valid != 0;
+            sg.rec.p1x = cs.p1x; sg.rec.p1y = cs.p1y; sg.rec.p2x = cs.p2x; sg.rec.p2y = cs.p2y;
+            sg.rec.denom = cs.denom;
+            sg.rec.rdenom = 1.0 / cs.denom;
+            sg.is_cap = 1u;
+            cand_off = cs.cand_off;
+        }
+        if (valid && !(sg.rec.p1x == sg.rec.p2x && sg.rec.p1y == sg.rec.p2y)) { /* line.rs:73-75 */
+            sg.ft = stroke_ft(g_aux[oi.aux].half_width);
+            const SubWindow w = vseg_window(sg.rec.p1x, sg.rec.p1y, sg.rec.p2x, sg.rec.p2y, sg.rec.denom, sg.ft, n_sub_x, n_sub_y);
+            const uint32_t wc = window_count(w);
+            if (wc && (unsigned long long)cand_off + wc <= oi.rec_cap) { /* always: k_opinfo reserved this very window */
+                sg.sx0 = w.sx0;
+                sg.sy0 = w.sy0;
+                sg.ncols = (uint32_t)(w.sx1 - w.sx0 + 1);
+                sg.slot0 = oi.arena_off + cand_off;
+                sg.op = o;
+                sg.job = g_op_job[o];
+                sg._pad = 0u;
+                sg.rec.k_lo0 = sg.rec.k_lo1 = sg.rec.m_lo0 = sg.rec.m_lo1 = 0;
+                sg.rec.k_n0 = sg.rec.k_n1 = sg.rec.n_x0 = sg.rec.n_x1 = 0;
+                sh.seg[lane] = sg;
+                n_pairs = wc;
             }
         }
+    }
+    const uint32_t incl = wave_incl_scan(n_pairs);
+    sh.incl[lane] = incl;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    __syncthreads();
+    /* ---- step B, lane = (segment, sub-tile of its window): the ranges of perpendicular runs that can reach the
+     * sub-tile (osmt_seg_ranges) -> the slot's record and key, or a hole.  One slot per sub-tile of the window, row-major.
+     * Segments have windows of 1 .. 30 sub-tiles: dealt pair by pair the lanes stay full, dealt segment by segment
+     * (round 2) the wave ran as long as its largest window with a third of its lanes. ---- */
+    for (uint32_t i = lane; i < total; i += 64u) {
+        uint32_t v = 0u; /* first segment whose inclusive count exceeds i */
+#pragma unroll
+        for (uint32_t step = 32u; step; step >>= 1)
+            if (sh.incl[v + step - 1u] <= i) v += step;
+        const StrokeBinSeg& sg = sh.seg[v];
+        const uint32_t j = i - (v ? sh.incl[v - 1u] : 0u);
+        const uint32_t ncols = sg.ncols;
+        uint32_t qy = (uint32_t)((float)j * __builtin_amdgcn_rcpf((float)ncols)); /* j / ncols for j < 2^11: estimate + fix-up */
+        if ((qy + 1u) * ncols <= j) ++qy;
+        if (qy * ncols > j) --qy;
+        const int32_t sx = sg.sx0 + (int32_t)(j - qy * ncols), sy = sg.sy0 + (int32_t)qy;
+        const int32_t x0 = sx * SUB, y0 = sy * SUBH;
+        osmt_srec rec = sg.rec;
+        osmt_item_ranges ir;
+        const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, sg.ft, x0, y0, x0 + SUB - 1, y0 + SUBH - 1, &ir);
+        const size_t slot = (size_t)sg.slot0 + j;
+        if (cnt == 0u) {
+            g_skey[slot] = make_uint2(0xFFFFFFFFu, 0u);
+            continue;
+        }
+        rec.k_lo0 = ir.k_lo0; rec.k_n0 = (uint16_t)ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = (uint16_t)ir.k_n1;
+        rec.m_lo0 = ir.m_lo0; rec.n_x0 = (uint16_t)ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = (uint16_t)ir.n_x1;
+        g_srec[slot] = rec;
+        g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
+        /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
+        const uint32_t bit = 1u << sx;
+        if (!(atomicOr(&g_submask[(size_t)sg.op * sub_rows + (uint32_t)sy], bit) & bit))
+            atomicAdd(g_cnt + ((size_t)sg.job * sub_rows + (uint32_t)sy) * (uint32_t)n_sub_x + (uint32_t)sx, 1u);
     }
 }
 
@@ -1229,7 +1277,10 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
                                                uint32_t* __restrict__ g_cnt) {
-    __shared__ FillShared sh;
+    __shared__ union {
+        FillShared fill;
+        StrokeBinShared bin;
+    } shu;
     const uint32_t b = blockIdx.x;
 #if defined(OSMT_ABL) && OSMT_ABL == 9
     if (b < n_vblk) return; /* ablation: no stroke binning */
@@ -1238,11 +1289,11 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
     if (b >= n_vblk) return; /* ablation: no fill rows */
 #endif
     if (b < n_vblk)
-        stroke_bin_body(reinterpret_cast<uint32_t*>(&sh.r_xmin[0]), b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
+        stroke_bin_body(shu.bin, b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
                         g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey,
                         g_op_job, g_cnt);
     else
-        fill_rows_body(sh, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
+        fill_rows_body(shu.fill, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
                        g_op_job, g_cnt);
 }
 
