@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--n-poly", type=int, default=50, help="diagnostic: polygons per tile (default = the named config)")
     ap.add_argument("--n-line", type=int, default=40, help="diagnostic: polylines per tile (default = the named config)")
     ap.add_argument("--config4-tiles", type=int, default=10000)
-    ap.add_argument("--config5-tiles", type=int, default=64)
+    ap.add_argument("--config5-tiles", type=int, default=256)
     ap.add_argument("--sustained-seconds", type=float, default=2.0)
     ap.add_argument("--label-tiles", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -192,14 +192,22 @@ __device__ __forceinline__ uint32_t window_count(const SubWindow& w) {
  * Offsets come from two global cursors (atomicAdd: the order of the ops in the arenas does not matter, k_raster
  * finds everything through osmt_opinfo).  With fmask_cap == srec_cap == 0 the kernel only sizes (upload-time pass). */
 __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
-    const uint32_t o = blockIdx.x * 64u + threadIdx.x;
-    if (o >= a.n_ops) return;
-    const osmt_op op = a.ops[o];
+    const uint32_t o_raw = blockIdx.x * 64u + threadIdx.x;
+    const bool live = o_raw < a.n_ops;
+    const uint32_t o = live ? o_raw : a.n_ops - 1u; /* lanes past the pool shadow the last op and store nothing: the wave
+                                                     * stays whole for the reservation at the end */
+    osmt_op op = a.ops[o];
+    if (!live) op.kind = OSMT_OP_NONE;
     const osmt_ring* __restrict__ rings = a.rings;
     const int2* __restrict__ pts = a.pts;
     const uint32_t sub_rows = a.sub_rows;
-    uint32_t* __restrict__ sm = a.submask + (size_t)o * sub_rows;
-    for (uint32_t r = 0; r < sub_rows; ++r) sm[r] = 0u;
+    {
+        /* the sub-tile words of the wave's 64 ops are one contiguous piece: cleared with whole-line stores (a lane
+         * clearing its own op's 16 words touched 64 lines per store) */
+        const size_t w_first = (size_t)blockIdx.x * 64u * sub_rows;
+        const size_t w_end = min((size_t)a.n_ops, (size_t)(blockIdx.x + 1u) * 64u) * sub_rows;
+        for (size_t i = w_first + threadIdx.x; i < w_end; i += 64u) a.submask[i] = 0u;
+    }
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
     oi.x1 = oi.y1 = INT32_MIN;
@@ -218,10 +226,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     oi.fill_geom = 0;
     oi.image_id = op.image_id;
     oi.opacity = op.opacity;
-    if (op.kind == OSMT_OP_NONE) {
-        a.info[o] = oi;
-        return;
-    }
+    const bool none = op.kind == OSMT_OP_NONE;
+    if (none) op.n_rings = 0u;
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * a.scale);
     const int32_t n_sub_y = (int32_t)sub_rows, n_sub_x = W / OSMT_SUB_W;
     const bool is_stroke = op.kind == OSMT_OP_STROKE;
@@ -306,6 +312,11 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         }
     }
     if (cur_blk != 0xFFFFFFFFu) a.blk[blk_off + cur_blk] = bb;
+    /* ---- the two arena reservations of the wave's 64 ops go out as ONE atomicAdd per cursor (wave sums, per-lane
+     * offsets from a prefix scan): 2.3 M single-lane atomics on two addresses were what bounded this kernel on the
+     * dense config (~1 atomic per clock at the L2) ---- */
+    unsigned long long want_f = 0ull, want_s = 0ull; /* fill groups / stroke slots this op reserves */
+    uint32_t fill_geom_ok = 0u;
     if (is_stroke) {
         osmt_stroke_aux* sa = &a.aux[oi.aux];
         sa->half_width = hw;
@@ -342,25 +353,49 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         sa->caps.n_segs = 1;
         if (cand > 0xFFFFFFFFull) cand = 0xFFFFFFFFull; /* cannot happen below 2^32 records per scene (checked by the host) */
         oi.rec_cap = (uint32_t)cand;
-        if (cand) {
-            const unsigned long long off = atomicAdd(&a.cursors[1], cand);
-            oi.arena_off = (uint32_t)off;
-            if (a.srec_cap && off + cand > a.srec_cap) oi.rec_cap = 0; /* never: the arena was sized by this same code */
-        }
-    } else {
+        want_s = cand;
+    } else if (!none) {
         /* fills: rows ytop+1 .. ybot carry records (fill.rs:66-72), spans lie inside the points' x range */
         const int32_t ylo = max(oi.y0 + 1, 0), yhi = min(oi.y1, W - 1);
         const int32_t xlo = max(oi.x0, 0), xhi = min(oi.x1, W - 1);
         if (oi.x0 <= oi.x1 && ylo <= yhi && xlo <= xhi) {
             const uint32_t sr0 = (uint32_t)(ylo >> OSMT_SUB_H_LOG2), nsr = (uint32_t)(yhi >> OSMT_SUB_H_LOG2) - sr0 + 1u;
             const uint32_t c0 = (uint32_t)(xlo >> 5), ncols = (uint32_t)(xhi >> 5) - c0 + 1u;
-            const unsigned long long groups = (unsigned long long)nsr * ncols;
-            const unsigned long long off = atomicAdd(&a.cursors[0], groups);
-            oi.arena_off = (uint32_t)off;
-            if (!(a.fmask_cap && off + groups > a.fmask_cap)) oi.fill_geom = sr0 | (c0 << 8) | (ncols << 16) | (nsr << 24);
+            want_f = (unsigned long long)nsr * ncols;
+            fill_geom_ok = sr0 | (c0 << 8) | (ncols << 16) | (nsr << 24);
         }
     }
-    a.info[o] = oi;
+    {
+        /* per-op counts are below 2^32 (clamped) and a fill window below 2^16: 16-bit halves scan without overflow */
+        const uint32_t lane = threadIdx.x;
+        const uint32_t f = (uint32_t)want_f;
+        const uint32_t s_lo = (uint32_t)want_s & 0xFFFFu, s_hi = (uint32_t)(want_s >> 16);
+        const uint32_t f_incl = wave_incl_scan(f);
+        const unsigned long long s_incl = ((unsigned long long)wave_incl_scan(s_hi) << 16) + wave_incl_scan(s_lo);
+        const uint32_t f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_incl, 63);
+        const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), 63) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, 63);
+        unsigned long long f_base = 0ull, s_base = 0ull;
+        if (lane == 0u) {
+            if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
+            if (s_tot) s_base = atomicAdd(&a.cursors[1], s_tot);
+        }
+        f_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f_base >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f_base);
+        s_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_base >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_base);
+        if (want_s) {
+            const unsigned long long off = s_base + (s_incl - want_s);
+            oi.arena_off = (uint32_t)off;
+            if (a.srec_cap && off + want_s > a.srec_cap) oi.rec_cap = 0; /* never: the arena was sized by this same code */
+        }
+        if (want_f) {
+            const unsigned long long off = f_base + (f_incl - f);
+            oi.arena_off = (uint32_t)off;
+            if (!(a.fmask_cap && off + want_f > a.fmask_cap)) oi.fill_geom = fill_geom_ok;
+        }
+    }
+    if (live) a.info[o] = oi;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -886,20 +921,29 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
     const uint32_t n_sub_x = OSMT_TILE_SIZE * scale / SUB;
     /* the group's ops and their sub-tile rows: slot t of the group = (op k, sub-tile row sr0_k + t - base_k) */
     uint32_t g_geom[FILL_GROUP], g_arena[FILL_GROUP], g_base[FILL_GROUP + 1];
+    uint32_t g_ne[FILL_GROUP], g_pt0[FILL_GROUP]; /* SIMPLE ops (one ring, <= 16 edges): edge count and first point; else g_ne = 0xFFFFFFFF */
     g_base[0] = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < FILL_GROUP; ++k) {
-        uint32_t geom = 0u, arena = 0u;
+        uint32_t geom = 0u, arena = 0u, ne = 0u, pt0 = 0u;
         if (o_first + k < n_ops) {
             const osmt_opinfo* __restrict__ oi = &g_info[o_first + k];
             const uint32_t kind = oi->kind;
             if (kind == OSMT_OP_FILL_COLOR || kind == OSMT_OP_FILL_IMAGE) {
                 geom = oi->fill_geom; /* nsr == 0: no covered row inside the tile */
                 arena = oi->arena_off;
+                const osmt_op* __restrict__ op = &g_ops[o_first + k];
+                ne = 0xFFFFFFFFu;
+                if (op->n_rings == 1u && oi->n_edges <= 16u) {
+                    ne = oi->n_edges;
+                    pt0 = g_rings[op->ring_off].first_pt;
+                }
             }
         }
         g_geom[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom);
         g_arena[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)arena);
+        g_ne[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ne);
+        g_pt0[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt0);
         g_base[k + 1] = g_base[k] + (g_geom[k] >> 24);
     }
     const uint32_t n_slots = g_base[FILL_GROUP];
@@ -937,6 +981,64 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
             /* ---- step 1: crossing edges of the ops that own rows of the window ---- */
             uint32_t n_list = 0u, n_cross = 0u;
             bool overflow = false;
+            /* SIMPLE ops only in this window (the common case: a polygon is one ring of a few edges): ONE round for all of
+             * them, lane = (op lane / 16, edge lane % 16), instead of a round per op with a quarter of the lanes */
+            bool pooled = true;
+#pragma unroll
+            for (uint32_t k = 0; k < FILL_GROUP; ++k) {
+                const uint32_t s_lo = max(g_base[k], t0), s_hi = min(g_base[k + 1], t0 + 4u);
+                if (s_lo < s_hi && max((s_lo - t0) * SUBH, w0) < min((s_hi - t0) * SUBH, w0 + ww) && g_ne[k] == 0xFFFFFFFFu) pooled = false;
+            }
+            if (pooled) {
+                const uint32_t k = lane >> 4, e = lane & 15u;
+                uint32_t kbase = g_base[0], kend = g_base[1], kgeom = g_geom[0], kne = g_ne[0], kpt0 = g_pt0[0];
+#pragma unroll
+                for (uint32_t q = 1; q < FILL_GROUP; ++q)
+                    if (k == q) {
+                        kbase = g_base[q];
+                        kend = g_base[q + 1];
+                        kgeom = g_geom[q];
+                        kne = g_ne[q];
+                        kpt0 = g_pt0[q];
+                    }
+                const uint32_t s_lo = max(kbase, t0), s_hi = min(kend, t0 + 4u);
+                uint32_t cnt = 0u, l0 = 0u;
+                int32_t first = 0;
+                int2 p1 = make_int2(0, 0), p2 = p1;
+                if (s_lo < s_hi && e < kne) {
+                    const uint32_t la = max((s_lo - t0) * SUBH, w0), lb = min((s_hi - t0) * SUBH, w0 + ww);
+                    if (la < lb) {
+                        const int32_t ybase = ((int32_t)(kgeom & 255u) + (int32_t)t0 - (int32_t)kbase) * SUBH;
+                        const int32_t ya = ybase + (int32_t)la, yb = ybase + (int32_t)lb - 1;
+                        p1 = g_pts[kpt0 + e];
+                        p2 = g_pts[kpt0 + e + 1u];
+                        const int32_t ytop = min(p1.y, p2.y), ybot = max(p1.y, p2.y);
+                        first = max(ytop + 1, ya);
+                        const int32_t last = min(ybot, yb);
+                        cnt = last >= first ? (uint32_t)(last - first + 1) : 0u;
+                        l0 = la + (uint32_t)(first - ya);
+                    }
+                }
+                const unsigned long long has = __ballot(cnt != 0u);
+                if (has != 0ull) {
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    const uint32_t pos = (uint32_t)__popcll(has & ((1ull << lane) - 1ull));
+                    n_list = (uint32_t)__popcll(has); /* <= 64 <= FILL_EMAX */
+                    n_cross = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (n_cross > FILL_RMAX) {
+                        overflow = true;
+                    } else if (cnt != 0u) {
+                        sh.e_p1[pos] = p1;
+                        sh.e_p2[pos] = p2;
+                        sh.e_y0[pos] = first;
+                        sh.e_lane0[pos] = l0;
+                        sh.e_pre[pos] = incl;
+                        sh.e_key[pos] = e;
+                        atomicAdd(&sh.diff[l0], 1);
+                        atomicAdd(&sh.diff[l0 + cnt], -1);
+                    }
+                }
+            } else
 #pragma unroll 1
             for (uint32_t k = 0; k < FILL_GROUP; ++k) {
                 /* slots of op k inside this pass and window -> lanes [la, lb) */
