@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-3 evidence run: full GPU suite, the bench line, kernel traces + counter passes of configs 2 / 5 / @2x.
+TAG=${1:-r03_final}
+O=gpurun_out/$TAG; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; tail -2 $O/bench.err
+timeout 600 python tools/prof_workload.py config2 $O/config2 kt,sq1,sq2,fetch,write > $O/prof.log 2>&1
+timeout 900 python tools/prof_workload.py config5:256 $O/config5 kt,sq1,fetch,write >> $O/prof.log 2>&1
+timeout 600 python tools/prof_workload.py raster_2x:256 $O/raster_2x kt,sq1,fetch,write >> $O/prof.log 2>&1
+timeout 300 python tools/bench_e2e_breakdown.py 1024 > $O/e2e_breakdown.txt 2>&1
+timeout 300 python tools/bench_png_chunks.py 1 2 4 > $O/png_chunks.txt 2>&1
+OSMT_TIME_BIG=1 timeout 600 python tools/time_variants.py base > $O/stage_times.txt 2>&1; cat $O/stage_times.txt
