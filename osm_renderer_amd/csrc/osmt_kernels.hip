@@ -1512,6 +1512,15 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
  * of perpendicular-run ranges per (segment, sub-tile) (k_stroke_bin).  What is left here is the part that needs the
  * pixels: walking the runs of a generation into the LDS alpha plane (set_pixel keeps the larger alpha,
  * tile_pixels.rs:114-118) and blending generation after generation in order (tile_pixels.rs:205-223). */
+/* The lane id as a value the compiler cannot connect to its earlier uses: addresses derived from it (output pixel,
+ * staging slots, plane cells) are then computed WHERE they are used instead of once in the prologue and carried — or,
+ * at 128 registers, spilled: nine such values cost 300 MB of scratch stores per launch. */
+__device__ __forceinline__ uint32_t fresh_lane() {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 /* The kernel's own argument block, re-read from the kernel-argument segment at the point of use: the empty asm makes
  * the pointer opaque, so the compiler can neither hoist the (invariant) loads to the top of the kernel nor keep their
  * results alive across the loops in between. */
@@ -1601,8 +1610,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     OSMT_DBG(if (lane < 8) sh.dbg[lane] = 0u; __syncthreads();)
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    /* this sub-tile's own list (k_sublist): the ops that draw here, in order, 64 at a time; the NEXT chunk's entries are
-     * fetched while the current one is processed */
+    /* this sub-tile's own list (k_sublist): the ops that draw here, in order, 64 at a time.  (Fetching the next chunk's
+     * entries a chunk ahead cost eight registers for the whole chunk: 21 more spilled registers at 128, whose scratch
+     * stores more than doubled the kernel's HBM writes.) */
     const uint2 hdr = a.hdr[(size_t)tile * nsub + sub];
     const uint32_t n_ent = hdr.y;
     const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
@@ -1611,14 +1621,12 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         if (base + lane < n_ent) e_ = my_ent[base + lane];
         return e_;
     };
-    OpEntry e_next = load_ent(0);
 
     for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
         const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
         const bool hit = lane < total;
         const unsigned long long bal = (total >= 64u) ? ~0ull : ((1ull << total) - 1ull);
-        OpEntry e = e_next;
-        if (base + OPCHUNK < n_ent) e_next = load_ent(base + OPCHUNK);
+        OpEntry e = load_ent(base);
         const bool is_stroke = hit && (e.kind_color & 255u) == OSMT_OP_STROKE;
         const unsigned long long sbal = __ballot(is_stroke), fbal = bal & ~sbal;
         const uint32_t pos = lane;
@@ -1645,15 +1653,16 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const bool any_stroke = sbal != 0ull;
         if (any_stroke && !plane_clean) {
             static_assert((PLANE_STRIDE * SUBH) % NTHREADS == 0, "the plane is cleared in whole wave strides");
+            const uint32_t t_ = fresh_lane();
 #pragma unroll
-            for (uint32_t i = 0; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i + tid] = 0ull;
+            for (uint32_t i = 0; i < PLANE_STRIDE * SUBH; i += NTHREADS) sh.plane[i + t_] = 0ull;
             plane_clean = true;
         }
         __syncthreads();
         {
             /* coverage words of the chunk's fills: lane -> (staged fill, row), all in flight together */
             const uint32_t n_fill_staged = min((uint32_t)__popcll(fbal), (uint32_t)STAGECAP);
-            for (uint32_t i = lane; i < n_fill_staged * SUBH; i += NTHREADS) {
+            for (uint32_t i = fresh_lane(); i < n_fill_staged * SUBH; i += NTHREADS) {
                 const uint32_t f = i / SUBH, row = i % SUBH;
                 sh.fmask[f][row] = g_fmask[(size_t)sh.farena[f] + row];
             }
@@ -1932,10 +1941,12 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* ---- to_rgb_triples (tile_pixels.rs:164-181) / raw canvas ---------------- */
     void* const g_out = late_args()->out;
     const size_t g_out_tile_stride = late_args()->out_tile_stride;
+    const uint32_t t_out = fresh_lane();
+    const uint32_t lx_o = t_out & (SUB - 1), ly_o = t_out / SUB;
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
-        const uint32_t row = ly0 + (uint32_t)j * ROWSTEP;
-        const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx);
+        const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;
+        const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx_o);
         if (OUT_F64) {
             double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
             *out = make_double4(acc[j][0], acc[j][1], acc[j][2], 1.0);
