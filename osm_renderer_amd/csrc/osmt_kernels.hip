@@ -881,7 +881,9 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
  * polygon a few rows tall would leave most of a wave idle.
  *   pass     64 rows = four slots of 16; a slot is one sub-tile row of one FILL op.  A wave owns FILL_GROUP consecutive
  *            ops and deals their sub-tile rows to the slots in order: four rows of one tall polygon, or the rows of
- *            up to four small ones.
+ *            several small ones.  (FILL_GROUP, measured: pre-pass of config 2 / @2x / config 5 with 1: 263 / 140 / 1177 us,
+ *            2: 252 / 145 / 1032, 3: 261 / 161 / 1028, 4: 261 / 169 / 1021, 8: 285 / 204 / 1015 — tall polygons want
+ *            more waves, small ones fuller passes.)
  *   step 1   lane = edge (64 per round; ops with more: further rounds, 64-edge blocks whose box misses the rows are
  *            skipped): rows of the pass the edge crosses -> a compact edge list with the running crossing count, and a
  *            difference array over the rows (+1 on the first row, -1 behind the last).
@@ -894,7 +896,10 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
  *            here" bits of the op's sub-tile mask and the list counts of k_sublist fall out of the same words.
  * A window of rows with more crossing edges / crossings than the buffers hold is halved until it fits; a single row
  * beyond them streams its records storage-free (fill_row_streaming, cold). */
-constexpr uint32_t FILL_GROUP = 4;
+#ifndef OSMT_V_FILL_GROUP
+#define OSMT_V_FILL_GROUP 2
+#endif
+constexpr uint32_t FILL_GROUP = OSMT_V_FILL_GROUP;
 constexpr uint32_t FILL_EMAX = 128;
 constexpr uint32_t FILL_RMAX = 512;
 struct FillShared {
@@ -990,8 +995,20 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
                 if (s_lo < s_hi && max((s_lo - t0) * SUBH, w0) < min((s_hi - t0) * SUBH, w0 + ww) && g_ne[k] == 0xFFFFFFFFu) pooled = false;
             }
             if (pooled) {
-                const uint32_t k = lane >> 4, e = lane & 15u;
-                uint32_t kbase = g_base[0], kend = g_base[1], kgeom = g_geom[0], kne = g_ne[0], kpt0 = g_pt0[0];
+                /* the (at most four) ops with slots in this pass, in order: lane / 16 picks one of them */
+                uint32_t kq[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu}, nq = 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < FILL_GROUP; ++q)
+                    if (max(g_base[q], t0) < min(g_base[q + 1], t0 + 4u)) {
+                        if (nq == 0u) kq[0] = q;
+                        if (nq == 1u) kq[1] = q;
+                        if (nq == 2u) kq[2] = q;
+                        if (nq == 3u) kq[3] = q;
+                        ++nq;
+                    }
+                const uint32_t qi = lane >> 4, e = lane & 15u;
+                const uint32_t k = qi == 0u ? kq[0] : (qi == 1u ? kq[1] : (qi == 2u ? kq[2] : kq[3]));
+                uint32_t kbase = g_base[0], kend = k == 0u ? g_base[1] : 0u, kgeom = g_geom[0], kne = k == 0u ? g_ne[0] : 0u, kpt0 = g_pt0[0];
 #pragma unroll
                 for (uint32_t q = 1; q < FILL_GROUP; ++q)
                     if (k == q) {
