@@ -781,6 +781,7 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
 #if defined(OSMT_ABL) && OSMT_ABL == 8
     if (MODE != 2) return; /* ablation: plain runs are not walked */
 #endif
+    OSMT_DBG(if (lane == 0u) { sh.dbg[1] += (it_hi - it_lo + 63u) / 64u; sh.dbg[2] += it_hi - it_lo; if (MODE == 2) sh.dbg[3] += (it_hi - it_lo + 63u) / 64u; })
     for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
         uint32_t lo_s = slot0, n = nslot;
         while (n > 1u) {

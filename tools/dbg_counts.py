@@ -7,12 +7,13 @@ from osm_renderer_amd import synth
 from osm_renderer_amd.renderer import Context
 
 ctx = Context(0)
-dl = synth.config2(64)
-out = ctx.render(ctx.upload(dl)).cpu().numpy().view(np.uint32).reshape(64, 256, 256)
-c = out[:, ::16, :].reshape(64, 16, 8, 32)[:, :, :, :8].reshape(-1, 8).astype(np.int64)
-names = ["stroke_visits", "passes", "items", "lane_iters", "-", "fill_visits", "set_pixels", "max_iters_seen"]
+which = sys.argv[1] if len(sys.argv) > 1 else "config2"
+dl = synth.config5(16) if which == "config5" else synth.config2(64)
+NT = dl.n_jobs
+out = ctx.render(ctx.upload(dl)).cpu().numpy().view(np.uint32).reshape(NT, 256, 256)
+c = out[:, ::16, :].reshape(NT, 16, 8, 32)[:, :, :, :8].reshape(-1, 8).astype(np.int64)
+names = ["stroke_visits", "passes", "items", "dashed_or_stub_passes", "-", "fill_visits", "-", "-"]
 print("waves", len(c))
 for i, n in enumerate(names):
-    print(f"{n:16s} per wave {c[:, i].mean():10.2f}   per tile {c[:, i].sum() / 64:12.1f}")
-print("items per pass", c[:, 2].sum() / max(c[:, 1].sum(), 1), " iters per item", c[:, 3].sum() / max(c[:, 2].sum(), 1),
-      " set pixels per item", c[:, 6].sum() / max(c[:, 2].sum(), 1))
+    print(f"{n:16s} per wave {c[:, i].mean():10.2f}   per tile {c[:, i].sum() / NT:12.1f}")
+print("items per pass", c[:, 2].sum() / max(c[:, 1].sum(), 1), " passes per stroke visit", c[:, 1].sum() / max(c[:, 0].sum(), 1))
