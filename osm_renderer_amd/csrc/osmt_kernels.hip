@@ -191,8 +191,14 @@ __device__ __forceinline__ uint32_t window_count(const SubWindow& w) {
  * 16 row words per sub-tile of its clipped window, a stroke op one record per (virtual segment, candidate sub-tile).
  * Offsets come from two global cursors (atomicAdd: the order of the ops in the arenas does not matter, k_raster
  * finds everything through osmt_opinfo).  With fmask_cap == srec_cap == 0 the kernel only sizes (upload-time pass). */
+#ifndef OSMT_V_OPINFO_THREADS
+#define OSMT_V_OPINFO_THREADS 64
+#endif
+constexpr uint32_t OPINFO_THREADS = OSMT_V_OPINFO_THREADS; /* ops per wave.  Half-empty waves, more of them (measured: config-2 pre-pass 257 us with
+                                                           * 64, 274 with 32, 309 with 16) do not help: a wave runs as long as its longest op anyway */
+static_assert(OPINFO_THREADS == 64 || OPINFO_THREADS == 32 || OPINFO_THREADS == 16, "the wave scans read their totals from the last active lane");
 __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
-    const uint32_t o_raw = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t o_raw = blockIdx.x * OPINFO_THREADS + threadIdx.x;
     const bool live = o_raw < a.n_ops;
     const uint32_t o = live ? o_raw : a.n_ops - 1u; /* lanes past the pool shadow the last op and store nothing: the wave
                                                      * stays whole for the reservation at the end */
@@ -204,9 +210,9 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     {
         /* the sub-tile words of the wave's 64 ops are one contiguous piece: cleared with whole-line stores (a lane
          * clearing its own op's 16 words touched 64 lines per store) */
-        const size_t w_first = (size_t)blockIdx.x * 64u * sub_rows;
-        const size_t w_end = min((size_t)a.n_ops, (size_t)(blockIdx.x + 1u) * 64u) * sub_rows;
-        for (size_t i = w_first + threadIdx.x; i < w_end; i += 64u) a.submask[i] = 0u;
+        const size_t w_first = (size_t)blockIdx.x * OPINFO_THREADS * sub_rows;
+        const size_t w_end = min((size_t)a.n_ops, (size_t)(blockIdx.x + 1u) * OPINFO_THREADS) * sub_rows;
+        for (size_t i = w_first + threadIdx.x; i < w_end; i += OPINFO_THREADS) a.submask[i] = 0u;
     }
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
@@ -372,9 +378,9 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         const uint32_t s_lo = (uint32_t)want_s & 0xFFFFu, s_hi = (uint32_t)(want_s >> 16);
         const uint32_t f_incl = wave_incl_scan(f);
         const unsigned long long s_incl = ((unsigned long long)wave_incl_scan(s_hi) << 16) + wave_incl_scan(s_lo);
-        const uint32_t f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_incl, 63);
-        const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), 63) << 32) |
-                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, 63);
+        const uint32_t f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_incl, OPINFO_THREADS - 1);
+        const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), OPINFO_THREADS - 1) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, OPINFO_THREADS - 1);
         unsigned long long f_base = 0ull, s_base = 0ull;
         if (lane == 0u) {
             if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
@@ -2133,7 +2139,7 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
     const size_t n_cnt = (a.fmask_cap || a.srec_cap) ? (size_t)a.n_jobs * (Wt / SUB) * (Wt / SUBH) : 0;
     hipError_t e = hipMemsetAsync(a.cursors, 0, 4 * sizeof(unsigned long long) + n_cnt * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + 63u) / 64u), dim3(64), 0, st, a);
+    if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + OPINFO_THREADS - 1u) / OPINFO_THREADS), dim3(OPINFO_THREADS), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
     if (a.n_ops)
