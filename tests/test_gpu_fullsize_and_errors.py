@@ -265,3 +265,27 @@ def test_worker_threads_with_their_own_scenes_do_not_wait_for_each_other(gpu_ctx
     assert len(lat) == 5
     # with a device-wide synchronisation inside any of the calls the worker could not finish before the big queue did
     assert t_worker_done < 0.5 * t_queue_done, (t_worker_done, t_queue_done, lat)
+
+
+def test_big_upload_checks_coordinates_on_its_helper_threads(gpu_ctx, oracle):
+    """Uploads of >= 65536 coordinates run the O(n_pts) coordinate scan on helper threads beside the copies and build the
+    point -> job table on the device: a bad coordinate anywhere is still refused (with the lowest offending index), before
+    any kernel has seen it; a good batch renders like the oracle (k_ptjob's table = the host's)."""
+    dl = synth.make_tiles(synth.config_tiles(110), n_poly=50, n_line=40)  # 75 900 points
+    assert len(dl.coords) >= 65536
+    good = gpu_ctx.render_batch_host(dl)
+    pick = [0, 57, 109]
+    np.testing.assert_array_equal(good[pick], oracle.render_batch(dl.subset(pick), threads=3))
+    for idx in (len(dl.coords) - 1, 40000, 3):
+        bad = synth.make_tiles(synth.config_tiles(110), n_poly=50, n_line=40)
+        bad.coords[idx, 0] = 89.5  # beyond the Web-Mercator square
+        bad.coords[len(bad.coords) - 2, 1] = float("nan")
+        with pytest.raises(OsmtError) as e:
+            gpu_ctx.upload(bad)
+        assert e.value.code == abi.UNSUPPORTED
+        first = min(idx, len(bad.coords) - 2)
+        assert f"point {first}:" in str(e.value), str(e.value)
+        with pytest.raises(OsmtError):
+            gpu_ctx.render_batch_host(bad)
+    again = gpu_ctx.render_batch_host(dl)  # the context is fine afterwards
+    np.testing.assert_array_equal(again, good)
