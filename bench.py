@@ -139,6 +139,10 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
                    "src/http_server.rs:50-83,134-181); tiles_per_s = all threads together",
            "cases": {}}
     max_w, max_b = max(workers), max(batches)
+    # the worker loops are Python threads: a thread coming back from the C call has to win the GIL again, and with the
+    # default 5 ms switch interval that wait (not the library) was the p99 at 16 workers; 50 us keeps it out of the numbers
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(5e-5)
     pool = [synth.make_tiles(synth.config_tiles(max_b, x0=19000 + 7 * w, y0=10000 + 3 * w), zoom=15, scale=args.scale, n_poly=args.n_poly,
                              n_line=args.n_line) for w in range(max_w)]
     bufs = [ctx.host_alloc((max_b, pool[0].dim * pool[0].dim * 3)) for _ in range(max_w)]
@@ -197,6 +201,7 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
                     "mean_us": float(allv.mean()), "tiles_per_s": float(allv.size * bsz / wall),
                 }
     finally:
+        sys.setswitchinterval(old_switch)
         for b in bufs:
             ctx.host_free(b)
     return out
