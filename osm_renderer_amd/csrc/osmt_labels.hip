@@ -20,9 +20,11 @@
  *                                   of its CHANNEL (column parity, A/S kind, stripe parity) in LDS, lists compacted;
  *                    consumer wave  lane = channel: a cell belongs to exactly one channel, so the eight lists are
  *                                   independent chains walked side by side in call order, the running cell in a
- *                                   register, into the LDS-resident A / S accumulators (no atomics);
- *                  double-buffered hand-over (one barrier per batch).  Calls whose cells collide in a channel are
- *                  replayed stripe by stripe by the consumer (lane = stripe) at their place in the order.  Then
+ *                                   register, into the LDS-resident A / S accumulators (no atomics, no test for
+ *                                   "same cell as the last sum": write back, read the next cell, add);
+ *                  double-buffered hand-over (one barrier per batch).  Calls whose cells would collide in a channel
+ *                  (three stripes tall, three cells wide) are replayed stripe by stripe by the consumer
+ *                  (lane = stripe) at their place in the order.  Then
  *                  lane = stripe runs save_to_figure's scan over [x_min, x_max] (:121-143) and the band goes out
  *                  coalesced: total = min(a + s_acc, 1.0) per cell (0 where the stripe has no key) for k_raster, one
  *                  bit per cell (total > 0) for k_label_resolve.
@@ -98,8 +100,10 @@ __device__ __forceinline__ osmt_label_seg label_seg_prep(const double4 q) {
  * every channel is a chain of sums that no other channel's cells take part in.  Calls whose cells collide in a
  * channel (three cells wide, three stripes tall, ...) are replayed stripe by stripe by the row owners instead. */
 #define LC_CH 8
-static_assert(LC_CELLS < 1024, "a parked sum's cell is stripe << 10 | column");
-#define LC_NOCELL 0xFFFFu /* stripe 63, column 1023: no window has it (cols <= OSMT_LABEL_LDS_CELLS < 1024) */
+/* a parked sum names its cell by its byte offset in the band's accumulator array: A cells first, then the S cells, then
+ * one cell that nobody reads (what a channel holds before its first sum and after a replay) */
+static_assert((2 * LC_CELLS + 1) * 8 < 65536, "a parked sum's cell offset is a uint16");
+#define LC_TRASH (2u * LC_CELLS * 8u)
 
 /* channel list strides, skewed so that the eight channel lanes reading entry j of their lists hit different banks */
 #define LC_VSTRIDE 65 /* doubles */
@@ -129,10 +133,11 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
                                                      const osmt_label_band* __restrict__ g_band, uint32_t n_bands,
                                                      const double4* __restrict__ g_seg, double* __restrict__ g_a,
                                                      unsigned long long* __restrict__ g_bits, uint32_t* g_err) {
-    __shared__ double sh_a[LC_CELLS];
-    __shared__ double sh_s[LC_CELLS];
+    __shared__ double sh_acc[2 * LC_CELLS + 1];
+    double* const sh_a = sh_acc;
+    double* const sh_s = sh_acc + LC_CELLS;
     __shared__ double sh_ev_val[2][LC_CH * LC_VSTRIDE]; /* [buffer][channel][call of the batch]: the parked sum */
-    __shared__ uint16_t sh_ev_key[2][LC_CH * LC_KSTRIDE]; /* its cell: local stripe << 10 | column (the kind is the channel's) */
+    __shared__ uint16_t sh_ev_key[2][LC_CH * LC_KSTRIDE]; /* its cell: byte offset in sh_acc */
     __shared__ LcBatch sh_batch[2];
     __shared__ uint32_t sh_cmin[64], sh_cmax[64]; /* per stripe: columns of its keys */
     if (blockIdx.x >= n_bands) return;
@@ -179,11 +184,13 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
             if (overlaps) {
                 const osmt_label_seg sg = label_seg_prep(seg_cur);
                 const int32_t ya = max(sg.yf, band0), yb = min(sg.yl, band1);
+                /* two stripes (different stripe parity) of at most two A cells (different column parity) and one S
+                 * cell never meet in a channel; anything taller or wider is replayed */
+                slow = yb - ya >= 2;
                 auto emit = [&](uint32_t kind, uint32_t row, uint32_t col, double val) {
                     const uint32_t ch = (col & 1u) | (kind << 1) | ((row & 1u) << 2);
-                    if ((chmask >> ch) & 1u) slow = true; /* a second cell of this call in the channel: replay */
                     chmask |= 1u << ch;
-                    ev_key[ch * LC_KSTRIDE + lane] = (uint16_t)((row << 10) | col);
+                    ev_key[ch * LC_KSTRIDE + lane] = (uint16_t)((kind * LC_CELLS + row * cols + col) * 8u);
                     ev_val[ch * LC_VSTRIDE + lane] = val;
                 };
                 for (int32_t yy = ya; yy <= yb && !slow; ++yy) {
@@ -207,6 +214,10 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
                         break;
                     }
                     const uint32_t row = (uint32_t)(yy - band0);
+                    /* the stripe's keys span [x_from, x_to + 1] (save_to_figure's x_min / x_max, :115-120); a call
+                     * that turns out to be replayed has the same span, so adding it twice is harmless */
+                    atomicMin(&sh_cmin[row], (uint32_t)(x_from - cx0));
+                    atomicMax(&sh_cmax[row], (uint32_t)(x_to + 1 - cx0));
                     for (int32_t x = x_from; x <= x_to; ++x) {
                         const double x_left = fmax((double)x, x_smallest);
                         const double x_next = (double)(x + 1);
@@ -229,24 +240,33 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
             const unsigned long long slowm = __ballot(overlaps && slow);
             /* every channel's parked sums move to the front of its list (in place: the wave reads before it writes,
              * and a sum never moves up), so that the consumer walks them without looking for the next call */
-#pragma unroll
-            for (int c = 0; c < LC_CH; ++c) {
-                const bool has = overlaps && !slow && ((chmask >> c) & 1u);
-                const unsigned long long m = __ballot(has);
-                if (lane == (uint32_t)c) hb->mine[c] = m;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint16_t key = 0;
-                double val = 0.0;
-                if (has) {
-                    key = ev_key[c * LC_KSTRIDE + lane];
-                    val = ev_val[c * LC_VSTRIDE + lane];
-                }
-                wave_lds_order();
-                if (has) {
-                    ev_key[c * LC_KSTRIDE + rank] = key;
-                    ev_val[c * LC_VSTRIDE + rank] = val;
-                }
-            }
+            if (!overlaps || slow) chmask = 0u;
+            uint32_t mine_lo = 0u, mine_hi = 0u; /* lane c: channel c's calls */
+/* lane c of (mine_lo, mine_hi) takes the ballot.  gfx950 wants two wait states between the v_cmp that writes the mask
+ * and a VALU read of it as a scalar operand; the compiler does not look into inline assembly, hence the s_nop */
+#define LC_MINE(c)                                                              \
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" \
+        : "+v"(mine_lo), "+v"(mine_hi)                                          \
+        : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"(c));
+#define LC_COMPACT(c)                                                                                                  \
+    {                                                                                                                  \
+        const bool has = (chmask & (1u << (c))) != 0u;                                                                 \
+        const unsigned long long m = __ballot(has);                                                                    \
+        LC_MINE(c)                                                                                                     \
+        if (has) { /* one wave: the reads of all lanes are done before the first write lands */                        \
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
+            const uint16_t key = ev_key[(c) * LC_KSTRIDE + lane];                                                      \
+            const double val = ev_val[(c) * LC_VSTRIDE + lane];                                                        \
+            wave_lds_order();                                                                                          \
+            ev_key[(c) * LC_KSTRIDE + rank] = key;                                                                     \
+            ev_val[(c) * LC_VSTRIDE + rank] = val;                                                                     \
+        }                                                                                                              \
+        wave_lds_order();                                                                                              \
+    }
+            LC_COMPACT(0) LC_COMPACT(1) LC_COMPACT(2) LC_COMPACT(3) LC_COMPACT(4) LC_COMPACT(5) LC_COMPACT(6) LC_COMPACT(7)
+#undef LC_COMPACT
+#undef LC_MINE
+            if (lane < LC_CH) hb->mine[lane] = ((unsigned long long)mine_hi << 32) | mine_lo;
             if (lane == 0u) {
                 hb->rest = rest;
                 hb->slowm = slowm;
@@ -261,17 +281,16 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
     } else {
         /* ---- lane = channel (the first LC_CH lanes): the parked sums are applied strictly in call order.  Every
          * cell belongs to exactly one channel, so the channels' sums are independent chains that advance side by
-         * side; a lane keeps the cell it is adding to in a register (consecutive calls of a curve land in the same
-         * cell), LDS is touched only when its channel moves on to another cell. ---- */
+         * side; a lane keeps the running sum of the cell it is on in a register and puts it back before it reads the
+         * cell of the next sum (the same cell again, most of the time: that costs less than testing for it). ---- */
         const bool active = lane < nrow;
         const int32_t y = ry0 + (int32_t)(rbase + lane);
         double* a_row = sh_a + (active ? lane * cols : 0u);
         double* s_row = sh_s + (active ? lane * cols : 0u);
-        double* const my_plane = ((lane >> 1) & 1u) ? sh_s : sh_a;
-        uint32_t ckey = LC_NOCELL;
+        uint32_t ccell = LC_TRASH; /* the cell this channel is adding to (byte offset), its running sum in cval */
+        auto cell = [&](uint32_t off) -> double* { return reinterpret_cast<double*>(reinterpret_cast<char*>(sh_acc) + off); };
         double cval = 0.0;
         uint32_t c_min = 0xFFFFFFFFu, c_max = 0u; /* columns of the stripe's keys added by replayed calls (x - cx0) */
-        auto cell_of = [&](uint32_t K) -> double* { return my_plane + (K >> 10) * cols + (K & 1023u); };
         for (uint32_t k = 0;; ++k) {
             __syncthreads(); /* hand-over k */
             const LcBatch* const hb = &sh_batch[k & 1u];
@@ -290,23 +309,21 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
                 const unsigned long long seg = sl < 64u ? (rest & ((1ull << sl) - 1ull)) : rest;
                 const uint32_t end = pos + (uint32_t)__popcll(mine & seg);
                 while (pos < end) {
+                    /* no test for "same cell as before": the sum goes back to its cell and the next cell is read,
+                     * in this order — when the channel stays on a cell that reads back what was just written */
                     const uint32_t K = my_key[pos];
                     const double v = my_val[pos];
                     ++pos;
-                    if (K != ckey) { /* the channel moves to another cell */
-                        if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
-                        cval = *cell_of(K);
-                        ckey = K;
-                        atomicMin(&sh_cmin[K >> 10], K & 1023u);
-                        atomicMax(&sh_cmax[K >> 10], K & 1023u);
-                    }
-                    cval += v;
+                    *cell(ccell) = cval;
+                    wave_lds_order();
+                    cval = *cell(K) + v;
+                    ccell = K;
                 }
                 if (sl >= 64u) break;
                 { /* the replayed call works on LDS directly: write the cached cells back first */
                     const osmt_label_seg q = label_seg_prep(segs[base + sl]);
-                    if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
-                    ckey = LC_NOCELL;
+                    *cell(ccell) = cval;
+                    ccell = LC_TRASH;
                     wave_lds_order();
                     if (active && y >= q.yf && y <= q.yl) {
                         int32_t x_min = INT32_MAX, x_max = INT32_MIN;
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(128) void k_label_cover(const osmt_labelinfo* __res
                 rest &= ~((2ull << sl) - 1ull);
             }
         }
-        if (ckey != LC_NOCELL) *cell_of(ckey) = cval;
+        *cell(ccell) = cval;
         wave_lds_order();
         c_min = min(c_min, sh_cmin[lane]);
         c_max = max(c_max, sh_cmax[lane]);
