@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -692,6 +693,8 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
     const size_t nsub = (W / OSMT_SUB_W) * (W / OSMT_SUB_H);
     unsigned long long groups = (unsigned long long)n_fills * nsub, recs = (unsigned long long)s->n_vsegs * nsub;
     const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 8ull) + ((unsigned long long)n_fills + s->n_strokes) * nsub * sizeof(osmt_ent);
+    /* (taking the worst case up to 2 GB instead — 1.8 GB for 1024 config-2 tiles — was tried to save this sizing run,
+     * 0.14 ms of a 0.84 ms upload: no gain on one thread, and four worker threads' arenas then outgrow the buffer cache) */
     if (worst_bytes > ((unsigned long long)32 << 20)) {
         hipStream_t st = s->own_stream;
         if (s->coord_kind != OSMT_COORD_POINT_I32)
@@ -782,6 +785,20 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         }
     }
 
+    /* OSMT_TRACE_UPLOAD=1 (diagnostic): where the host time of this call goes, one line on stderr */
+    static const bool trace_upload = getenv("OSMT_TRACE_UPLOAD") != nullptr;
+    using tclock = std::chrono::steady_clock;
+    tclock::time_point tp[6];
+    auto mark = [&](int i) {
+        if (trace_upload) tp[i] = tclock::now();
+    };
+    auto report = [&] {
+        if (!trace_upload) return;
+        auto us = [&](int a, int b2) { return std::chrono::duration<double, std::micro>(tp[b2] - tp[a]).count(); };
+        fprintf(stderr, "osmt upload: tables %.0f us, alloc %.0f us, copies %.0f us, coordinate check join %.0f us, arenas %.0f us\n",
+                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
+    };
+    mark(0);
     osmt_scene* s = new (std::nothrow) osmt_scene();
     if (!s) return fail(OSMT_OOM, "out of host memory");
     s->own_stream = st;
@@ -900,7 +917,9 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
     s->bytes = off + 256;
+    mark(1);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
+    mark(2);
     if (e != hipSuccess) {
         scene_delete(s);
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
@@ -971,8 +990,12 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             scene_delete(s);
             return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
         }
+        mark(3);
         rc = cc.join(); /* no kernel has seen the coordinates yet */
+        mark(4);
         if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
+        mark(5);
+        report();
         if (rc != OSMT_OK) {
             osmt_scene_free(s);
             return rc;
@@ -1002,8 +1025,12 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
+    mark(3);
     rc = cc.join(); /* no kernel has seen the coordinates yet */
+    mark(4);
     if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
+    mark(5);
+    report();
     if (rc != OSMT_OK) {
         osmt_scene_free(s);
         return rc;

@@ -11,3 +11,5 @@ timeout 300 python tools/bench_e2e_breakdown.py 1024 > $O/e2e_breakdown.txt 2>&1
 timeout 300 python tools/bench_png_chunks.py 1 2 4 > $O/png_chunks.txt 2>&1
 OSMT_TIME_BIG=1 timeout 600 python tools/time_variants.py base > $O/stage_times.txt 2>&1; cat $O/stage_times.txt
 timeout 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+bash tools/bench_label_variants.sh > $O/labels_kernel_trace.txt 2>&1; tail -4 $O/labels_kernel_trace.txt
+bash tools/pmc_labels.sh > $O/labels_pmc.txt 2>&1
