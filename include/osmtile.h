@@ -278,10 +278,11 @@ int osmt_encode_png(const uint8_t* rgba, uint32_t width, uint32_t height, size_t
                     uint8_t* out_png, size_t out_capacity, size_t* out_len);
 
 /* ---- PNG files produced on the GPU ---------------------------------------- */
-/* The same file format as above (RGB8, one IDAT) written by a HIP kernel, one wave per tile: Paeth-filtered
- * rows, one fixed-Huffman deflate block with distance-1 run matches, Adler-32 and chunk CRCs computed on the
- * device.  Decoded pixels equal the framebuffer; a map tile shrinks ~4-5x, so a server moves ~50 KB per tile
- * over PCIe instead of 256 KB and spends no host time in zlib.
+/* The same file format as above (RGB8, one IDAT) written by a HIP kernel, one workgroup per tile: Paeth-filtered
+ * rows, one deflate block with distance-1 run matches under a prefix code fitted to map tiles (the same "dynamic
+ * Huffman" header in every file), Adler-32 and chunk CRCs computed on the device.  Decoded pixels equal the
+ * framebuffer; a map tile shrinks 5-8x, so a server moves 30-50 KB per tile over PCIe instead of 256 KB and spends
+ * no host time in zlib.
  * d_rgba: n framebuffers (RGBA8, rows tightly packed) tile_stride bytes apart; d_png: n slots png_stride >=
  * osmt_png_device_bound(W, H) bytes apart (multiples of 4); d_len[i] = size of file i.  W multiple of 4, <= 1024. */
 size_t osmt_png_device_bound(uint32_t width, uint32_t height);

@@ -23,6 +23,7 @@
 #include "../../include/osmtile.h"
 #include "osmt_geom.h"
 #include "osmt_internal.h"
+#include "osmt_png_table.h" /* PNG_LMAX, PNG_BLOCK_HDR_BITS: the slot bound */
 
 namespace {
 
@@ -1503,10 +1504,11 @@ static uint32_t ihdr_crc(uint32_t W, uint32_t H) {
 }
 
 size_t osmt_png_device_bound(uint32_t W, uint32_t H) {
-    /* 43 header bytes + one fixed-Huffman block of at most 9 bits per filtered byte + EOB, Adler, CRC, IEND */
-    const size_t bits = 3 + (size_t)H * (3 * (size_t)W + 1) * 9 + 7;
-    /* + 4 x 3 words of slack: the fast kernel stages four row bands in the slot, each rounded up to words */
-    return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8 + 128, 256);
+    /* 43 header bytes + one deflate block (its constant header, then at most PNG_LMAX bits per filtered byte, EOB) +
+     * Adler, CRC, IEND */
+    const size_t bits = PNG_BLOCK_HDR_BITS + (size_t)H * (3 * (size_t)W + 1) * PNG_LMAX + PNG_LMAX;
+    /* + slack: the fast kernel stages four row bands in the slot behind the header words, each rounded up to words */
+    return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8 + 4 * PNG_HEAD_WORDS + 128, 256);
 }
 
 static int osmt_encode_png_device_body(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, void* d_png,

@@ -7,31 +7,41 @@
 #include <stdint.h>
 
 #include "osmt_internal.h"
+#define PNG_TABLE_QUAL static __device__ __constant__
+#include "osmt_png_table.h"
 
 /* ------------------------------------------------------------------------- */
-/* PNG encoding on the GPU (rgb_triples_to_png, png_writer.rs:4-21): one wave per tile
- * turns an RGBA8 framebuffer into a complete RGB8 PNG file — Paeth-filtered rows, ONE fixed-Huffman deflate
- * block whose only matches are distance-1 runs, Adler-32, chunk CRCs — so that a serving pipeline moves
- * ~50 KB per tile over PCIe instead of 256 KB and the host does no zlib work.  The reference's tests compare
- * decoded pixels only (tests/test_rendering.rs:15-23), so the encoder is free to differ from the png crate.
+/* PNG encoding on the GPU (rgb_triples_to_png, png_writer.rs:4-21): one workgroup per tile
+ * turns an RGBA8 framebuffer into a complete RGB8 PNG file — Paeth-filtered rows, ONE deflate block whose only
+ * matches are distance-1 runs, Adler-32, chunk CRCs — so that a serving pipeline moves ~45 KB per tile over PCIe
+ * instead of 256 KB and the host does no zlib work.  The reference's tests compare decoded pixels only
+ * (tests/test_rendering.rs:15-23), so the encoder is free to differ from the png crate.
+ * The block is a "dynamic Huffman" one whose code is the SAME for every tile (osmt_png_table.h, fitted to map tiles by
+ * tools/make_png_huffman.py: -20 % against the fixed code of RFC 1951, what a per-tile code would give, without a
+ * second pass): the 521 header bits are a constant, a token is a table look-up (LDS copy of the table).
  *
  * Per row (3W+1 filtered bytes in LDS, one wave): lanes own contiguous byte spans; a byte starts a run when it differs
  * from its predecessor; a run (v, L) becomes literal(v), matches(len <= 258, dist 1) for the other L-1 bytes,
  * and at most two trailing literals.  Bit counts are prefix-summed across lanes and tokens are OR-ed into an LDS
  * bit buffer; rows are sized first so that every row knows its bit position in the file (see k_png_encode). */
 #define PNG_HDR_BYTES 43u /* 8 signature + 25 IHDR + 4 IDAT length + 4 "IDAT" + 2 zlib header */
+#define PNG_TOKENS_BIT (PNG_HDR_BYTES * 8u + PNG_BLOCK_HDR_BITS) /* file bit the first token starts at */
+#define PNG_HEAD_FULL_WORDS ((PNG_TOKENS_BIT >> 5) - 10u)          /* words 10 .. that hold header bits only */
+static_assert(PNG_HEAD_WORDS == PNG_HEAD_FULL_WORDS + ((PNG_TOKENS_BIT & 31u) ? 1u : 0u), "osmt_png_table.h: head words");
+static_assert(PNG_LMAX + 5u + 1u <= 32u, "a token fits one png_put");
+#define PNG_TAB_WORDS 286u
 
-__device__ __forceinline__ void png_lit(uint32_t v, uint32_t& bits, uint32_t& n) {
-    if (v < 144u) {
-        bits = __brev(0x30u + v) >> 24;
-        n = 8u;
-    } else {
-        bits = __brev(0x190u + (v - 144u)) >> 23;
-        n = 9u;
-    }
+/* `tab`: the LDS copy of png_code_table (bit-reversed code | length << 16) */
+__device__ __forceinline__ void png_tab_load(uint32_t* tab, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < PNG_TAB_WORDS; i += nthreads) tab[i] = png_code_table[i];
 }
-/* match of length L (3..258) at distance 1: length code + extra bits + the 5-bit distance code 0 */
-__device__ __forceinline__ void png_run(uint32_t L, uint32_t& bits, uint32_t& n) {
+__device__ __forceinline__ void png_lit(const uint32_t* tab, uint32_t v, uint32_t& bits, uint32_t& n) {
+    const uint32_t e = tab[v];
+    bits = e & 0xFFFFu;
+    n = e >> 16;
+}
+/* match of length L (3..258) at distance 1: length code + extra bits + the one distance code (a single 0 bit) */
+__device__ __forceinline__ void png_run(const uint32_t* tab, uint32_t L, uint32_t& bits, uint32_t& n) {
     uint32_t idx, eb = 0u, ev = 0u;
     if (L == 258u) {
         idx = 28u;
@@ -43,28 +53,23 @@ __device__ __forceinline__ void png_run(uint32_t L, uint32_t& bits, uint32_t& n)
         idx = 4u + 4u * eb + ((l >> eb) & 3u);
         ev = l & ((1u << eb) - 1u);
     }
-    uint32_t hb, hn;
-    if (idx <= 22u) { /* codes 257..279: 7 bits */
-        hb = __brev(idx + 1u) >> 25;
-        hn = 7u;
-    } else { /* 280..285: 8 bits */
-        hb = __brev(0xC0u + idx - 23u) >> 24;
-        hn = 8u;
-    }
-    bits = hb | (ev << hn);
-    n = hn + eb + 5u;
+    const uint32_t e = tab[257u + idx];
+    const uint32_t hn = e >> 16;
+    bits = (e & 0xFFFFu) | (ev << hn);
+    n = hn + eb + 1u;
 }
 /* bits of the tokens of run (v, L) */
-__device__ __forceinline__ uint32_t png_run_bits(uint32_t v, uint32_t L) {
-    const uint32_t ln = v < 144u ? 8u : 9u;
+__device__ __forceinline__ uint32_t png_run_bits(const uint32_t* tab, uint32_t v, uint32_t L) {
+    const uint32_t ln = tab[v] >> 16;
     uint32_t total = ln, R = L - 1u;
-    while (R >= 258u) { /* code 285: 8 + 0 + 5 bits; at most 11 rounds per 1024-px row (no integer division) */
-        total += 13u;
+    const uint32_t n258 = (tab[285] >> 16) + 1u; /* code 285: no extra bits */
+    while (R >= 258u) { /* at most 11 rounds per 1024-px row (no integer division) */
+        total += n258;
         R -= 258u;
     }
     if (R >= 3u) {
         uint32_t b, n;
-        png_run(R, b, n);
+        png_run(tab, R, b, n);
         total += n;
     } else {
         total += R * ln;
@@ -109,8 +114,8 @@ __device__ __forceinline__ void png_filter_row(const uint8_t* __restrict__ src, 
 /* One row of the filtered stream, one wave.  EMIT = false: returns the row's bit count (lane-uniform) and its
  * Adler partial sums; EMIT = true: ORs the tokens into `bits` (zeroed, LDS) starting at bit 0. */
 template <bool EMIT>
-__device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB, uint32_t lane, uint32_t* bits, uint32_t& adler1,
-                                                   uint32_t& adler2) {
+__device__ __forceinline__ uint32_t png_row_tokens(const uint32_t* tab, const uint8_t* f, uint32_t NB, uint32_t lane, uint32_t* bits,
+                                                   uint32_t& adler1, uint32_t& adler2) {
     const uint32_t span = (NB - 1u + 63u) / 64u;
     const uint32_t s0 = min(NB, 1u + lane * span), s1 = min(NB, s0 + span);
     uint32_t first_start = 0xFFFFFFFFu;
@@ -128,13 +133,13 @@ __device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB
     const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
     const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
     const uint32_t nxt_pos = later ? nxt_pos_raw : NB; /* where the run that leaves this span ends */
-    uint32_t my_bits = lane == 0 ? 8u : 0u; /* the filter-type byte: literal(4) */
+    uint32_t my_bits = lane == 0 ? (tab[4] >> 16) : 0u; /* the filter-type byte: literal(4) */
     for (uint32_t k = s0; k < s1;) {
         const uint32_t v = f[k];
         const bool is_start = k == 1u || v != f[k - 1u];
         uint32_t e = k + 1u;
         while (e < s1 && f[e] == v) ++e;
-        if (is_start) my_bits += png_run_bits(v, ((e == s1) ? nxt_pos : e) - k);
+        if (is_start) my_bits += png_run_bits(tab, v, ((e == s1) ? nxt_pos : e) - k);
         k = e;
     }
     uint32_t incl = my_bits;
@@ -161,7 +166,7 @@ __device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB
     uint32_t pos = incl - my_bits;
     if (lane == 0) {
         uint32_t b, n;
-        png_lit(4u, b, n);
+        png_lit(tab, 4u, b, n);
         png_put(bits, pos, b, n);
     }
     for (uint32_t k = s0; k < s1;) {
@@ -172,13 +177,13 @@ __device__ __forceinline__ uint32_t png_row_tokens(const uint8_t* f, uint32_t NB
         if (is_start) {
             const uint32_t end = (e == s1) ? nxt_pos : e;
             uint32_t lb, ln;
-            png_lit(v, lb, ln);
+            png_lit(tab, v, lb, ln);
             png_put(bits, pos, lb, ln);
             uint32_t R = end - k - 1u;
             while (R >= 3u) {
                 const uint32_t m = min(R, 258u);
                 uint32_t b, n;
-                png_run(m, b, n);
+                png_run(tab, m, b, n);
                 png_put(bits, pos, b, n);
                 R -= m;
             }
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
                                                               uint32_t W, uint32_t H, uint32_t ihdr_crc, uint8_t* g_out,
                                                               size_t out_stride, uint32_t* __restrict__ g_len) {
     __shared__ uint8_t sh_f[PNG_WAVES][3u * PNG_MAX_W + 4u];
-    __shared__ uint32_t sh_bits[PNG_WAVES][(9u * (3u * PNG_MAX_W + 1u)) / 32u + 4u];
+    __shared__ uint32_t sh_bits[PNG_WAVES][(PNG_LMAX * (3u * PNG_MAX_W + 1u)) / 32u + 4u];
+    __shared__ uint32_t sh_tab[PNG_TAB_WORDS];
     __shared__ uint32_t sh_rowpos[PNG_MAX_W + 1u]; /* pass 1: bits of row y; after the scan: its absolute bit position */
     __shared__ uint32_t sh_a1[PNG_MAX_W], sh_a2[PNG_MAX_W];
     __shared__ uint32_t sh_crc_tab[256];
@@ -217,13 +223,15 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
         sh_crc_tab[i] = c;
     }
+    png_tab_load(sh_tab, tid, 64u * PNG_WAVES);
+    __syncthreads();
     /* ---- pass 1: size every row ---- */
     for (uint32_t y = wave; y < H; y += PNG_WAVES) {
         png_filter_row(src, W, y, lane, sh_f[wave]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t a1, a2;
-        const uint32_t rb = png_row_tokens<false>(sh_f[wave], NB, lane, nullptr, a1, a2);
+        const uint32_t rb = png_row_tokens<false>(sh_tab, sh_f[wave], NB, lane, nullptr, a1, a2);
         if (lane == 0) {
             sh_rowpos[y] = rb;
             sh_a1[y] = a1;
@@ -232,9 +240,9 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    /* ---- row positions (bit 0 of the deflate stream = byte 43, after the 3 block-header bits) + Adler-32 ---- */
+    /* ---- row positions (bit 0 of the deflate stream = byte 43; the block header comes first) + Adler-32 ---- */
     if (tid == 0) {
-        uint32_t pos = PNG_HDR_BYTES * 8u + 3u;
+        uint32_t pos = PNG_TOKENS_BIT;
         uint32_t A = 1u, B = 0u;
         for (uint32_t y = 0; y < H; ++y) {
             const uint32_t rb = sh_rowpos[y];
@@ -258,25 +266,25 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
         out_w[9] = 0x41444900u;
     }
     __syncthreads();
-    /* words shared by two rows (and the word the stream ends in) start from zero; word 10 carries 'T', the zlib
-     * header and the block header */
+    /* words shared by two rows (and the word the stream ends in) start from zero; words 10 .. carry 'T', the zlib
+     * header and the block header (the last of them may be where row 0 starts) */
     for (uint32_t y = tid; y <= H; y += 64u * PNG_WAVES) {
         const uint32_t w = sh_rowpos[y] >> 5;
-        if (w != 10u) out_w[w] = 0u;
-        if (y == H) out_w[w + 1u] = 0u; /* the 7 EOB bits may spill into the next word */
+        if (w >= 10u + PNG_HEAD_WORDS) out_w[w] = 0u;
+        if (y == H) out_w[w + 1u] = 0u; /* the end-of-block code may spill into the next word */
     }
-    if (tid == 0) out_w[10] = 0x00017854u | (3u << 24);
+    if (tid < PNG_HEAD_WORDS) out_w[10u + tid] = png_head_words[tid];
     __threadfence_block();
     __syncthreads();
     /* ---- pass 2: emit ---- */
-    const uint32_t nwords_row = (9u * NB) / 32u + 2u;
+    const uint32_t nwords_row = (PNG_LMAX * NB) / 32u + 2u;
     for (uint32_t y = wave; y < H; y += PNG_WAVES) {
         png_filter_row(src, W, y, lane, sh_f[wave]);
         for (uint32_t i = lane; i < nwords_row; i += 64u) sh_bits[wave][i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t a1, a2;
-        const uint32_t row_bits = png_row_tokens<true>(sh_f[wave], NB, lane, sh_bits[wave], a1, a2);
+        const uint32_t row_bits = png_row_tokens<true>(sh_tab, sh_f[wave], NB, lane, sh_bits[wave], a1, a2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t gbit = sh_rowpos[y];
@@ -297,10 +305,16 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
     }
     __threadfence_block();
     __syncthreads();
-    /* end of block (7 zero bits: already there), pad to a byte, Adler-32, IDAT length */
-    const uint32_t gend = sh_rowpos[H] + 7u;
+    /* end of block, pad to a byte, Adler-32, IDAT length */
+    const uint32_t eob = sh_tab[256];
+    const uint32_t gend = sh_rowpos[H] + (eob >> 16);
     const uint32_t endb = (gend + 7u) >> 3; /* first byte after the deflate stream */
     if (tid == 0) {
+        { /* the words the code lands in were zeroed above; the last row's bits are in (barrier) */
+            const uint32_t pos = sh_rowpos[H], w = pos >> 5, sh = pos & 31u, eb = eob & 0xFFFFu;
+            out_w[w] |= eb << sh;
+            if (sh + (eob >> 16) > 32u) out_w[w + 1u] |= eb >> (32u - sh);
+        }
         const uint32_t adler = sh_adler;
         out[endb + 0u] = (uint8_t)(adler >> 24);
         out[endb + 1u] = (uint8_t)(adler >> 16);
@@ -371,8 +385,9 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
                                                          uint32_t H, uint32_t ihdr_crc, uint8_t* g_out, size_t out_stride,
                                                          uint32_t band_cap_words, uint32_t* __restrict__ g_len) {
     constexpr uint32_t W = 64u * PX, NB = 3u * W + 1u, NBY = 3u * PX; /* bytes per lane */
-    constexpr uint32_t ROWW = (9u * NB) / 32u + 3u;
+    constexpr uint32_t ROWW = (PNG_LMAX * NB) / 32u + 3u;
     __shared__ uint32_t sh_bits[4][ROWW];
+    __shared__ uint32_t sh_tab[PNG_TAB_WORDS];
     __shared__ uint32_t sh_crc_tab[256];
     __shared__ uint32_t sh_col[32];
     __shared__ uint32_t sh_raw[256];
@@ -390,11 +405,15 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
         sh_crc_tab[i] = c;
     }
+    png_tab_load(sh_tab, tid, 256u);
+    __syncthreads();
     const uint32_t rows = H / 4u, y_begin = wave * rows, y_end = y_begin + rows;
     /* where this band's bits go while it is being produced */
-    const uint32_t stage_w = wave == 0u ? 0u : 11u + wave * band_cap_words; /* band 0: the file itself */
-    uint32_t gbit = wave == 0u ? PNG_HDR_BYTES * 8u + 3u : 0u;               /* bit cursor relative to out_w[stage_w] */
-    uint32_t carry = wave == 0u ? (0x00017854u | (3u << 24)) : 0u;           /* band 0 continues word 10 */
+    const uint32_t stage_w = wave == 0u ? 0u : 11u + PNG_HEAD_WORDS + wave * band_cap_words; /* band 0: the file itself */
+    uint32_t gbit = wave == 0u ? PNG_TOKENS_BIT : 0u;                        /* bit cursor relative to out_w[stage_w] */
+    /* band 0 continues the last word of the block header */
+    uint32_t carry = (wave == 0u && (PNG_TOKENS_BIT & 31u)) ? png_head_words[PNG_HEAD_WORDS - 1u] : 0u;
+    if (tid < PNG_HEAD_FULL_WORDS) out_w[10u + tid] = png_head_words[tid]; /* 'T', zlib header, block header */
     if (tid == 0) {
         out_w[0] = 0x474E5089u;
         out_w[1] = 0x0A1A0A0Du;
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
         const uint32_t nxt_pos = later ? nxt_pos_raw : NB;
         /* ---- size, prefix, emit ---- */
-        uint32_t my_bits = lane == 0u ? 8u : 0u, a1 = lane == 0u ? 4u : 0u, a2 = lane == 0u ? NB * 4u : 0u;
+        uint32_t my_bits = lane == 0u ? (sh_tab[4] >> 16) : 0u, a1 = lane == 0u ? 4u : 0u, a2 = lane == 0u ? NB * 4u : 0u;
 #pragma unroll
         for (int i = 0; i < (int)NBY; ++i) {
             a1 += fb[i];
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
             if ((startmask >> i) & 1u) {
                 const uint32_t rest = startmask >> (i + 1); /* i + 1 < 32 always: NBY <= 24 */
                 const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
-                my_bits += png_run_bits(fb[i], end - (base + (uint32_t)i));
+                my_bits += png_run_bits(sh_tab, fb[i], end - (base + (uint32_t)i));
             }
         }
         uint32_t incl = my_bits;
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         uint32_t pos = incl - my_bits;
         if (lane == 0u) {
             uint32_t b, n;
-            png_lit(4u, b, n);
+            png_lit(sh_tab, 4u, b, n);
             png_put(bits, pos, b, n);
         }
 #pragma unroll
@@ -505,13 +524,13 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
                 const uint32_t rest = startmask >> (i + 1);
                 const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
                 uint32_t lb, ln;
-                png_lit(fb[i], lb, ln);
+                png_lit(sh_tab, fb[i], lb, ln);
                 png_put(bits, pos, lb, ln);
                 uint32_t R = end - (base + (uint32_t)i) - 1u;
                 while (R >= 3u) {
                     const uint32_t m = min(R, 258u);
                     uint32_t b, n;
-                    png_run(m, b, n);
+                    png_run(sh_tab, m, b, n);
                     png_put(bits, pos, b, n);
                     R -= m;
                 }
@@ -558,17 +577,17 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
     /* flush the band's partial word (upper bits zero) and publish its length and checksum */
     if (lane == 0u) {
         if (gbit & 31u) out_w[stage_w + (gbit >> 5)] = carry;
-        sh_band_bits[wave] = wave == 0u ? gbit - (PNG_HDR_BYTES * 8u + 3u) : gbit;
+        sh_band_bits[wave] = wave == 0u ? gbit - PNG_TOKENS_BIT : gbit;
         sh_band_a[wave] = adler_a;
         sh_band_b[wave] = adler_b;
     }
     __threadfence_block();
     __syncthreads();
     /* ---- move bands 1..3 down behind their predecessors ---- */
-    uint32_t endpos = PNG_HDR_BYTES * 8u + 3u + sh_band_bits[0];
+    uint32_t endpos = PNG_TOKENS_BIT + sh_band_bits[0];
     for (uint32_t b = 1; b < 4u; ++b) {
         const uint32_t L = sh_band_bits[b];
-        const uint32_t sw = 11u + b * band_cap_words; /* staging: bit 0 of out_w[sw] */
+        const uint32_t sw = 11u + PNG_HEAD_WORDS + b * band_cap_words; /* staging: bit 0 of out_w[sw] */
         const uint32_t sh = endpos & 31u, wb = endpos >> 5;
         const uint32_t n_src = (L + 31u) >> 5;
         const uint32_t n_dst = ((endpos + L + 31u) >> 5) - wb; /* destination words holding bits of this band */
@@ -588,9 +607,15 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         }
         endpos += L;
     }
-    /* end of block: 7 zero bits (the word after the last one may receive some of them) */
+    /* end of block (the stream's last word has zeros above its bits; the code may spill into the next one) */
+    const uint32_t eob = sh_tab[256];
     if (tid == 0) {
-        if (((endpos + 7u) >> 5) != (endpos >> 5) || !(endpos & 31u)) out_w[(endpos + 7u) >> 5] = 0u;
+        const uint32_t w = endpos >> 5, sh = endpos & 31u, eb = eob & 0xFFFFu;
+        if (sh)
+            out_w[w] |= eb << sh;
+        else
+            out_w[w] = eb;
+        if (sh + (eob >> 16) > 32u) out_w[w + 1u] = eb >> (32u - sh);
         /* Adler-32 of the concatenation (zlib's adler32_combine): A = A1 + A2 - 1, B = B1 + B2 + len2 * (A1 - 1) */
         unsigned long long A = sh_band_a[0], B = sh_band_b[0];
         const unsigned long long len2 = (unsigned long long)rows * NB;
@@ -603,7 +628,7 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
     }
     __threadfence_block();
     __syncthreads();
-    const uint32_t gend = endpos + 7u;
+    const uint32_t gend = endpos + (eob >> 16);
     const uint32_t endb = (gend + 7u) >> 3;
     if (tid == 0) {
         const uint32_t adler = sh_move[0];
@@ -707,9 +732,9 @@ hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uin
     if (n == 0) return hipSuccess;
     if (W > PNG_MAX_W) return hipErrorInvalidValue;
     if ((W == 256u || W == 512u) && (H % 4u) == 0u && H >= 4u) {
-        /* staging capacity of one band: H/4 rows of at most 9 bits per filtered byte */
-        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * 9u + 31u) / 32u + 2u);
-        if ((size_t)(11u + 4u * band_cap_words) * 4u + 64u <= out_stride) {
+        /* staging capacity of one band: H/4 rows of at most PNG_LMAX bits per filtered byte */
+        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * PNG_LMAX + 31u) / 32u + 2u);
+        if ((size_t)(11u + PNG_HEAD_WORDS + 4u * band_cap_words) * 4u + 64u <= out_stride) {
             if (W == 256u)
                 hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
                                    ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);

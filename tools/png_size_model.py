@@ -5,7 +5,8 @@ For 8 config-2 tiles: the Paeth-filtered scanlines are tokenised the way k_png_e
 runs), then sized (a) with the fixed Huffman code the kernel emits, (b) with the optimal prefix code for the tile's
 own literal/length histogram (+ header), and (c) compressed by zlib level 6, which also finds real LZ77 matches.
 Result (round 2): fixed 59 KB, dynamic 47 KB, zlib-6 42 KB per tile — dynamic tables are worth 20 %, not the 45 % the
-gap to a full encoder suggests; see DESIGN.md 3.7."""
+gap to a full encoder suggests; see DESIGN.md 3.7.
+(Round 3 built the cheaper cousin: ONE code fitted to map tiles and shared by every tile, tools/make_png_huffman.py.)"""
 import heapq
 import os
 import sys
