@@ -421,73 +421,6 @@ __device__ __forceinline__ double opacity_by_center_distance(double cd, double h
     return opacity_mul * v;
 }
 
-/* x / d with the (very common) d == 1.0 short-cut: x / 1.0 == x exactly */
-__device__ __forceinline__ double div_or_same(double x, double d) { return d == 1.0 ? x : x / d; }
-
-/* opacity_calculator.rs:32-80 calculate (+ get_opacity_by_start_distance).  `sa` carries the
- * per-op constants of the cap_dist == 0 case (half_line_width = sqrt(h*h - 0*0) and its
- * feather terms), which is every pixel unless a Round cap shrinks the line. */
-__device__ __forceinline__ bool opacity_calculate(const osmt_dash_table* __restrict__ t,
-                                                  const osmt_stroke_aux* __restrict__ sa, double traveled, double cd,
-                                                  double sd, double* opacity) {
-    double sd_op = 1.0;
-    double cap_dist = 0.0;
-    const int n = t->n_segs;
-    if (n > 0) {
-        double dist_rem = traveled + sd;
-        const double total = t->total_len;
-        if (total > 0.0) dist_rem = osmt_fmod_pos(dist_rem, total); /* dist_rem >= 0: exact `%` */
-        sd_op = 0.0;
-        bool has = false;
-        double dic = 0.0;
-        const int has_orig = t->has_orig;
-        for (int i = 0; i < n; ++i) {
-            const osmt_dash_seg* s = &t->segs[i];
-            /* :145-157 */
-            if (dist_rem < s->start_from || dist_rem > s->end_to) continue;
-            double base;
-            if (dist_rem <= s->start_to)
-                base = div_or_same(dist_rem - s->start_from, s->start_to - s->start_from);
-            else if (dist_rem < s->end_from)
-                base = 1.0;
-            else
-                base = div_or_same(s->end_to - dist_rem, s->end_to - s->end_from);
-            sd_op = fmax(sd_op, s->opacity_mul * base);
-            if (has_orig) { /* :159-169 */
-                double d;
-                if (dist_rem < s->orig_a)
-                    d = s->orig_a - dist_rem;
-                else if (dist_rem <= s->orig_b)
-                    d = 0.0;
-                else
-                    d = dist_rem - s->orig_b;
-                if (!has || d < dic) {
-                    has = true;
-                    dic = d;
-                }
-            }
-        }
-        cap_dist = has ? dic : 0.0;
-    }
-    double cdop;
-    if (cap_dist == 0.0) {
-        /* sqrt(h*h - 0*0) and its feather terms: the per-op constants (opacity_calculator.rs:36,171-176) */
-        double v;
-        if (cd < sa->ff0)
-            v = 1.0;
-        else if (cd < sa->ft0)
-            v = div_or_same(sa->ft0 - cd, sa->fd0);
-        else
-            v = 0.0;
-        cdop = sa->mul0 * v;
-    } else {
-        const double hw = sa->half_width;
-        cdop = opacity_by_center_distance(cd, sqrt(hw * hw - cap_dist * cap_dist));
-    }
-    *opacity = fmin(sd_op, cdop);
-    return cdop > 0.0;
-}
-
 /* f64::from(c) / 255.0 for every u8 (tile_pixels.rs:226-228): the compiler folds each entry with a correctly rounded
  * IEEE division, so a lookup returns exactly what the reference computes — without three f64 divisions per op. */
 #define OSMT_C4(i) (double)(i) / 255.0, (double)((i) + 1) / 255.0, (double)((i) + 2) / 255.0, (double)((i) + 3) / 255.0
@@ -511,10 +444,6 @@ static_assert(SEGCAP >= 8 && SEGCAP <= 64, "a filter pass is at most one wave wi
 #define OSMT_V_PLANE_STRIDE 32
 #endif
 constexpr int PLANE_STRIDE = OSMT_V_PLANE_STRIDE;
-#ifndef OSMT_V_ROWCAP
-#define OSMT_V_ROWCAP 16
-#endif
-constexpr int ROWCAP = OSMT_V_ROWCAP; /* crossing records kept per row before the slow path (k_fill_rows) */
 
 #if defined(OSMT_ABL) && OSMT_ABL == 5
 #define OSMT_DBG(...) __VA_ARGS__
@@ -812,7 +741,7 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
 
 /* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
  * repeated minimum search and OR the paired spans that fall into [x0, x1].  Used only for rows
- * with more than ROWCAP crossings (cold; deliberately not inlined). */
+ * whose crossings overflow the record segment of the fast path (cold; deliberately not inlined). */
 __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict__ rings, const int2* __restrict__ pts,
                                                     uint32_t ring_off, uint32_t n_rings, int32_t y, int32_t x0,
                                                     int32_t x1) {
