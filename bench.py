@@ -238,10 +238,16 @@ def main():
     n_dev = torch.cuda.device_count()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
-    if n_dev < args.gpus:
-        # never a silent N = 1 run under an N-GPU label
+    launched = "WORLD_SIZE" in os.environ
+    pinned = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if n_dev < args.gpus and not (launched and pinned):
+        # never a silent N = 1 run under an N-GPU label.  Not under a launcher that pins one device per rank
+        # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, common under SLURM): every rank of a correctly provisioned N-GPU
+        # job then sees ONE device — there the check is the all-reduced rank count below (rccl_nranks_seen == N)
         sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible: refusing to run")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if launched and n_dev < 1:
+        sys.exit("bench.py: no GPU visible to this rank: refusing to run")
+    if not launched and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run on
         # 127.0.0.1), the way the reference deals tiles to its own workers (src/http_server.rs:50-83,105-108)
         sys.exit(self_launch(args.gpus))
@@ -254,6 +260,8 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        if local_rank >= n_dev:
+            local_rank = 0  # one pinned device per rank: it is device 0 of this process
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -305,6 +313,8 @@ def main():
             one = torch.ones(1, dtype=torch.int64, device=dev)
             dist.all_reduce(one)
             nranks_seen = int(one.item())
+        if nranks_seen != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the all-reduce of 1 over the job's ranks returned {nranks_seen}: refusing to report")
         if native_comm:
             collective = "osmt_allreduce_tile_count_enqueue (library-owned RCCL communicator, ncclAllReduce of one uint64 on the render stream)"
 

@@ -248,6 +248,12 @@ int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* scene, const osmt_label_bat
 /* Label statuses of the last osmt_render_scene (label_generation_statuses,
  * tile_pixels.rs:160-162): ok[i] = 1 if label i succeeded.  Synchronises the stream. */
 int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* scene, uint8_t* ok);
+/* Waits for the launches that read the scene (not for the device) and reports what they could not report themselves:
+ * osmt_render_scene is asynchronous, so a kernel-side internal error — a pre-pass arena that does not fit, which the
+ * sizing at upload rules out — would otherwise show as blank tiles.  OSMT_OK, or OSMT_HIP_ERROR with the detail in
+ * osmt_last_error().  The host-buffer calls (osmt_render_batch*) make the same check before they return.  (No analogue in
+ * the reference: its canvas is written synchronously by the calling thread, src/draw/drawer.rs:60-131.) */
+int osmt_scene_check(osmt_ctx* ctx, osmt_scene* scene);
 /* Copies the projected integer points of the scene back: xy = [n_pts][2]. */
 int osmt_scene_read_points(osmt_ctx* ctx, osmt_scene* scene, int32_t* xy);
 
@@ -293,6 +299,23 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
  * is too small, so the call can be repeated with out_off[n_jobs] bytes). */
 int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off);
+
+/* ---- the per-request entry: one worker handle per server thread (SURVEY.md 8(b) "Threading") ----------------
+ * The reference's server gives every request — ONE tile — to one of available_parallelism() worker threads, each
+ * with a TilePixels of its own (src/http_server.rs:50-83,105-108,134-181: handle_connection -> draw_tile_png).
+ * An osmt_worker is that per-thread handle.  osmt_worker_render is osmt_render_batch_rgb for the calling thread
+ * (same arguments, same pixels, same errors, blocks until out_rgb holds the tiles), but requests of different
+ * workers of one context that are in flight at the same moment are gathered into ONE launch sequence on the device:
+ * a request that finds the device free starts at once, alone; requests that arrive while it renders wait and go out
+ * together with the next one (at most 64 tiles per group, OSMT_WORKER_INFLIGHT = 2 groups on the device at a time).
+ * Sixteen threads calling the batch entry with one tile each queue up behind each other instead (round 3: 17 k
+ * tiles/s at p99 9.6 ms).  Any thread may use any worker; a worker keeps its context alive like a scene does.
+ * Batches of more than 64 tiles are rendered directly. */
+typedef struct osmt_worker osmt_worker;
+int osmt_worker_create(osmt_ctx* ctx, osmt_worker** out_worker);
+void osmt_worker_destroy(osmt_worker* worker);
+int osmt_worker_render(osmt_worker* worker, const osmt_batch* batch, const osmt_label_batch* labels /* may be NULL */, uint8_t* out_rgb,
+                       size_t out_tile_stride_bytes);
 
 /* ---- one node, several GPUs ------------------------------------------------ */
 /* The reference deals tiles round-robin to its worker threads, each with its own TilePixels

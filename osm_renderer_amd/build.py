@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libosmtile.so")
 SOURCES = ["osmt_kernels.hip", "osmt_labels.hip", "osmt_pngenc.hip", "osmt_api.cpp", "osmt_png.cpp"]
-HEADERS = ["osmt_geom.h", "osmt_internal.h", os.path.join("..", "..", "include", "osmtile.h")]
+HEADERS = ["osmt_geom.h", "osmt_internal.h", "osmt_png_table.h", os.path.join("..", "..", "include", "osmtile.h")]
 # -ffp-contract=off: the reference never fuses a*b+c; its u8 output truncates, so an FMA flips pixels.
 # zlib: PNG encoding of rendered tiles (osmt_png.cpp); --no-undefined: a symbol lost in an edit fails the build, not the first call
 LIBS = ["-lz", "-ldl", "-lpthread", "-Wl,--no-undefined"]

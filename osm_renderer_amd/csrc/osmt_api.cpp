@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <dlfcn.h>
 
 #include <mutex>
@@ -102,6 +104,17 @@ struct osmt_ctx {
     void* comm = nullptr;
     uint32_t comm_rank = 0, comm_size = 0;
     unsigned long long* d_count = nullptr; /* device words of the reductions: [0], [1] blocking call, [2], [3] enqueued one */
+    /* One pinned, device-visible word per live scene: a pre-pass kernel whose arena reservation does not fit stores a code
+     * there (osmt_prepass_args.err) and the host reads it behind the synchronisation it does anyway — an internal error
+     * surfaces as OSMT_HIP_ERROR instead of blank tiles, and costs no copy and no extra wait. */
+    uint32_t* err_page = nullptr;
+    std::vector<uint16_t> err_free;
+    /* The gathering point of the per-request entry (osmt_worker_render): requests of concurrent worker threads wait here
+     * and are rendered together, see the "coalescing worker" section. */
+    std::mutex co_mu;
+    std::condition_variable co_cv;
+    std::deque<struct coalesce_req*> co_queue;
+    int co_in_flight = 0;
 };
 
 struct osmt_scene {
@@ -158,6 +171,7 @@ struct osmt_scene {
     std::mutex use_mu;
     std::vector<std::pair<hipStream_t, hipEvent_t>> last_use;
     void* h_stage = nullptr;          /* pinned staging of a packed upload, returned to the pool when the scene goes */
+    uint32_t* h_err = nullptr;        /* the scene's word of osmt_ctx::err_page (NULL: none left, errors stay unreported) */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
     char* d_lab_base = nullptr;
@@ -235,6 +249,33 @@ void stream_release(osmt_ctx* ctx, hipStream_t st) {
 }
 
 constexpr size_t STAGE_MAX_BYTES = (size_t)4 << 20; /* calls with more input than this copy array by array */
+constexpr uint32_t ERR_SLOTS = 1024;
+
+uint32_t* err_slot_acquire(osmt_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    if (!ctx->err_page) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, ERR_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        memset(p, 0, ERR_SLOTS * sizeof(uint32_t));
+        ctx->err_page = (uint32_t*)p;
+        ctx->err_free.reserve(ERR_SLOTS);
+        for (uint32_t i = ERR_SLOTS; i-- > 0;) ctx->err_free.push_back((uint16_t)i);
+    }
+    if (ctx->err_free.empty()) return nullptr;
+    uint32_t* w = ctx->err_page + ctx->err_free.back();
+    ctx->err_free.pop_back();
+    *w = 0u;
+    return w;
+}
+
+void err_slot_release(osmt_ctx* ctx, uint32_t* w) {
+    if (!w) return;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    ctx->err_free.push_back((uint16_t)(w - ctx->err_page));
+}
 
 void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
     bytes = align_up(bytes ? bytes : 1, (size_t)64 << 10);
@@ -332,6 +373,7 @@ void ctx_teardown(osmt_ctx* ctx) {
     for (auto& c : ctx->cache) (void)hipFree(c.p);
     for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
     for (auto& c : ctx->host_cache) (void)hipHostFree(c.p);
+    if (ctx->err_page) (void)hipHostFree(ctx->err_page);
     delete ctx;
 }
 
@@ -354,7 +396,21 @@ hipError_t copy_back(osmt_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 /* Host-buffer entry points: an internal error of the label coverage kernels (window overflow) must not return OSMT_OK
  * with wrong pixels.  Called after the call's work was enqueued on `st`; synchronises it. */
+/* the pre-pass kernels' word: valid once the stream(s) the scene was rendered on have been synchronised */
+int prepass_error_check(osmt_scene* sc) {
+    if (!sc->h_err) return OSMT_OK;
+    const uint32_t code = *(volatile uint32_t*)sc->h_err;
+    if (!code) return OSMT_OK;
+    *(volatile uint32_t*)sc->h_err = 0u;
+    return fail(OSMT_HIP_ERROR, "pre-pass arena overflow (internal error %u: %s arena)", code,
+                code == OSMT_PREPASS_ERR_FILL_ARENA ? "fill" : code == OSMT_PREPASS_ERR_STROKE_ARENA ? "stroke" : "list");
+}
+
 int label_error_check(osmt_scene* sc, hipStream_t st) {
+    {
+        const int rc = prepass_error_check(sc); /* every caller has synchronised the scene's stream(s) by now */
+        if (rc != OSMT_OK) return rc;
+    }
     if (!sc->n_labels) return OSMT_OK;
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, sc->d_lab_err, 4, hipMemcpyDeviceToHost, st));
@@ -367,6 +423,7 @@ int label_error_check(osmt_scene* sc, hipStream_t st) {
 void scene_delete(osmt_scene* s) {
     for (auto& u : s->last_use) (void)hipEventDestroy(u.second);
     osmt_ctx* ctx = s->ctx;
+    if (ctx) err_slot_release(ctx, s->h_err);
     delete s;
     if (ctx) ctx_release(ctx);
 }
@@ -536,6 +593,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.skey = sc->d_skey;
     a.fmask_cap = sizing ? 0ull : sc->fmask_cap;
     a.srec_cap = sizing ? 0ull : sc->srec_cap;
+    a.err = sizing ? nullptr : sc->h_err; /* hipHostMallocMapped memory: one address on both sides (unified addressing) */
     return a;
 }
 
@@ -869,6 +927,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
 
     s->ctx = ctx;
     ctx->refs.fetch_add(1);
+    s->h_err = err_slot_acquire(ctx);
     s->n_jobs = (uint32_t)b->n_jobs;
     s->n_ops = (uint32_t)b->n_ops;
     s->n_rings = (uint32_t)b->n_rings;
@@ -1328,6 +1387,17 @@ int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_ma
     return guarded([&] { return osmt_render_scene_stages_body(ctx, scene, stage_mask, d_out_rgba, stride, stream); });
 }
 
+static int osmt_scene_check_body(osmt_ctx* ctx, osmt_scene* sc) {
+    if (!ctx || !sc || sc->ctx != ctx) return fail(OSMT_INVALID_ARG, "bad ctx/scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(scene_wait_idle(sc));
+    return prepass_error_check(sc);
+}
+
+int osmt_scene_check(osmt_ctx* ctx, osmt_scene* scene) {
+    return guarded([&] { return osmt_scene_check_body(ctx, scene); });
+}
+
 static int osmt_scene_read_points_body(osmt_ctx* ctx, osmt_scene* sc, int32_t* xy) {
     if (!ctx || !sc || !xy) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1554,10 +1624,14 @@ static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, co
     const uint32_t min_chunk = std::max<uint32_t>(1u, 512u / (batch->scale * batch->scale));
     uint32_t chunk = n;
     if (n >= 2u * min_chunk) chunk = std::max<uint32_t>(min_chunk, (n + 1u) / 2u);
-    if (const char* ev_chunks = getenv("OSMT_PNG_CHUNKS")) { /* diagnostic: force the number of chunks */
-        const uint32_t k = (uint32_t)std::max(1, atoi(ev_chunks));
-        chunk = std::max<uint32_t>(1u, (n + k - 1u) / k);
-    }
+    /* OSMT_PNG_CHUNKS (diagnostic: force the number of chunks): read ONCE — getenv on every call from worker threads is
+     * not safe against a host that calls setenv — and clamped, so that a large value cannot turn one call into n events,
+     * n tiny encode launches and n copies */
+    static const int forced_chunks = [] {
+        const char* v = getenv("OSMT_PNG_CHUNKS");
+        return v ? std::min(std::max(atoi(v), 1), 16) : 0;
+    }();
+    if (forced_chunks) chunk = std::max<uint32_t>(1u, (n + (uint32_t)forced_chunks - 1u) / (uint32_t)forced_chunks);
     const uint32_t n_chunks = n ? (n + chunk - 1u) / chunk : 0u;
     char* d = nullptr;
     uint32_t* h_len = nullptr;       /* pinned: lengths come back asynchronously, offsets go out */
@@ -2189,6 +2263,303 @@ int osmt_render_batch_multi_ex(osmt_ctx* const* ctxs, uint32_t n, const osmt_bat
                                uint8_t* out, size_t stride, uint64_t* out_count) {
     return guarded([&] { return render_batch_multi_body(ctxs, n, batch, labels, flags, out, stride, out_count); });
 }
+
+}  // extern "C"
+
+/* ---- the per-request entry: worker handles that gather concurrent one-tile requests -------------------------------
+ * The reference's server hands ONE tile per request to each of available_parallelism() worker threads, every one with
+ * its own TilePixels (src/http_server.rs:50-83,105-108,134-181).  Sixteen threads that each run the whole chain — five
+ * pre-pass launches, a raster launch for 128 waves, a copy, a synchronisation — for one tile queue up behind each other
+ * on the device (round 3: 17 k tiles/s, p99 9.6 ms from 16 workers).  The GPU renders 16 tiles in the time of one, so
+ * the requests are gathered ("group commit"): a request that finds fewer than OSMT_WORKER_INFLIGHT groups on the
+ * device becomes a leader at once and takes EVERY request that is waiting (up to 64 tiles) with it; requests that
+ * arrive while the device is busy wait for the next leader.  No timer: a lone request never waits for company, and
+ * the group size follows the load.  The leader merges the display lists (a valid batch: op ranges partition the merged
+ * pool, every request was validated by its own thread), renders them with ONE launch sequence into pinned staging and
+ * every requester copies its own tiles out in parallel.  A group of one skips all of that and is osmt_render_batch_rgb. */
+struct coalesce_group {
+    osmt_ctx* ctx = nullptr;
+    void* stage = nullptr;
+    std::atomic<int> pending{0}; /* requesters that still have to copy their tiles out of `stage` */
+};
+
+struct coalesce_req {
+    const osmt_batch* b = nullptr;
+    const osmt_label_batch* lb = nullptr;
+    uint8_t* out = nullptr;
+    size_t stride = 0;
+    bool taken = false, done = false;
+    int rc = OSMT_OK;
+    std::string err;
+    coalesce_group* grp = nullptr; /* where the pixels are (NULL: already in `out`, or failed) */
+    const uint8_t* src = nullptr;
+};
+
+struct osmt_worker {
+    osmt_ctx* ctx = nullptr;
+};
+
+namespace {
+
+constexpr size_t CO_MAX_TILES = 64;
+
+int co_max_in_flight() {
+    static const int v = [] {
+        const char* e = getenv("OSMT_WORKER_INFLIGHT");
+        return e ? std::min(std::max(atoi(e), 1), 8) : 2;
+    }();
+    return v;
+}
+
+/* the display lists (and label lists) of several requests as ONE batch, in request order */
+struct merged_batch {
+    std::vector<osmt_tile_job> jobs;
+    std::vector<osmt_op> ops;
+    std::vector<osmt_ring> rings;
+    std::vector<double> latlon; /* per point, or the concatenated node tables */
+    std::vector<int32_t> points;
+    std::vector<uint32_t> node_refs;
+    std::vector<double> dashes;
+    std::vector<osmt_label> labels;
+    std::vector<uint32_t> job_label_off;
+    std::vector<double> segs;
+    osmt_batch b;
+    osmt_label_batch lb;
+    bool has_labels = false;
+};
+
+void merge_requests(const std::vector<coalesce_req*>& reqs, merged_batch* m) {
+    const osmt_batch* b0 = reqs[0]->b;
+    const bool ll = b0->coord_kind == OSMT_COORD_LATLON_F64, nr = b0->coord_kind == OSMT_COORD_NODE_REF;
+    for (const coalesce_req* r : reqs)
+        if (r->lb && r->lb->n_labels) m->has_labels = true;
+    if (m->has_labels) m->job_label_off.push_back(0u);
+    for (const coalesce_req* r : reqs) {
+        const osmt_batch* b = r->b;
+        const uint32_t op0 = (uint32_t)m->ops.size(), ring0 = (uint32_t)m->rings.size(), dash0 = (uint32_t)m->dashes.size();
+        const uint32_t pt0 = (uint32_t)(ll ? m->latlon.size() / 2 : nr ? m->node_refs.size() : m->points.size() / 2);
+        const uint32_t node0 = nr ? (uint32_t)(m->latlon.size() / 2) : 0u;
+        for (size_t j = 0; j < b->n_jobs; ++j) {
+            osmt_tile_job job = b->jobs[j];
+            job.op_off += op0;
+            job.pt_off += pt0;
+            m->jobs.push_back(job);
+        }
+        for (size_t o = 0; o < b->n_ops; ++o) {
+            osmt_op op = b->ops[o];
+            if (op.kind != OSMT_OP_NONE) {
+                op.ring_off += ring0;
+                if (op.kind == OSMT_OP_STROKE && op.has_dashes) op.dashes_off += dash0;
+            }
+            m->ops.push_back(op);
+        }
+        for (size_t k = 0; k < b->n_rings; ++k) {
+            osmt_ring ring = b->rings[k];
+            ring.first_pt += pt0;
+            m->rings.push_back(ring);
+        }
+        if (ll) {
+            m->latlon.insert(m->latlon.end(), b->latlon, b->latlon + 2 * b->n_pts);
+        } else if (nr) {
+            m->latlon.insert(m->latlon.end(), b->nodes, b->nodes + 2 * b->n_nodes);
+            for (size_t i = 0; i < b->n_pts; ++i) m->node_refs.push_back(b->node_refs[i] + node0);
+        } else {
+            m->points.insert(m->points.end(), b->points, b->points + 2 * b->n_pts);
+        }
+        if (b->n_dashes) m->dashes.insert(m->dashes.end(), b->dashes, b->dashes + b->n_dashes);
+        if (m->has_labels) {
+            const osmt_label_batch* lb = r->lb;
+            const uint32_t lab0 = (uint32_t)m->labels.size(), seg0 = (uint32_t)(m->segs.size() / 4);
+            if (lb && lb->n_labels) {
+                for (size_t i = 0; i < lb->n_labels; ++i) {
+                    osmt_label l = lb->labels[i];
+                    l.seg_off += seg0;
+                    m->labels.push_back(l);
+                }
+                m->segs.insert(m->segs.end(), lb->segs, lb->segs + 4 * lb->n_segs);
+                for (size_t j = 0; j < b->n_jobs; ++j) m->job_label_off.push_back(lab0 + lb->job_label_off[j + 1]);
+            } else {
+                for (size_t j = 0; j < b->n_jobs; ++j) m->job_label_off.push_back(lab0);
+            }
+        }
+    }
+    memset(&m->b, 0, sizeof m->b);
+    m->b.jobs = m->jobs.data();
+    m->b.n_jobs = m->jobs.size();
+    m->b.ops = m->ops.data();
+    m->b.n_ops = m->ops.size();
+    m->b.rings = m->rings.data();
+    m->b.n_rings = m->rings.size();
+    m->b.coord_kind = b0->coord_kind;
+    m->b.scale = b0->scale;
+    m->b.n_pts = ll ? m->latlon.size() / 2 : nr ? m->node_refs.size() : m->points.size() / 2;
+    m->b.latlon = ll ? m->latlon.data() : nullptr;
+    m->b.points = (!ll && !nr) ? m->points.data() : nullptr;
+    m->b.nodes = nr ? m->latlon.data() : nullptr;
+    m->b.n_nodes = nr ? m->latlon.size() / 2 : 0;
+    m->b.node_refs = nr ? m->node_refs.data() : nullptr;
+    m->b.dashes = m->dashes.data();
+    m->b.n_dashes = m->dashes.size();
+    memset(&m->lb, 0, sizeof m->lb);
+    m->lb.labels = m->labels.data();
+    m->lb.n_labels = m->labels.size();
+    m->lb.job_label_off = m->job_label_off.data();
+    m->lb.segs = m->segs.data();
+    m->lb.n_segs = m->segs.size() / 4;
+}
+
+/* label batches are validated where they are attached (osmt_scene_set_labels); here only what merging itself reads */
+int label_batch_shape_ok(const osmt_batch* b, const osmt_label_batch* lb) {
+    if (!lb || !lb->n_labels) return OSMT_OK;
+    if (!lb->labels || !lb->job_label_off || (lb->n_segs && !lb->segs)) return fail(OSMT_INVALID_ARG, "label batch: NULL pool");
+    if (lb->n_labels >= 0x7FFFFFFFull || lb->n_segs >= 0x7FFFFFFFull) return fail(OSMT_INVALID_ARG, "label batch too large");
+    if (lb->job_label_off[0] != 0u) return fail(OSMT_INVALID_ARG, "job_label_off[0] must be 0");
+    for (size_t j = 0; j < b->n_jobs; ++j)
+        if (lb->job_label_off[j + 1] < lb->job_label_off[j] || lb->job_label_off[j + 1] > lb->n_labels)
+            return fail(OSMT_INVALID_ARG, "job_label_off not monotonic / out of range at tile %zu", j);
+    if (lb->job_label_off[b->n_jobs] != lb->n_labels) return fail(OSMT_INVALID_ARG, "job_label_off[n_jobs] != n_labels");
+    return OSMT_OK;
+}
+
+/* renders the requests of one group; fills rc / err / grp / src of every request (the caller marks them done) */
+void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
+    auto run_alone = [&](coalesce_req* r) {
+        r->rc = osmt_render_batch_rgb(ctx, r->b, (r->lb && r->lb->n_labels) ? r->lb : nullptr, r->out, r->stride);
+        if (r->rc != OSMT_OK) r->err = osmt_last_error();
+    };
+    if (reqs.size() == 1) {
+        run_alone(reqs[0]);
+        return;
+    }
+    const size_t W = (size_t)OSMT_TILE_SIZE * reqs[0]->b->scale, tile_rgb = W * W * 3;
+    size_t n_tiles = 0;
+    for (const coalesce_req* r : reqs) n_tiles += r->b->n_jobs;
+    int rc = OSMT_OK;
+    void* stage = nullptr;
+    try {
+        merged_batch m;
+        merge_requests(reqs, &m);
+        stage = stage_acquire(ctx, n_tiles * tile_rgb);
+        if (!stage) {
+            rc = OSMT_OOM;
+        } else {
+            rc = osmt_render_batch_labels_body(ctx, &m.b, m.has_labels ? &m.lb : nullptr, (uint8_t*)stage, tile_rgb, true, true);
+        }
+    } catch (...) {
+        rc = OSMT_OOM;
+    }
+    if (rc != OSMT_OK) {
+        /* whatever went wrong (one request's labels refused, no pinned memory): every request on its own, so that a bad
+         * one fails alone */
+        if (stage) stage_release(ctx, stage);
+        for (coalesce_req* r : reqs) run_alone(r);
+        return;
+    }
+    coalesce_group* g = new coalesce_group();
+    g->ctx = ctx;
+    g->stage = stage;
+    g->pending.store((int)reqs.size());
+    size_t first = 0;
+    for (coalesce_req* r : reqs) {
+        r->grp = g;
+        r->src = (const uint8_t*)stage + first * tile_rgb;
+        r->rc = OSMT_OK;
+        first += r->b->n_jobs;
+    }
+}
+
+int worker_render_body(osmt_worker* w, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgb, size_t stride) {
+    if (!w || !w->ctx || !out_rgb) return fail(OSMT_INVALID_ARG, "NULL argument");
+    osmt_ctx* ctx = w->ctx;
+    int rc = validate_batch(batch); /* by the requesting thread: the merged batch is trusted */
+    if (rc != OSMT_OK) return rc;
+    rc = label_batch_shape_ok(batch, labels);
+    if (rc != OSMT_OK) return rc;
+    const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale, tile_rgb = W * W * 3;
+    if (stride < tile_rgb) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*3");
+    if (batch->n_jobs == 0) return OSMT_OK;
+    if (batch->n_jobs > CO_MAX_TILES) return osmt_render_batch_rgb(ctx, batch, labels, out_rgb, stride); /* a batch of its own anyway */
+
+    coalesce_req me;
+    me.b = batch;
+    me.lb = labels;
+    me.out = out_rgb;
+    me.stride = stride;
+    std::vector<coalesce_req*> group;
+    {
+        std::unique_lock<std::mutex> lk(ctx->co_mu);
+        ctx->co_queue.push_back(&me);
+        for (;;) {
+            if (me.done) break;
+            if (!me.taken && ctx->co_in_flight < co_max_in_flight()) {
+                /* leader: everything that waits and fits, in arrival order (its own request is in there) */
+                size_t tiles = 0;
+                const osmt_batch* b0 = ctx->co_queue.front()->b;
+                while (!ctx->co_queue.empty()) {
+                    coalesce_req* r = ctx->co_queue.front();
+                    if (r->b->scale != b0->scale || r->b->coord_kind != b0->coord_kind) break; /* the next leader's */
+                    if (!group.empty() && tiles + r->b->n_jobs > CO_MAX_TILES) break;
+                    tiles += r->b->n_jobs;
+                    r->taken = true;
+                    group.push_back(r);
+                    ctx->co_queue.pop_front();
+                }
+                ++ctx->co_in_flight;
+                lk.unlock();
+                coalesce_run_group(ctx, group);
+                lk.lock();
+                --ctx->co_in_flight;
+                for (coalesce_req* r : group) r->done = true;
+                group.clear();
+                ctx->co_cv.notify_all();
+                continue; /* its own request may have been behind an incompatible one: look again */
+            }
+            ctx->co_cv.wait(lk);
+        }
+    }
+    if (me.rc != OSMT_OK) return fail(me.rc, "%s", me.err.c_str());
+    if (me.grp) {
+        /* the requester's own share of the read-back: pinned staging -> its buffer, all requesters in parallel */
+        for (size_t j = 0; j < batch->n_jobs; ++j) memcpy(out_rgb + j * stride, me.src + j * tile_rgb, tile_rgb);
+        coalesce_group* g = me.grp;
+        if (g->pending.fetch_sub(1) == 1) {
+            stage_release(g->ctx, g->stage);
+            delete g;
+        }
+    }
+    return OSMT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osmt_worker_create(osmt_ctx* ctx, osmt_worker** out_worker) {
+    return guarded([&] {
+        if (!ctx || !out_worker) return fail(OSMT_INVALID_ARG, "NULL argument");
+        osmt_worker* w = new (std::nothrow) osmt_worker();
+        if (!w) return fail(OSMT_OOM, "out of host memory");
+        w->ctx = ctx;
+        ctx->refs.fetch_add(1); /* like a scene: the context outlives its workers */
+        *out_worker = w;
+        return (int)OSMT_OK;
+    });
+}
+
+void osmt_worker_destroy(osmt_worker* w) {
+    if (!w) return;
+    osmt_ctx* ctx = w->ctx;
+    delete w;
+    if (ctx) ctx_release(ctx);
+}
+
+int osmt_worker_render(osmt_worker* w, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgb, size_t out_tile_stride_bytes) {
+    return guarded([&] { return worker_render_body(w, batch, labels, out_rgb, out_tile_stride_bytes); });
+}
+
+}  // extern "C"
+
+extern "C" {
 
 static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy, double* out_read) {
     if (!ctx || !out_copy) return fail(OSMT_INVALID_ARG, "NULL argument");

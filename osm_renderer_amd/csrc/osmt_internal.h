@@ -269,7 +269,14 @@ struct osmt_prepass_args {
     osmt_srec* srec;
     uint2* skey;
     unsigned long long fmask_cap, srec_cap; /* arena capacities (groups / records); 0 = sizing pass: only the cursors are produced */
+    /* host-mapped (pinned, coherent) word of the scene, or NULL: a kernel whose arena reservation does not fit — it cannot,
+     * the arenas are sized by the same code; a future change to the binning that breaks the invariant must not show as
+     * silently blank tiles — stores an OSMT_PREPASS_ERR_* code here, the host looks at it after its own synchronisation */
+    uint32_t* err;
 };
+#define OSMT_PREPASS_ERR_FILL_ARENA 1u
+#define OSMT_PREPASS_ERR_STROKE_ARENA 2u
+#define OSMT_PREPASS_ERR_LIST_ARENA 4u
 
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
                                uint32_t n_pts, double scale, int32_t* pts, hipStream_t st);

@@ -393,12 +393,18 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         if (want_s) {
             const unsigned long long off = s_base + (s_incl - want_s);
             oi.arena_off = (uint32_t)off;
-            if (a.srec_cap && off + want_s > a.srec_cap) oi.rec_cap = 0; /* never: the arena was sized by this same code */
+            if (a.srec_cap && off + want_s > a.srec_cap) { /* never: the arena was sized by this same code */
+                oi.rec_cap = 0;
+                if (a.err) *(volatile uint32_t*)a.err = OSMT_PREPASS_ERR_STROKE_ARENA;
+            }
         }
         if (want_f) {
             const unsigned long long off = f_base + (f_incl - f);
             oi.arena_off = (uint32_t)off;
-            if (!(a.fmask_cap && off + want_f > a.fmask_cap)) oi.fill_geom = fill_geom_ok;
+            if (!(a.fmask_cap && off + want_f > a.fmask_cap))
+                oi.fill_geom = fill_geom_ok;
+            else if (a.err)
+                *(volatile uint32_t*)a.err = OSMT_PREPASS_ERR_FILL_ARENA;
         }
     }
     if (live) a.info[o] = oi;
@@ -434,7 +440,11 @@ constexpr int SUBH = OSMT_SUB_H;   /* sub-tile height */
 constexpr int NTHREADS = 64;       /* one wave per sub-tile: no cross-wave barrier anywhere */
 constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int ROWSTEP = NTHREADS / SUB;    /* rows between a thread's consecutive pixels */
-constexpr int OPCHUNK = NTHREADS;  /* ops culled per pass */
+#ifndef OSMT_V_OPCHUNK
+#define OSMT_V_OPCHUNK 32
+#endif
+constexpr int OPCHUNK = OSMT_V_OPCHUNK; /* list entries staged per pass (config 2: ~5 per sub-tile, config 5: ~107) */
+static_assert(OPCHUNK == 32 || OPCHUNK == 64, "a chunk is staged by one wave");
 #ifndef OSMT_V_SEGCAP
 #define OSMT_V_SEGCAP 32
 #endif
@@ -450,10 +460,20 @@ constexpr int PLANE_STRIDE = OSMT_V_PLANE_STRIDE;
 #else
 #define OSMT_DBG(...)
 #endif
-/* One compacted list entry of a chunk: everything the sequential per-op loop needs, staged in LDS by the lane that
- * owns the op, so the loop itself never waits for global memory. */
-typedef osmt_ent OpEntry; /* as k_sublist wrote it; .stage = FILL: index of the staged coverage words; STROKE: index of the staged
-                           * constants; 255: not staged */
+/* One list entry of a chunk as the sequential per-op loop wants it, staged in LDS by the lane that loaded it: the loop
+ * reads it with three uniform 16-byte LDS loads and never waits for global (or constant) memory.  The colour terms are
+ * the values the reference computes per op — from_color's o * (c / 255) (tile_pixels.rs:12-19) for a fill, c / 255 for
+ * a stroke (whose o is per pixel) — looked up and multiplied ONCE by the staging lane, 64 entries side by side,
+ * instead of three scalar table loads and their wait in front of every op. */
+struct alignas(16) StagedEnt {
+    double c0, c1, c2; /* FILL_COLOR: opacity * c/255 of r, g, b; STROKE: c/255 */
+    double op;         /* FILL_COLOR: 1.0 - opacity (blend_pixel's factor of the old colour); STROKE: opacity */
+    uint32_t arena;    /* as osmt_ent */
+    uint32_t kind_stage; /* kind | stage << 8; stage = FILL: index of the staged coverage words, STROKE: of the staged constants; 255: not staged */
+    uint32_t aux;
+    uint32_t nv;
+};
+static_assert(sizeof(StagedEnt) == 48, "three 16-byte LDS loads");
 /* per-op constants of the un-dashed / cap_dist == 0 across test (osmt_stroke_aux), staged with the entry */
 struct StrokeConst {
     double ff0, ft0, fd0, rfd0, mul0;
@@ -472,22 +492,36 @@ __device__ __forceinline__ uint32_t stroke_flags(const osmt_stroke_aux* __restri
 #endif
 constexpr int STAGECAP = OSMT_V_STAGECAP; /* fills / strokes of one chunk whose data is staged in LDS; the rest reads global memory */
 
+/* What every perpendicular run of a record needs and only the record determines (line.rs:75-104), computed ONCE by the
+ * record's lane of the filter pass instead of by every item lane of every walk pass. */
+struct alignas(8) SegDer {
+    int32_t a, b;     /* mn_delta, mx_delta (0 <= a <= b) */
+    float r2b, r2a;   /* v_rcp_f32 of 2b, 2a: quotient estimates of the closed forms (osmt_udiv24r_small) */
+    uint32_t w;       /* SEGW_* */
+    uint32_t n_main;  /* k_n0 + k_n1 */
+    /* center_dist_raw (line.rs:116-117) at the run start (k, c) is k * ru + c * rv, one pixel along the minor axis adds
+     * rv, one along the major axis ru (integers below 2^30: exact as f64) */
+    double ru, rv;
+};
+static_assert(sizeof(SegDer) == 40, "five 8-byte LDS words");
+constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_CAP = 8u, SEGW_SLOW = 16u;
+
 struct RasterShared {
-    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] lane iterations [5] fill visits [6] set pixels */
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [5] fill visits */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
+    SegDer der[SEGCAP];
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
-    uint8_t seg_cap[SEGCAP];        /* the record belongs to a cap stub (opacity_calculator_for_outer_caps, line.rs:22) */
     unsigned long long plane[PLANE_STRIDE * SUBH]; /* generation alpha plane (f64 bit patterns) */
-    OpEntry ent[OPCHUNK];           /* ops of the chunk that draw into this sub-tile, in order */
+    StagedEnt ent[OPCHUNK];         /* ops of the chunk that draw into this sub-tile, in order */
     uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
     StrokeConst sconst[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
     uint32_t farena[STAGECAP];      /* first coverage word of the staged fills */
-    uint8_t grp_base[OPCHUNK + 1];  /* first record lane of every list entry of a group */
-    uint8_t s_ent[OPCHUNK];         /* group-local index of the k-th STROKE entry of the group */
+    uint8_t mark[64];               /* filter pass: mark[s] = chunk index of the stroke entry whose slots start at lane s */
 #ifdef OSMT_V_LDSPAD
     uint8_t occupancy_experiment_pad[OSMT_V_LDSPAD];
 #endif
 };
+static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
 
 struct SubRect {
     int32_t x0, y0, x1, y1; /* inclusive */
@@ -525,54 +559,89 @@ struct RunState {
     int32_t d1x, d1y;       /* pixel - p1 (dashed runs: dist(pixel, p1), line.rs:119) */
 };
 
-/* One item of a segment record = one perpendicular run: items [0, k_n0 + k_n1) are the main perpendiculars of steps on
- * side +1 then -1, the rest the extra perpendiculars of line.rs:152-154, located directly by osmt_extra_event.
- * *skip_first: the run is the -1 side of a MAIN step — its first pixel is the Bresenham centre the +1 side of the
- * same step starts on as well (line.rs:139-141 calls both from the same point); see walk_plain. */
-__device__ __forceinline__ void walk_setup(RunState& st, const osmt_srec& r, uint32_t local, const SubRect& rc, bool* skip_first) {
+/* The record's share of a run's set-up (filter pass, lane = record). */
+__device__ __forceinline__ SegDer seg_derive(const osmt_srec& r, bool is_cap) {
     const int32_t dxs = r.p2x - r.p1x, dys = r.p2y - r.p1y; /* sdx, sdy (line.rs:102-103) */
     const int32_t adx = abs(dxs), ady = abs(dys);
     const bool swap = adx > ady; /* x is the major axis */
-    const int32_t a = swap ? ady : adx, b = swap ? adx : ady;
     const int32_t incx = r.p1x <= r.p2x ? 1 : -1, incy = r.p1y <= r.p2y ? 1 : -1;
-    const int32_t mn_inc = swap ? incy : incx, mx_inc = swap ? incx : incy;
-    const uint32_t n_main = (uint32_t)r.k_n0 + (uint32_t)r.k_n1;
-    int32_t k, c, pe, mul;
-    if (local < n_main) {
-        const bool side1 = local >= (uint32_t)r.k_n0;
-        k = side1 ? r.k_lo1 + (int32_t)(local - (uint32_t)r.k_n0) : r.k_lo0 + (int32_t)local;
-        mul = side1 ? -1 : 1;
-        *skip_first = side1;
-        osmt_stroke_main(a, b, k, &c, &pe);
+    SegDer d;
+    d.a = swap ? ady : adx;
+    d.b = swap ? adx : ady;
+    d.r2b = osmt_rcp24(2 * d.b);
+    d.r2a = osmt_rcp24(2 * d.a); /* a == 0: infinite, and never used (such a segment has no extra perpendiculars) */
+    d.w = (incx < 0 ? SEGW_INCX_NEG : 0u) | (incy < 0 ? SEGW_INCY_NEG : 0u) | (swap ? SEGW_SWAP : 0u) | (is_cap ? SEGW_CAP : 0u) |
+          (d.b >= OSMT_STEP24_MAX_B ? SEGW_SLOW : 0u);
+    d.n_main = (uint32_t)r.k_n0 + (uint32_t)r.k_n1;
+    /* raw = sdy * (px - p1x) - sdx * (py - p1y) (line.rs:116-117, the constant cancels at p1); the major axis unit is
+     * (incx, 0) when swapped, (0, incy) otherwise, the minor one the other */
+    const double fx = (double)(dys * incx), fy = (double)(-dxs * incy); /* |.| <= 2^29: 32-bit products of a delta and +-1 */
+    d.ru = swap ? fx : fy;
+    d.rv = swap ? fy : fx;
+    return d;
+}
+
+/* One item of a segment record = one perpendicular run: items [0, k_n0 + k_n1) are the main perpendiculars of steps on
+ * side +1 then -1, the rest the extra perpendiculars of line.rs:152-154.  Both kinds go through ONE instruction stream:
+ *   main  step k:  c = max(0, ceil((2a k - b) / 2b)),  d = max(0, ceil((2a c - b) / 2b)),  pe = 2a c - 2b d   (osmt_stroke_main)
+ *   extra event m: c = floor((2b m - b) / 2a) + 1,      k = floor((2b c - b) / 2a),          pe = 2a c - 2b m   (osmt_extra_event)
+ * i.e. twice q = n <= 0 ? 0 : floor((n + add) / Q) with (P, Q) = (2a, 2b) / (2b, 2a) and add = Q - 1 (a ceiling),
+ * Q (floor + 1; the numerator of an event is positive) or 0.  Records with b >= 2048 (SEGW_SLOW) take the 64-bit forms.
+ * *skip_first: the run is the -1 side of a MAIN step — its first pixel is the Bresenham centre the +1 side of the
+ * same step starts on as well (line.rs:139-141 calls both from the same point); see walk_plain. */
+__device__ __forceinline__ void walk_setup(RunState& st, const osmt_srec& r, const SegDer& d, uint32_t local, const SubRect& rc, bool* skip_first) {
+    const bool is_main = local < d.n_main;
+    const uint32_t x = is_main ? local : local - d.n_main;
+    const uint32_t n_first = is_main ? (uint32_t)r.k_n0 : (uint32_t)r.n_x0;
+    const bool side1 = x >= n_first;
+    const int32_t lo = is_main ? (side1 ? r.k_lo1 : r.k_lo0) : (side1 ? r.m_lo1 : r.m_lo0);
+    const int32_t idx = lo + (int32_t)(side1 ? x - n_first : x); /* the step k, or the event m */
+    *skip_first = is_main && side1;
+    const int32_t a = d.a, b = d.b;
+    int32_t c, k, pe;
+    if (!(d.w & SEGW_SLOW)) {
+        const int32_t P = is_main ? 2 * a : 2 * b, Q = is_main ? 2 * b : 2 * a;
+        const float rq = is_main ? d.r2b : d.r2a;
+        const int32_t n1 = OSMT_MUL24(P, idx) - b;
+        c = n1 <= 0 ? 0 : osmt_udiv24r_small(n1 + (is_main ? Q - 1 : Q), Q, rq);
+        const int32_t n2 = OSMT_MUL24(P, c) - b;
+        const int32_t v2 = n2 <= 0 ? 0 : osmt_udiv24r_small(n2 + (is_main ? Q - 1 : 0), Q, rq);
+        k = is_main ? idx : v2;
+        pe = OSMT_MUL24(2 * a, c) - OSMT_MUL24(2 * b, is_main ? v2 : idx);
+    } else if (is_main) {
+        k = idx;
+        osmt_stroke_main(a, b, idx, &c, &pe);
     } else {
-        const uint32_t x = local - n_main;
-        const bool side1 = x >= (uint32_t)r.n_x0;
-        const int32_t m = side1 ? r.m_lo1 + (int32_t)(x - (uint32_t)r.n_x0) : r.m_lo0 + (int32_t)x;
-        mul = side1 ? -1 : 1;
-        *skip_first = false;
-        osmt_extra_event(a, b, m, &c, &k, &pe);
+        osmt_extra_event(a, b, idx, &c, &k, &pe);
     }
-    /* start (p_mn, p_mx) = (mx, mn) of the main loop (line.rs:109-110), un-swapped (line.rs:113) */
-    const int32_t mxo = k * mx_inc, mno = c * mn_inc; /* offsets from p1 along the major / minor axis */
-    st.d1x = swap ? mxo : mno;
-    st.d1y = swap ? mno : mxo;
+    /* start (p_mn, p_mx) = (mx, mn) of the main loop (line.rs:109-110), un-swapped (line.rs:113): k steps along the
+     * major axis, c along the minor one */
+    const bool swap = (d.w & SEGW_SWAP) != 0u;
+    const bool xneg = (d.w & SEGW_INCX_NEG) != 0u, yneg = (d.w & SEGW_INCY_NEG) != 0u;
+    const int32_t tx = swap ? k : c, ty = swap ? c : k;
+    st.d1x = xneg ? -tx : tx; /* selects and negations, no integer multiplies (quarter rate) */
+    st.d1y = yneg ? -ty : ty;
     st.rx = r.p1x + st.d1x - rc.x0;
     st.ry = r.p1y + st.d1y - rc.y0;
-    st.err = mul * pe;
-    const int32_t step_mx = mul * mn_inc;  /* p_mx += (every iteration): moves the pixel along the MINOR axis of the segment */
-    const int32_t step_mn = -mul * mx_inc; /* p_mn -= mul * mx_inc (when corrected): along the major axis */
-    st.sx = swap ? 0 : step_mx;
-    st.sy = swap ? step_mx : 0;
-    st.cx = swap ? step_mn : 0;
-    st.cy = swap ? 0 : step_mn;
+    st.err = side1 ? -pe : pe; /* mul * p_error */
+    /* every iteration moves the pixel mul along the MINOR axis (p_mx += mul * mn_inc), a correction -mul along the major one */
+    const int32_t mx = (side1 != xneg) ? -1 : 1, my = (side1 != yneg) ? -1 : 1; /* mul * incx, mul * incy */
+    st.sx = swap ? 0 : mx;
+    st.sy = swap ? my : 0;
+    st.cx = swap ? -mx : 0;
+    st.cy = swap ? 0 : -my;
     st.two_a = 2 * a;
     st.two_b = 2 * b;
     st.b = b;
-    /* raw = numer_const + sdy*px - sdx*py (line.rs:116-117) = sdy*(px - p1x) - sdx*(py - p1y): the constant cancels at p1 */
-    const int64_t raw0 = (int64_t)dys * (int64_t)st.d1x - (int64_t)dxs * (int64_t)st.d1y;
-    st.raw = (double)raw0;
-    st.raw_step = (double)(dys * st.sx - dxs * st.sy); /* steps are 0 / +-1: 32-bit products */
-    st.raw_corr = (double)(dys * st.cx - dxs * st.cy);
+    if (!(d.w & SEGW_SLOW)) {
+        st.raw = fma((double)k, d.ru, (double)c * d.rv); /* integers below 2^42 (k, c <= 2048): exact whatever the rounding */
+    } else {
+        const int32_t dxs = r.p2x - r.p1x, dys = r.p2y - r.p1y;
+        st.raw = (double)((int64_t)dys * (int64_t)st.d1x - (int64_t)dxs * (int64_t)st.d1y);
+    }
+    const double sg = side1 ? -1.0 : 1.0;
+    st.raw_step = sg * d.rv;
+    st.raw_corr = -sg * d.ru;
     st.denom = r.denom;
     st.rdenom = r.rdenom;
 }
@@ -703,20 +772,19 @@ __device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc,
     }
 }
 
-/* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of one op, lanes packed: the record of item
- * `it` is the first slot whose inclusive item prefix exceeds it (bisection over the LDS prefix).  MODE 0 / 1: records
- * of un-dashed edges (feather_dist == 1.0 / any); MODE 2: `tab` is the calculator of these records. */
-template <int MODE, class Shared>
-__device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t slot0, uint32_t nslot, uint32_t item_base,
-                                           uint32_t it_lo, uint32_t it_hi, const StrokeConst& kc, const osmt_dash_table* __restrict__ tab,
-                                           double half_width, double initial_opacity, const SubRect& rc) {
-#if defined(OSMT_ABL) && OSMT_ABL == 7
-    if (MODE == 2) return; /* ablation: dashed / cap-stub runs are not walked */
-#endif
-#if defined(OSMT_ABL) && OSMT_ABL == 8
-    if (MODE != 2) return; /* ablation: plain runs are not walked */
-#endif
-    OSMT_DBG(if (lane == 0u) { sh.dbg[1] += (it_hi - it_lo + 63u) / 64u; sh.dbg[2] += it_hi - it_lo; if (MODE == 2) sh.dbg[3] += (it_hi - it_lo + 63u) / 64u; })
+/* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of ONE op — its edges' records and, behind them,
+ * its cap stubs' — lanes packed: the record of item `it` is the first slot whose inclusive item prefix exceeds it
+ * (bisection over the LDS prefix).  Edges and stubs share a pass (round 3 walked them in separate ones: a quarter of all
+ * passes carried the 2-6 items of two stubs and paid a whole set-up for them); what differs is the calculator, so the
+ * lanes of un-dashed edges run the plain loop and then the others run the full one once per table that has lanes —
+ * the table of a round is wave-uniform (scalar loads). */
+template <class Shared>
+__device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t slot0, uint32_t nslot, uint32_t item_base, uint32_t it_lo, uint32_t it_hi,
+                                           const StrokeConst& kc, uint32_t sflags, const osmt_stroke_aux* __restrict__ sa, double initial_opacity,
+                                           const SubRect& rc) {
+    OSMT_DBG(if (lane == 0u) { sh.dbg[1] += (it_hi - it_lo + 63u) / 64u; sh.dbg[2] += it_hi - it_lo; })
+    const bool main_plain = (sflags & STROKE_PLAIN_MAIN) != 0u;
+    const bool unit_fd = (sflags & (STROKE_UNIT_FD | STROKE_TINY_MUL)) == STROKE_UNIT_FD;
     for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
         uint32_t lo_s = slot0, n = nslot;
         while (n > 1u) {
@@ -727,15 +795,21 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
         }
         const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
         const osmt_srec& r = sh.seg[lo_s];
+        const SegDer& d = sh.der[lo_s];
+        const bool is_cap = (d.w & SEGW_CAP) != 0u;
         RunState st;
         bool skip_first;
-        walk_setup(st, r, it - base_items, rc, &skip_first);
-        if (MODE == 0)
-            walk_plain<true>(st, kc, initial_opacity, skip_first, sh.plane);
-        else if (MODE == 1)
-            walk_plain<false>(st, kc, initial_opacity, skip_first, sh.plane);
-        else
-            walk_dashed(st, kc, tab, half_width, r.traveled, initial_opacity, sh.plane);
+        walk_setup(st, r, d, it - base_items, rc, &skip_first);
+        if (main_plain && !is_cap) {
+            if (unit_fd)
+                walk_plain<true>(st, kc, initial_opacity, skip_first, sh.plane);
+            else
+                walk_plain<false>(st, kc, initial_opacity, skip_first, sh.plane);
+        } else {
+#pragma unroll 1
+            for (uint32_t t = main_plain ? 1u : 0u; t < 2u; ++t) /* t = 0: dashed edges (calculator `main`), 1: cap stubs (`caps`, line.rs:22) */
+                if (is_cap == (t == 1u)) walk_dashed(st, kc, t ? &sa->caps : &sa->main, sa->half_width, r.traveled, initial_opacity, sh.plane);
+        }
     }
 }
 
@@ -1366,7 +1440,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              const osmt_opinfo* __restrict__ g_info, const uint32_t* __restrict__ g_submask,
                                                              uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
                                                              unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
-                                                             osmt_ent* __restrict__ g_ent, unsigned long long ent_cap) {
+                                                             osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err) {
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1395,6 +1469,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
             const unsigned long long first = total ? atomicAdd(g_cursor, (unsigned long long)total) : 0ull;
             s_base[0] = (uint32_t)first;
             s_base[1] = (first + total <= ent_cap) ? 1u : 0u; /* always: the arena holds every (op, sub-tile) pair the binning can produce */
+            if (!s_base[1] && g_err) *(volatile uint32_t*)g_err = OSMT_PREPASS_ERR_LIST_ARENA; /* the tile would be blank: tell the host */
         }
     }
     __syncthreads();
@@ -1477,24 +1552,37 @@ __device__ __forceinline__ uint32_t fresh_lane() {
 /* The kernel's own argument block, re-read from the kernel-argument segment at the point of use: the empty asm makes
  * the pointer opaque, so the compiler can neither hoist the (invariant) loads to the top of the kernel nor keep their
  * results alive across the loops in between. */
+/* a (uniform) index the compiler cannot connect to the loads it already made with it */
+__device__ __forceinline__ uint32_t late_index(uint32_t i) {
+    asm volatile("" : "+s"(i));
+    return i;
+}
+
 __device__ __forceinline__ const osmt_raster_args* late_args() {
     const osmt_raster_args* p = (const osmt_raster_args*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
 }
 
-/* Filler::Image (fill.rs:36-40): icon.get(x % w, y % h) for the covered pixels of one lane (pixel j = column x, row
- * y0 + ROWSTEP * j), opacity ignored.  Deliberately NOT inlined: see the call. */
-__device__ __attribute__((noinline)) void fill_image_cold(double (*a)[3], uint32_t cov, const double4* __restrict__ ipx, uint32_t w, uint32_t h,
-                                                          uint32_t x, uint32_t y0) {
-    const uint32_t ix = x % w;
-    for (uint32_t j = 0; j < (uint32_t)PXT; ++j) {
-        if ((cov >> j) & 1u) {
-            const uint32_t iy = (y0 + j * (uint32_t)ROWSTEP) % h;
-            const double4 c = ipx[(size_t)iy * w + ix];
-            blend_rgb(a[j], c.x, c.y, c.z, c.w);
-        }
-    }
+/* blend_pixel (tile_pixels.rs:209-219) of one wave-uniform source colour into the pixels whose bit is set in `m`
+ * (bit = lane): new = s + k * old, k = 1 - alpha, mul then add (no FMA).  The coverage of a fill arrives as whole
+ * words, so the set of lanes IS the execution mask: six instructions for the covered lanes instead of six plus six
+ * selects (and the bit extraction) for all of them. */
+__device__ __forceinline__ void blend_masked(double& r, double& g, double& b, double sr, double sg, double sb, double k, unsigned long long m) {
+    unsigned long long save;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_and_b64 exec, %[sv], %[m]\n\t"
+        "v_mul_f64 %[r], %[k], %[r]\n\t"
+        "v_mul_f64 %[g], %[k], %[g]\n\t"
+        "v_mul_f64 %[b], %[k], %[b]\n\t"
+        "v_add_f64 %[r], %[sr], %[r]\n\t"
+        "v_add_f64 %[g], %[sg], %[g]\n\t"
+        "v_add_f64 %[b], %[sb], %[b]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "+v"(r), [g] "+v"(g), [b] "+v"(b), [sv] "=&s"(save)
+        : [k] "v"(k), [sr] "v"(sr), [sg] "v"(sg), [sb] "v"(sb), [m] "s"(m)
+        : "scc");
 }
 
 template <bool OUT_F64, bool LABELS>
@@ -1536,9 +1624,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     rc.x1 = rc.x0 + SUB - 1;
     rc.y1 = rc.y0 + SUBH - 1;
 
-    /* thread -> pixels: column lx, rows ly0 + 2*j; a wave covers two full 128-byte rows */
-    const uint32_t lx = tid & (SUB - 1);
-    const uint32_t ly0 = tid / SUB;
+    /* thread -> pixels: column tid % 32, rows tid / 32 + 2*j; a wave covers two full 128-byte rows.  (Both are
+     * re-derived from a fresh lane id where they are used: carried from here they occupy registers across every loop.) */
 
     /* tile_pixels.rs:89-93 reset.  Only r,g,b are carried: the canvas alpha starts at 1.0 and
      * blend_pixel keeps it at exactly 1.0 — fl(a + fl(1-a)*1.0) == 1.0 for every alpha in
@@ -1561,33 +1648,41 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
     OSMT_DBG(if (lane < 8) sh.dbg[lane] = 0u; __syncthreads();)
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    /* this sub-tile's own list (k_sublist): the ops that draw here, in order, 64 at a time.  (Fetching the next chunk's
-     * entries a chunk ahead cost eight registers for the whole chunk: 21 more spilled registers at 128, whose scratch
-     * stores more than doubled the kernel's HBM writes.) */
+    /* this sub-tile's own list (k_sublist): the ops that draw here, in order, OPCHUNK at a time.  (Fetching the next
+     * chunk's entries a chunk ahead cost eight registers for the whole chunk: 21 more spilled registers at 128, whose
+     * scratch stores more than doubled the kernel's HBM writes.) */
     const uint2 hdr = a.hdr[(size_t)tile * nsub + sub];
     const uint32_t n_ent = hdr.y;
     const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
-    auto load_ent = [&](uint32_t base) -> OpEntry {
-        OpEntry e_ = {};
-        if (base + lane < n_ent) e_ = my_ent[base + lane];
-        return e_;
-    };
 
     for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
         const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
         const bool hit = lane < total;
-        const unsigned long long bal = (total >= 64u) ? ~0ull : ((1ull << total) - 1ull);
-        OpEntry e = load_ent(base);
-        const bool is_stroke = hit && (e.kind_color & 255u) == OSMT_OP_STROKE;
-        const unsigned long long sbal = __ballot(is_stroke), fbal = bal & ~sbal;
-        const uint32_t pos = lane;
-        const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & lanes_below);
+        osmt_ent e = {};
+        if (hit) e = my_ent[base + lane];
+        const uint32_t e_kind = e.kind_color & 255u;
+        const bool is_stroke = hit && e_kind == OSMT_OP_STROKE;
+        const unsigned long long sbal = __ballot(is_stroke), fbal = __ballot(hit && !is_stroke);
+        const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & ((1ull << fresh_lane()) - 1ull));
+        /* slots of the stroke entries, prefix-summed over the chunk's lanes: the groups of the filter passes are cut out
+         * of this scan with a ballot instead of a scalar loop over the entries (clamped: only "more than a pass" matters) */
+        const uint32_t nv_incl = wave_incl_scan(is_stroke ? min(e.nv, 1u << 20) : 0u);
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
-            e.stage = my_stage < (uint32_t)STAGECAP ? my_stage : 255u;
-            sh.ent[pos] = e;
+            StagedEnt se;
+            const double cr = k_u8_over_255[(e.kind_color >> 8) & 255u], cg = k_u8_over_255[(e.kind_color >> 16) & 255u],
+                         cb = k_u8_over_255[e.kind_color >> 24];
+            const bool fc = e_kind == OSMT_OP_FILL_COLOR;
+            se.c0 = fc ? e.opacity * cr : cr; /* from_color: o * (c / 255) */
+            se.c1 = fc ? e.opacity * cg : cg;
+            se.c2 = fc ? e.opacity * cb : cb;
+            se.op = fc ? 1.0 - e.opacity : e.opacity;
+            se.arena = e.arena;
+            se.kind_stage = e_kind | ((my_stage < (uint32_t)STAGECAP ? my_stage : 255u) << 8);
+            se.aux = e.aux;
+            se.nv = e.nv;
+            sh.ent[lane] = se;
             if (!is_stroke && my_stage < (uint32_t)STAGECAP) sh.farena[my_stage] = e.arena;
             if (is_stroke && my_stage < (uint32_t)STAGECAP) {
                 /* constants of the across test (second round trip, in parallel for all strokes of the chunk) */
@@ -1624,59 +1719,54 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
 
         uint32_t g0 = 0;
         while (g0 < total) {
-        /* ---- group = consecutive list entries whose stroke slots fit in the 64 lanes of ONE filter pass;
-         * an op with more than 64 slots forms a group of its own and is filtered 64 slots at a time ---- */
-        uint32_t gend = g0, V = 0, n_str = 0;
+        /* ---- group = consecutive list entries whose stroke slots fit in the SEGCAP lanes of ONE filter pass; an op with
+         * more slots forms a group of its own and is filtered SEGCAP slots at a time ---- */
+        uint32_t gend = total, V = 0;
         bool big = false;
-        unsigned long long starts = 0ull; /* bit V_j for every stroke entry j of the group */
-        if (!any_stroke) {
-            gend = total; /* fills only: one group, nothing to lay out */
-        } else {
-            for (; gend < total; ++gend) {
-                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.ent[gend].nv); /* 0: a fill */
-                if (nv > (uint32_t)SEGCAP) {
-                    if (gend == g0) {
-                        big = true;
-                        ++gend;
-                    }
-                    break;
+        unsigned long long starts = 0ull; /* bit s: the slots of a stroke entry of the group start at lane s of the filter pass */
+        uint32_t s_before = 0u;           /* slots of the chunk's entries in front of the group */
+        if (any_stroke) {
+            s_before = g0 ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)g0 - 1) : 0u;
+            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)SEGCAP);
+            if (over) gend = (uint32_t)__builtin_ctzll(over);
+            if (gend == g0) { /* the first entry alone does not fit */
+                big = true;
+                gend = g0 + 1u;
+            } else {
+                V = (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)gend - 1) - s_before;
+                const uint32_t t_ = fresh_lane();
+                sh.mark[t_] = 0xFFu;
+                __syncthreads();
+                {
+                    /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
+                    const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
+                    if (t_ >= g0 && t_ < gend && nv_incl != excl) sh.mark[excl - s_before] = (uint8_t)t_;
                 }
-                if (V + nv > (uint32_t)SEGCAP) break;
-                if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
-                if (nv) {
-                    starts |= 1ull << V;
-                    if (lane == 0) sh.s_ent[n_str] = (uint8_t)(gend - g0);
-                    ++n_str;
-                }
-                V += nv;
+                __syncthreads();
+                starts = __ballot(sh.mark[t_] != 0xFFu);
             }
-            if (lane == 0) sh.grp_base[gend - g0] = (uint8_t)V;
-            __syncthreads();
         }
-        unsigned long long gbal = 0ull, cbal = 0ull; /* lanes of the filter pass holding a record of this sub-tile / of a cap stub */
+        unsigned long long gbal = 0ull; /* lanes of the filter pass holding a record of this sub-tile */
         bool records_ready = false;
 
         for (uint32_t li = g0; li < gend; ++li) {
-            const OpEntry& en = sh.ent[li];
-            const uint32_t kc_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.kind_color);
-            const uint32_t kind = kc_ & 255u;
-            const double op_opacity = en.opacity;
-            const double cr = k_u8_over_255[(kc_ >> 8) & 255u], cg = k_u8_over_255[(kc_ >> 16) & 255u], cb = k_u8_over_255[kc_ >> 24];
-            const uint32_t stage = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.stage);
-#if defined(OSMT_ABL) && OSMT_ABL == 3
-            if (kind == OSMT_OP_STROKE) continue; /* ablation: no stroke work at all */
-#endif
+            const StagedEnt& en = sh.ent[li];
+            const uint32_t ks = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.kind_stage);
+            const uint32_t kind = ks & 255u, stage = ks >> 8;
+            const double cop = en.op; /* a uniform value in a vector register */
 #if defined(OSMT_ABL) && OSMT_ABL == 6
             if (kind != 77u) continue; /* ablation: lists are staged, nothing is drawn */
 #endif
-#if defined(OSMT_ABL) && (OSMT_ABL == 2 || OSMT_ABL == 4)
+#if defined(OSMT_ABL) && OSMT_ABL == 3
+            if (kind == OSMT_OP_STROKE) continue; /* ablation: no stroke work at all */
+#endif
+#if defined(OSMT_ABL) && OSMT_ABL == 4
             if (kind != OSMT_OP_STROKE) continue; /* ablation: no fill work */
 #endif
             if (kind == OSMT_OP_STROKE) {
                 /* ---------------- draw_lines (line.rs:9-61) ---------------- */
                 OSMT_DBG(if (lane == 0) sh.dbg[0] += 1u;)
                 const uint32_t aux_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.aux);
-                const uint32_t arena = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[aux_i];
                 StrokeConst kc;
                 if (stage != 255u) {
@@ -1691,26 +1781,28 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     kc._pad = 0;
                 }
                 const uint32_t sflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.flags);
-                uint32_t n_rounds = 1u, big_cap = 0u;
+                uint32_t n_rounds = 1u, big_cap = 0u, arena = 0u;
                 if (big) {
                     big_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
+                    arena = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
                     n_rounds = (big_cap + (uint32_t)SEGCAP - 1u) / (uint32_t)SEGCAP;
                 }
                 for (uint32_t round = 0; round < n_rounds; ++round) {
                     if (big || !records_ready) {
                         /* ---- filter pass: lane -> (list entry, slot of that op); keep the records of THIS sub-tile,
-                         * compact them in lane order (= op order, segment order) and prefix-sum their item counts ---- */
+                         * compact them in lane order (= op order, segment order), prefix-sum their item counts and
+                         * derive what all runs of a record share ---- */
                         if (big) __syncthreads(); /* previous round's records are consumed */
                         uint32_t ridx = 0xFFFFFFFFu;
                         if (big) {
                             const uint32_t v = round * (uint32_t)SEGCAP + lane;
                             if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
                         } else if (lane < V) {
-                            /* entry = the k-th stroke of the group, k = strokes starting at or below this lane */
-                            const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-                            const uint32_t k = (uint32_t)__popcll(starts & below) - 1u;
-                            const uint32_t j = sh.s_ent[k];
-                            ridx = sh.ent[g0 + j].arena + (lane - sh.grp_base[j]);
+                            /* the entry whose slots start at or below this lane, nearest first */
+                            const uint32_t t_ = fresh_lane();
+                            const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
+                            const uint32_t s0 = 63u - (uint32_t)__builtin_clzll(starts & upto);
+                            ridx = sh.ent[sh.mark[s0]].arena + (t_ - s0);
                         }
                         uint32_t cnt = 0, is_cap = 0;
                         if (ridx != 0xFFFFFFFFu) {
@@ -1721,13 +1813,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             }
                         }
                         gbal = __ballot(cnt > 0u);
-                        cbal = __ballot(cnt > 0u && is_cap != 0u);
                         const uint32_t incl = wave_incl_scan(cnt); /* inclusive prefix of the item counts over the lanes */
                         if (cnt > 0u) {
-                            const uint32_t slot = (uint32_t)__popcll(gbal & lanes_below);
-                            sh.seg[slot] = g_srec[ridx];
+                            const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << fresh_lane()) - 1ull));
+                            const osmt_srec r = g_srec[ridx];
+                            sh.seg[slot] = r;
+                            sh.der[slot] = seg_derive(r, is_cap != 0u);
                             sh.pre[slot] = incl;
-                            sh.seg_cap[slot] = (uint8_t)is_cap;
                         }
                         records_ready = true;
                         __syncthreads();
@@ -1735,8 +1827,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     /* the op's records are lanes [va, vb) of the filter pass */
                     uint32_t va = 0, vb = (uint32_t)SEGCAP;
                     if (!big) {
-                        va = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0]);
-                        vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.grp_base[li - g0 + 1u]);
+                        vb = (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)li) - s_before;
+                        va = li ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)li - 1) - s_before : 0u;
                     }
                     if (vb > va) {
                         const unsigned long long lanes_ab =
@@ -1746,26 +1838,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         if (nslot) {
                             const uint32_t item_lo = slot0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 - 1u]) : 0u;
                             const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + nslot - 1u]);
-#if defined(OSMT_ABL) && (OSMT_ABL == 1 || OSMT_ABL == 4)
-                            (void)item_lo; (void)item_hi;
+#if defined(OSMT_ABL) && (OSMT_ABL == 1 || OSMT_ABL == 2)
+                            (void)item_lo; (void)item_hi; /* ablation: the runs are not walked */
 #else
-                            /* slots are in segment order: the edges' records first, the cap stubs' (which need the
-                             * start-distance terms of opacity_calculator_for_outer_caps, line.rs:22) last — separate
-                             * passes, so a pass has ONE calculator (scalar table loads) and the plain runs never
-                             * execute the dash / cap arithmetic */
-                            const uint32_t n_edge = (uint32_t)__popcll(gbal & ~cbal & lanes_ab);
-                            const uint32_t item_mid = n_edge ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + n_edge - 1u]) : item_lo;
-                            const double half_width = sa->half_width;
-                            if (n_edge) {
-                                if ((sflags & (STROKE_PLAIN_MAIN | STROKE_UNIT_FD | STROKE_TINY_MUL)) == (STROKE_PLAIN_MAIN | STROKE_UNIT_FD))
-                                    walk_items<0>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, nullptr, half_width, op_opacity, rc);
-                                else if (sflags & STROKE_PLAIN_MAIN)
-                                    walk_items<1>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, nullptr, half_width, op_opacity, rc);
-                                else
-                                    walk_items<2>(sh, lane, slot0, n_edge, item_lo, item_lo, item_mid, kc, &sa->main, half_width, op_opacity, rc);
-                            }
-                            if (nslot > n_edge)
-                                walk_items<2>(sh, lane, slot0 + n_edge, nslot - n_edge, item_mid, item_mid, item_hi, kc, &sa->caps, half_width, op_opacity, rc);
+                            walk_items(sh, lane, slot0, nslot, item_lo, item_lo, item_hi, kc, sflags, sa, cop, rc);
 #endif
                         }
                     }
@@ -1773,67 +1849,95 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
                 /* branch-free: an untouched cell holds alpha = +0.0, and 0*c + (1 - 0)*old == old exactly */
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const uint32_t idx = (ly0 + (uint32_t)j * ROWSTEP) * PLANE_STRIDE + lx;
-                    const double al = __longlong_as_double((long long)sh.plane[idx]);
-                    sh.plane[idx] = 0ull;
-                    blend_rgb(acc[j], al * cr, al * cg, al * cb, al); /* from_color: o * (c/255) */
-                }
-                __syncthreads(); /* the plane is reused by the next op */
-            } else {
-                /* ---------------- fill_contour (fill.rs:16-47): coverage words from k_fill_rows ---------------- */
-                OSMT_DBG(if (lane == 0) sh.dbg[5] += 1u;)
-                uint32_t cov = 0u; /* bit j = this lane's pixel j is covered */
-                if (stage != 255u) {
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j) cov |= ((sh.fmask[stage][ly0 + (uint32_t)j * ROWSTEP] >> lx) & 1u) << j;
-                } else { /* more than STAGECAP fills in one chunk of one sub-tile: read the arena directly */
-                    const uint32_t* __restrict__ mw = g_fmask + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j) cov |= ((mw[ly0 + (uint32_t)j * ROWSTEP] >> lx) & 1u) << j;
-                }
-                if (kind == OSMT_OP_FILL_COLOR) {
-                    const double o_ = op_opacity;
-                    const double sr = o_ * cr, sg = o_ * cg, sb = o_ * cb;
-                    /* blend_pixel (tile_pixels.rs:209-219) for every pixel, kept where the pixel is covered: the op's colour is
-                     * wave-uniform, so new = s + (1 - a) * old costs two instructions per channel and a select */
-                    const double k_ = 1.0 - o_;
+#if defined(OSMT_ABL) && OSMT_ABL == 2
+                if (false) /* ablation: neither walked nor blended */
+#endif
+                {
+                    /* the colour is read only now: held across the walk it costs six registers where the kernel has none to spare */
+                    const StagedEnt& eb = sh.ent[late_index(li)];
+                    const double c0 = eb.c0, c1 = eb.c1, c2 = eb.c2;
+                    const uint32_t t_ = fresh_lane();
+                    const uint32_t cell0 = (t_ / SUB) * PLANE_STRIDE + (t_ & (SUB - 1));
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
-                        const bool c_ = (cov >> j) & 1u;
-                        const double nr = sr + k_ * acc[j][0], ng = sg + k_ * acc[j][1], nb = sb + k_ * acc[j][2];
-                        acc[j][0] = c_ ? nr : acc[j][0];
-                        acc[j][1] = c_ ? ng : acc[j][1];
-                        acc[j][2] = c_ ? nb : acc[j][2];
+                        const uint32_t idx = cell0 + (uint32_t)j * ROWSTEP * PLANE_STRIDE;
+                        const double al = __longlong_as_double((long long)sh.plane[idx]);
+                        sh.plane[idx] = 0ull;
+                        blend_rgb(acc[j], al * c0, al * c1, al * c2, al); /* from_color: o * (c/255) */
                     }
-                } else { /* Filler::Image: icon.get(x % w, y % h), opacity ignored (fill.rs:36-40) */
+                }
+                __syncthreads(); /* the plane is reused by the next op */
+            }
+            /* NOT an else: with two arms that both define all 48 accumulators the register allocator keeps the incoming
+             * values alive through the first arm (the structurised flow runs the arms one after the other) and copies
+             * them — 24 moves per fill visit in round 3's kernel.  Two independent if-blocks update them in place; the
+             * laundered copy of `kind` keeps the compiler from fusing the blocks again. */
+            if (late_index(kind) != OSMT_OP_STROKE) {
+                /* ---------------- fill_contour (fill.rs:16-47): coverage words from k_fill_rows ----------------
+                 * pixel j of lane t is column t % 32 of row t / 32 + 2j: the lanes that own a covered pixel j are the bits
+                 * of (word of row 2j) | (word of row 2j + 1) << 32 — a ready-made execution mask */
+                OSMT_DBG(if (lane == 0) sh.dbg[5] += 1u;)
+                uint32_t w_[SUBH];
+                if (stage != 255u) {
+                    const uint4* OSMT_R lw = reinterpret_cast<const uint4*>(&sh.fmask[stage][0]);
+#pragma unroll
+                    for (int q = 0; q < SUBH / 4; ++q) {
+                        const uint4 v = lw[q];
+                        w_[4 * q + 0] = v.x;
+                        w_[4 * q + 1] = v.y;
+                        w_[4 * q + 2] = v.z;
+                        w_[4 * q + 3] = v.w;
+                    }
+                } else { /* more than STAGECAP fills in one chunk of one sub-tile: the arena directly (a uniform address) */
+                    const uint32_t* OSMT_R mw = g_fmask + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
+#pragma unroll
+                    for (int q = 0; q < SUBH; ++q) w_[q] = mw[q];
+                }
+                unsigned long long m_[PXT];
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    m_[j] = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w_[2 * j]) |
+                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w_[2 * j + 1]) << 32);
+                /* Filler::Color: the wave-uniform colour the staging lane prepared */
+                const bool image = kind != OSMT_OP_FILL_COLOR;
+                if (!image) {
+                    const double c0 = en.c0, c1 = en.c1, c2 = en.c2;
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) blend_masked(acc[j][0], acc[j][1], acc[j][2], c0, c1, c2, cop, m_[j]);
+                }
+                /* Filler::Image: icon.get(x % w, y % h) per pixel, the opacity ignored (fill.rs:36-40) — again its own
+                 * if-block, through the same masked blend */
+                if (late_index((uint32_t)__builtin_amdgcn_readfirstlane(image ? 1 : 0))) {
                     const uint32_t img = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.aux);
                     const osmt_raster_args* la = late_args();
-                    if (img < la->n_images) {
+                    const uint32_t n_images = (uint32_t)__builtin_amdgcn_readfirstlane((int)la->n_images);
+                    if (img < n_images) { /* an unknown image id draws nothing */
                         const osmt_image_desc im = la->images[img];
                         const double4* __restrict__ ipx = la->image_pool + im.offset;
-                        /* out of line, on a COPY of the accumulators in scratch: inlined, the eight icon addresses and loads
-                         * in flight cost the whole kernel ~45 registers — a wave per SIMD — for a rare op */
-                        double tmp[PXT][3];
+                        const uint32_t t_ = fresh_lane();
+                        const uint32_t ix = ((uint32_t)rc.x0 + (t_ & (SUB - 1))) % im.width;
+                        const uint32_t iy0 = (uint32_t)rc.y0 + t_ / SUB;
 #pragma unroll
                         for (int j = 0; j < PXT; ++j) {
-                            tmp[j][0] = acc[j][0];
-                            tmp[j][1] = acc[j][1];
-                            tmp[j][2] = acc[j][2];
-                        }
-                        fill_image_cold(tmp, cov, ipx, im.width, im.height, (uint32_t)rc.x0 + lx, (uint32_t)rc.y0 + ly0);
-#pragma unroll
-                        for (int j = 0; j < PXT; ++j) {
-                            acc[j][0] = tmp[j][0];
-                            acc[j][1] = tmp[j][1];
-                            acc[j][2] = tmp[j][2];
+                            /* one pixel at a time (the scheduling barrier keeps the eight icon loads from being hoisted
+                             * together: eight addresses and pixels in flight cost the whole kernel ~45 registers — a wave
+                             * per SIMD — for a rare op) */
+                            double s0 = 0.0, s1 = 0.0, s2 = 0.0, kk = 1.0;
+                            if (__builtin_amdgcn_inverse_ballot_w64(m_[j])) {
+                                const double4 c = ipx[(size_t)((iy0 + (uint32_t)j * (uint32_t)ROWSTEP) % im.height) * im.width + ix];
+                                s0 = c.x;
+                                s1 = c.y;
+                                s2 = c.z;
+                                kk = 1.0 - c.w;
+                            }
+                            blend_masked(acc[j][0], acc[j][1], acc[j][2], s0, s1, s2, kk, m_[j]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
             }
         }
-        __syncthreads(); /* the group's records / bases are rewritten by the next group */
+        __syncthreads(); /* the group's records are rewritten by the next group */
         g0 = gend;
         }
     }
@@ -1873,6 +1977,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const double* OSMT_R plane = g_lab_plane + li->plane_off;
             const uint32_t cols = li->cols;
             const double4* OSMT_R ipx = g_image_pool + li->icon_off;
+            const uint32_t lx = fresh_lane() & (SUB - 1), ly0 = fresh_lane() / SUB;
             const int32_t x = rc.x0 + (int32_t)lx;
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
@@ -1910,7 +2015,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
                                                         (size_t)tile * g_out_tile_stride) + px;
             *out = v;
-            OSMT_DBG(__syncthreads(); if (j == 0 && ly0 == 0 && lx < 8) *out = sh.dbg[lx];)
+            OSMT_DBG(__syncthreads(); if (j == 0 && ly_o == 0 && lx_o < 8) *out = sh.dbg[lx_o];)
         }
     }
 }
@@ -2077,7 +2182,7 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
                            a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
     if (a.n_jobs) /* also without a single op: k_raster reads the (empty) list headers */
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
-                           a.cursors + 2, a.hdr, a.ent, a.ent_cap);
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ EXPORTS = [
     "osmt_scene_upload", "osmt_scene_free", "osmt_render_scene", "osmt_render_scene_f64", "osmt_render_scene_stages",
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_render_batch_rgb", "osmt_scene_set_labels", "osmt_scene_read_label_status",
+    "osmt_scene_check", "osmt_worker_create", "osmt_worker_destroy", "osmt_worker_render",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
     "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
     "osmt_render_batch_multi_ex",
@@ -86,6 +87,11 @@ def load():
     L.osmt_render_batch_rgb.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_scene_set_labels.argtypes = [vp, vp, C.POINTER(abi.LabelBatch)]
     L.osmt_scene_read_label_status.argtypes = [vp, vp, u8p]
+    L.osmt_scene_check.argtypes = [vp, vp]
+    L.osmt_worker_create.argtypes = [vp, C.POINTER(vp)]
+    L.osmt_worker_destroy.argtypes = [vp]
+    L.osmt_worker_destroy.restype = None
+    L.osmt_worker_render.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_png_device_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.osmt_png_device_bound.restype = C.c_size_t
     L.osmt_encode_png_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]

@@ -58,6 +58,10 @@ class Scene:
             check(load().osmt_scene_read_label_status(self.ctx._h, self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    def check(self):
+        """osmt_scene_check: waits for the scene's launches, raises if a kernel reported an internal error."""
+        check(load().osmt_scene_check(self.ctx._h, self._h))
+
     def free(self):
         if getattr(self, "_h", None):
             load().osmt_scene_free(self._h)
@@ -70,8 +74,44 @@ class Scene:
             pass
 
 
+class Worker:
+    """osmt_worker: the per-thread request handle of the reference's server loop (http_server.rs:50-83); concurrent
+    render() calls of the workers of one context are gathered into shared launches."""
+
+    def __init__(self, ctx):
+        h = C.c_void_p()
+        check(load().osmt_worker_create(ctx._h, C.byref(h)))
+        self._h = h
+        self.ctx = ctx
+
+    def render(self, dl: DisplayList, labels=None, out=None):
+        """osmt_worker_render: packed RGB8 [n, W*W*3] of the display list's tiles (usually one)."""
+        b = dl.as_batch()
+        tight = dl.dim * dl.dim * 3
+        if out is None:
+            out = np.empty((dl.n_jobs, tight), dtype=np.uint8)
+        lb = labels.as_batch() if labels is not None else None
+        check(load().osmt_worker_render(self._h, C.byref(b), C.byref(lb) if lb is not None else None,
+                                        out.ctypes.data_as(C.POINTER(C.c_uint8)), tight))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().osmt_worker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU (osmt_ctx): analogue of the reference's Drawer + per-worker TilePixels."""
+
+    def worker(self):
+        return Worker(self)
 
     def __init__(self, device=0):
         torch = _torch()
