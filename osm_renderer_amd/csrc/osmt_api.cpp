@@ -476,7 +476,16 @@ int validate_coords_range(const osmt_batch* b, size_t lo, size_t hi) {
 }
 size_t coord_count(const osmt_batch* b) { return b->coord_kind == OSMT_COORD_NODE_REF ? b->n_nodes : b->n_pts; }
 
-int validate_batch(const osmt_batch* b, bool with_coords = true) {
+/* ---- what Rust's types guarantee has to be checked at a C boundary, in three pieces so that callers can validate in
+ * parallel (osmt_render_batch_multi: one thread per GPU; osmt_worker_render: every requester its own request) ----------
+ * validate_batch_global: what needs the whole batch — the header, and that the jobs' op ranges PARTITION the op pool
+ * (every op of the pool is pre-processed on the device, k_opinfo runs over [0, n_ops): every op must be reachable through
+ * exactly one job) and their point ranges do not overlap (a point is projected against the tile of the job that owns it)
+ * — in O(n_jobs log n_jobs): two sorts of the ranges.  validate_job: everything about ONE job — its ops, rings, dashes,
+ * node references and (with_coords) the coordinates of its points; jobs are independent, any number of threads may run
+ * it on disjoint sets of jobs.  validate_nodes: a slice of the shared node table of OSMT_COORD_NODE_REF.  Points no job
+ * owns are not looked at: no kernel reads them either (k_project skips them). */
+int validate_batch_global(const osmt_batch* b) {
     if (!b) return fail(OSMT_INVALID_ARG, "batch is NULL");
     if (b->scale < 1 || b->scale > OSMT_MAX_SCALE) return fail(OSMT_INVALID_ARG, "scale %u not in 1..%u", b->scale, OSMT_MAX_SCALE);
     if (b->coord_kind != OSMT_COORD_LATLON_F64 && b->coord_kind != OSMT_COORD_POINT_I32 && b->coord_kind != OSMT_COORD_NODE_REF)
@@ -492,40 +501,45 @@ int validate_batch(const osmt_batch* b, bool with_coords = true) {
         if (b->coord_kind == OSMT_COORD_NODE_REF) {
             if (!b->node_refs || !b->nodes) return fail(OSMT_INVALID_ARG, "node table / node_refs is NULL");
             if (b->n_nodes >= 0xFFFFFFFFull) return fail(OSMT_INVALID_ARG, "node table too large for 32-bit indices");
-            for (size_t i = 0; i < b->n_pts; ++i)
-                if (b->node_refs[i] >= b->n_nodes) return fail(OSMT_INVALID_ARG, "point %zu: node reference %u out of range", i, b->node_refs[i]);
         }
     }
-    /* Every op of the pool is pre-processed on the device (k_opinfo runs over [0, n_ops)), so every op must be
-     * reachable through exactly one job: the jobs' op ranges partition the op pool and their point ranges do not
-     * overlap (a point is projected against the tile of the job that owns it). */
-    std::vector<uint32_t> op_job(b->n_ops, 0xFFFFFFFFu);
-    {
-        std::vector<std::pair<uint64_t, uint64_t>> pr; /* non-empty point ranges, for the overlap test */
-        pr.reserve(b->n_jobs);
-        for (size_t j = 0; j < b->n_jobs; ++j) {
-            const osmt_tile_job& job = b->jobs[j];
-            if (job.zoom > OSMT_MAX_ZOOM) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u > MAX_ZOOM (src/tile.rs:5)", j, job.zoom);
-            if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
-            if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
-            for (uint32_t k = 0; k < job.n_ops; ++k) {
-                uint32_t& owner = op_job[job.op_off + k];
-                if (owner != 0xFFFFFFFFu)
-                    return fail(OSMT_INVALID_ARG, "job %zu: op %u also belongs to job %u (op ranges must not overlap)", j, job.op_off + k, owner);
-                owner = (uint32_t)j;
-            }
-            if (job.n_pts) pr.emplace_back((uint64_t)job.pt_off, (uint64_t)job.pt_off + job.n_pts);
-        }
-        std::sort(pr.begin(), pr.end());
-        for (size_t i = 1; i < pr.size(); ++i)
-            if (pr[i].first < pr[i - 1].second) return fail(OSMT_INVALID_ARG, "the point ranges of two jobs overlap at point %llu", (unsigned long long)pr[i].first);
-    }
-    for (size_t o = 0; o < b->n_ops; ++o) {
-        const osmt_op& op = b->ops[o];
-        const size_t j = op_job[o];
-        if (j == 0xFFFFFFFFu) return fail(OSMT_INVALID_ARG, "op %zu is not covered by any job (the jobs' op ranges must partition the op pool)", o);
+    struct range {
+        uint64_t lo, hi;
+        uint32_t job;
+    };
+    std::vector<range> ops, pts;
+    ops.reserve(b->n_jobs);
+    pts.reserve(b->n_jobs);
+    for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
-        const uint32_t k = (uint32_t)(o - job.op_off);
+        if (job.zoom > OSMT_MAX_ZOOM) return fail(OSMT_INVALID_ARG, "job %zu: zoom %u > MAX_ZOOM (src/tile.rs:5)", j, job.zoom);
+        if ((size_t)job.op_off + job.n_ops > b->n_ops) return fail(OSMT_INVALID_ARG, "job %zu: op range out of bounds", j);
+        if ((size_t)job.pt_off + job.n_pts > b->n_pts) return fail(OSMT_INVALID_ARG, "job %zu: point range out of bounds", j);
+        if (job.n_ops) ops.push_back({job.op_off, (uint64_t)job.op_off + job.n_ops, (uint32_t)j});
+        if (job.n_pts) pts.push_back({job.pt_off, (uint64_t)job.pt_off + job.n_pts, (uint32_t)j});
+    }
+    auto by_lo = [](const range& x, const range& y) { return x.lo < y.lo; };
+    std::sort(ops.begin(), ops.end(), by_lo);
+    uint64_t next = 0;
+    for (const range& r : ops) {
+        if (r.lo < next)
+            return fail(OSMT_INVALID_ARG, "job %u: op %llu also belongs to another job (op ranges must not overlap)", r.job, (unsigned long long)r.lo);
+        if (r.lo > next)
+            return fail(OSMT_INVALID_ARG, "op %llu is not covered by any job (the jobs' op ranges must partition the op pool)", (unsigned long long)next);
+        next = r.hi;
+    }
+    if (next != b->n_ops)
+        return fail(OSMT_INVALID_ARG, "op %llu is not covered by any job (the jobs' op ranges must partition the op pool)", (unsigned long long)next);
+    std::sort(pts.begin(), pts.end(), by_lo);
+    for (size_t i = 1; i < pts.size(); ++i)
+        if (pts[i].lo < pts[i - 1].hi) return fail(OSMT_INVALID_ARG, "the point ranges of two jobs overlap at point %llu", (unsigned long long)pts[i].lo);
+    return OSMT_OK;
+}
+
+int validate_job(const osmt_batch* b, size_t j, bool with_coords = true) {
+    const osmt_tile_job& job = b->jobs[j];
+    for (uint32_t k = 0; k < job.n_ops; ++k) {
+        const osmt_op& op = b->ops[job.op_off + k];
         if (op.kind > OSMT_OP_STROKE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown kind %u", j, k, op.kind);
         if (op.kind == OSMT_OP_NONE) continue;
         if ((size_t)op.ring_off + op.n_rings > b->n_rings) return fail(OSMT_INVALID_ARG, "job %zu op %u: ring range out of bounds", j, k);
@@ -538,19 +552,34 @@ int validate_batch(const osmt_batch* b, bool with_coords = true) {
             return fail(OSMT_INVALID_ARG, "job %zu op %u: opacity must be in [0, 2^52]", j, k);
         if (op.kind == OSMT_OP_STROKE) {
             if (!std::isfinite(op.width)) return fail(OSMT_INVALID_ARG, "job %zu op %u: width not finite", j, k);
-            /* the per-segment reach bounds of the stroke cull are kept in 16 bits (osmt_reach_of); 4x the largest tile */
             if (std::fabs(op.width) > 65536.0) return fail(OSMT_UNSUPPORTED, "job %zu op %u: |width| > 65536 px", j, k);
             if (op.cap > OSMT_CAP_SQUARE) return fail(OSMT_INVALID_ARG, "job %zu op %u: unknown cap", j, k);
             if (op.has_dashes) {
-                /* Some([]) panics in the reference (opacity_calculator.rs:109 indexes dashes[0]) */
                 if (op.n_dashes == 0) return fail(OSMT_INVALID_ARG, "job %zu op %u: empty dash list", j, k);
                 if (op.n_dashes > OSMT_MAX_DASHES) return fail(OSMT_UNSUPPORTED, "job %zu op %u: more than %u dashes", j, k, OSMT_MAX_DASHES);
                 if ((size_t)op.dashes_off + op.n_dashes > b->n_dashes) return fail(OSMT_INVALID_ARG, "job %zu op %u: dash range out of bounds", j, k);
             }
         }
     }
-    if (with_coords) return validate_coords_range(b, 0, coord_count(b));
-    return OSMT_OK;
+    if (b->coord_kind == OSMT_COORD_NODE_REF) {
+        for (size_t i = job.pt_off; i < (size_t)job.pt_off + job.n_pts; ++i)
+            if (b->node_refs[i] >= b->n_nodes) return fail(OSMT_INVALID_ARG, "point %zu: node reference %u out of range", i, b->node_refs[i]);
+        return OSMT_OK; /* the node table itself: validate_nodes */
+    }
+    return with_coords ? validate_coords_range(b, job.pt_off, (size_t)job.pt_off + job.n_pts) : OSMT_OK;
+}
+
+int validate_nodes(const osmt_batch* b, size_t lo, size_t hi) {
+    return b->coord_kind == OSMT_COORD_NODE_REF ? validate_coords_range(b, lo, hi) : OSMT_OK;
+}
+
+/* the whole batch on the calling thread; with_coords = false: the caller scans the coordinates itself (big uploads do it
+ * on helper threads, validate_coords_range over the whole pool) */
+int validate_batch(const osmt_batch* b, bool with_coords = true) {
+    int rc = validate_batch_global(b);
+    for (size_t j = 0; rc == OSMT_OK && j < b->n_jobs; ++j) rc = validate_job(b, j, with_coords);
+    if (rc == OSMT_OK && with_coords) rc = validate_nodes(b, 0, b->n_nodes);
+    return rc;
 }
 
 /* Arguments of stage 2 (k_opinfo -> k_fill_rows -> k_stroke_bin); sizing: only the arena cursors are produced. */
@@ -2203,7 +2232,12 @@ static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt
         if (!ctxs[i]) return fail(OSMT_INVALID_ARG, "context %u is NULL", i);
     if (flags & ~(uint32_t)OSMT_MULTI_RGB8) return fail(OSMT_INVALID_ARG, "unknown flags 0x%x", flags);
     const bool rgb = (flags & OSMT_MULTI_RGB8) != 0;
-    int rc = validate_batch(batch); /* ONCE for the whole call: the shards are built from it and trusted */
+    /* Only what needs the whole batch is checked here, serially (O(n_jobs log n_jobs)); every GPU's thread validates the jobs
+     * of its own shard before it packs them.  (Round 3 validated the whole batch up front: 6 ms of one thread for the
+     * 10 000-tile batch while one GPU's share of the work is ~8 ms — Amdahl capped eight GPUs near 4.9x.) */
+    static const bool trace_multi = getenv("OSMT_TRACE_MULTI") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc = validate_batch_global(batch);
     if (rc != OSMT_OK) return rc;
     if (batch->n_jobs && !out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
     const size_t W = (size_t)OSMT_TILE_SIZE * batch->scale;
@@ -2222,10 +2256,19 @@ static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt
         }
     } pool;
     pool.th.reserve(n);
+    const auto t_forked = std::chrono::steady_clock::now();
     for (uint32_t d = 0; d < n; ++d) {
         pool.th.emplace_back([&, d] {
             osmt_batch_shard* sh = nullptr;
-            int r = guarded([&] { return shard_create_body(batch, d, n, &sh, true); });
+            int r = guarded([&] {
+                for (size_t j = d; j < batch->n_jobs; j += n) { /* the shard's own jobs */
+                    const int v = validate_job(batch, j);
+                    if (v != OSMT_OK) return v;
+                }
+                const size_t nn = batch->coord_kind == OSMT_COORD_NODE_REF ? batch->n_nodes : 0; /* its slice of the shared node table */
+                return validate_nodes(batch, nn * d / n, nn * (d + 1) / n);
+            });
+            if (r == OSMT_OK) r = guarded([&] { return shard_create_body(batch, d, n, &sh, true); });
             label_shard ls;
             if (r == OSMT_OK && labels) r = guarded([&] { return label_shard_build(labels, batch->n_jobs, d, n, &ls); });
             if (r == OSMT_OK && sh->b.n_jobs)
@@ -2239,8 +2282,13 @@ static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt
         });
     }
     for (auto& t : pool.th) t.join();
+    const auto t_joined = std::chrono::steady_clock::now();
     for (uint32_t d = 0; d < n; ++d)
-        if (rcs[d] != OSMT_OK) return fail(rcs[d], "GPU %u (device %d): %s", d, ctxs[d]->device, msgs[d].c_str());
+        if (rcs[d] != OSMT_OK) { /* lowest shard first; a failure in one shard's validation has stopped only that shard */
+            /* a malformed batch must leave the output untouched by contract?  No: like osmt_render_batch, a failing call
+             * leaves the buffer unspecified */
+            return fail(rcs[d], "GPU %u (device %d): %s", d, ctxs[d]->device, msgs[d].c_str());
+        }
     uint64_t total = 0;
     bool have_comm = n > 1;
     for (uint32_t d = 0; d < n; ++d) have_comm = have_comm && ctxs[d]->comm && ctxs[d]->comm_size == n;
@@ -2252,6 +2300,14 @@ static int render_batch_multi_body(osmt_ctx* const* ctxs, uint32_t n, const osmt
     }
     if (total != batch->n_jobs) return fail(OSMT_HIP_ERROR, "tile count %llu != %zu jobs", (unsigned long long)total, batch->n_jobs);
     if (out_count) *out_count = total;
+    if (trace_multi) { /* OSMT_TRACE_MULTI=1 (diagnostic): the serial share of the call, one line on stderr */
+        const auto t_end = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+            return std::chrono::duration<double, std::micro>(b2 - a).count();
+        };
+        fprintf(stderr, "osmt multi: %u contexts, %zu tiles: serial head %.0f us, parallel %.0f us, serial tail %.0f us\n", n, batch->n_jobs,
+                us(t_begin, t_forked), us(t_forked, t_joined), us(t_joined, t_end));
+    }
     return OSMT_OK;
 }
 
@@ -2306,7 +2362,7 @@ constexpr size_t CO_MAX_TILES = 64;
 int co_max_in_flight() {
     static const int v = [] {
         const char* e = getenv("OSMT_WORKER_INFLIGHT");
-        return e ? std::min(std::max(atoi(e), 1), 8) : 2;
+        return e ? std::min(std::max(atoi(e), 1), 16) : 4;
     }();
     return v;
 }

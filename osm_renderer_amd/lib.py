@@ -87,11 +87,12 @@ def load():
     L.osmt_render_batch_rgb.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_scene_set_labels.argtypes = [vp, vp, C.POINTER(abi.LabelBatch)]
     L.osmt_scene_read_label_status.argtypes = [vp, vp, u8p]
-    L.osmt_scene_check.argtypes = [vp, vp]
-    L.osmt_worker_create.argtypes = [vp, C.POINTER(vp)]
-    L.osmt_worker_destroy.argtypes = [vp]
-    L.osmt_worker_destroy.restype = None
-    L.osmt_worker_render.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
+    if hasattr(L, "osmt_scene_check"):  # absent only from older variant builds loaded through OSMT_LIB (A/B timing runs)
+        L.osmt_scene_check.argtypes = [vp, vp]
+        L.osmt_worker_create.argtypes = [vp, C.POINTER(vp)]
+        L.osmt_worker_destroy.argtypes = [vp]
+        L.osmt_worker_destroy.restype = None
+        L.osmt_worker_render.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
     L.osmt_png_device_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.osmt_png_device_bound.restype = C.c_size_t
     L.osmt_encode_png_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]

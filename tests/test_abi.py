@@ -138,3 +138,36 @@ def test_validate_batch_rejects_ops_no_job_covers():
     dl.jobs = dl.jobs[:0]
     dl.ops = dl.ops[:0]
     assert _validate(dl)[0] == abi.OK
+
+
+def test_validate_batch_partition_is_order_free_and_exact():
+    """The partition check sorts the jobs' ranges (O(n_jobs log n_jobs), osmt_render_batch_multi runs it on the calling
+    thread while every GPU's thread validates its own jobs): jobs may be listed in any order and empty jobs may sit
+    anywhere, but a gap at the end of the op pool, or a node reference beyond the table, is still refused."""
+    import numpy as np
+
+    from osm_renderer_amd import synth
+
+    dl = synth.config2(5)
+    dl.jobs = dl.jobs[[3, 0, 4, 1, 2]].copy()  # any order
+    assert _validate(dl)[0] == abi.OK
+    dl = synth.config2(4)
+    empty = dl.jobs[:1].copy()
+    empty["n_ops"] = 0
+    empty["n_pts"] = 0
+    empty["op_off"] = dl.jobs["op_off"][2]  # an empty job pointing into the middle of the pool
+    dl.jobs = np.concatenate([dl.jobs[:2], empty, dl.jobs[2:]])
+    assert _validate(dl)[0] == abi.OK
+    dl = synth.config2(3)
+    dl.jobs["n_ops"][2] -= 2  # the last two ops of the pool belong to nobody
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "not covered by any job" in msg
+    dl = synth.config2(2).with_node_refs()
+    assert _validate(dl)[0] == abi.OK
+    dl.coords[11] = len(dl.nodes)  # one past the node table
+    rc, msg = _validate(dl)
+    assert rc == abi.INVALID_ARG and "node reference" in msg
+    dl = synth.config2(2).with_node_refs()
+    dl.nodes[3, 0] = 91.0  # a node outside the Web-Mercator square
+    rc, msg = _validate(dl)
+    assert rc == abi.UNSUPPORTED and "Web-Mercator" in msg

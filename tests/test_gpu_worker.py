@@ -67,7 +67,7 @@ def test_requests_of_different_shapes_and_labels_share_groups(gpu_ctx, oracle):
     ll = labels.make_labels(12, labels_per_tile=6, n_images=len(ids), image_sizes=sizes, seed=3)
     ll.labels["image_id"] = np.asarray(ids, dtype=np.uint32)[ll.labels["image_id"] % len(ids)]
     hi = synth.make_tiles(synth.config_tiles(4, x0=19400, y0=10080), scale=2)
-    refs = synth.make_tiles(synth.config_tiles(4, x0=19500, y0=10090)).with_node_refs
+    refs = synth.make_tiles(synth.config_tiles(4, x0=19500, y0=10090)).with_node_refs()
     reqs, lab, want = [], [], []
     for i in range(0, 12, 3):  # three tiles per request, labelled
         idx = [i, i + 1, i + 2]
