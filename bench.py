@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tiles", type=int, default=1024, help="tiles per GPU per step (weak scaling, the default headline)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight per GPU: S resident copies of the batch (own lists, own workspace, own framebuffers), step i "
+                         "runs on stream i mod S — the latency-bound pre-pass of one batch overlaps the raster stage of the previous "
+                         "one, as a server that renders batch after batch would have it; 1 = every step waits for the one before")
     ap.add_argument("--total-tiles", type=int, default=0, help="strong scaling: a fixed global batch, tile i -> rank i mod N (configs[3]: 10000)")
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--composite-tiles", type=int, default=64)
@@ -343,28 +347,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_sharded(global_tiles_xy, zoom, scale, n_poly, n_line, steps, warmup, maker=None):
+    def run_sharded(global_tiles_xy, zoom, scale, n_poly, n_line, steps, warmup, maker=None, slots=1):
         """Tile i of the global batch -> rank i mod N.  W untimed + K timed steps bracketed by barrier + synchronize on
-        both sides, MAX over ranks; returns the whole-job figures and this rank's objects."""
+        both sides, MAX over ranks; returns the whole-job figures and this rank's objects.  slots > 1: that many resident
+        copies of the batch, step i on copy / stream i mod slots (every step still runs project -> pre-pass -> raster over
+        its own lists into its own framebuffers; nothing is shared or cached between steps)."""
         mine = global_tiles_xy[shard.shard_indices(len(global_tiles_xy), rank, world)]
         dl = maker(mine) if maker else synth.make_tiles(mine, zoom=zoom, scale=scale, n_poly=n_poly, n_line=n_line)
-        scene = ctx.upload(dl)
-        out = torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev)
+        scenes = [ctx.upload(dl) for _ in range(slots)]
+        outs = [torch.empty((dl.n_jobs, dl.dim, dl.dim, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
+        lanes = [torch.cuda.current_stream()] if slots == 1 else [torch.cuda.Stream() for _ in range(slots)]
+        scene, out = scenes[0], outs[0]
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        turn = [0]
 
         def step(i=None):
-            ctx.render_stages(scene, abi.STAGE_PROJECT | abi.STAGE_OPINFO)
-            if i is not None:
-                ev[i][0].record()
-            ctx.render_stages(scene, abi.STAGE_RASTER, out)
-            if i is not None:
-                ev[i][1].record()
-            if dist is not None:
-                if native_comm:  # queued behind the raster stage on the same stream, no host synchronisation
-                    shard.allreduce_tile_count_enqueue(ctx, dl.n_jobs)
-                else:
-                    count.fill_(dl.n_jobs)
-                    dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
+            k = turn[0] % slots
+            turn[0] += 1
+            with torch.cuda.stream(lanes[k]):
+                ctx.render_stages(scenes[k], abi.STAGE_PROJECT | abi.STAGE_OPINFO)
+                if i is not None:
+                    ev[i][0].record()
+                ctx.render_stages(scenes[k], abi.STAGE_RASTER, outs[k])
+                if i is not None:
+                    ev[i][1].record()
+                if dist is not None:
+                    if native_comm:  # queued behind the raster stage on the same stream, no host synchronisation
+                        shard.allreduce_tile_count_enqueue(ctx, dl.n_jobs)
+                    else:
+                        count.fill_(dl.n_jobs)
+                        dist.all_reduce(count)  # RCCL sum of tile counts: the path's only collective
 
         for _ in range(warmup):
             step()
@@ -382,6 +394,11 @@ def main():
             total = shard.allreduce_tile_count_result(ctx) if native_comm else int(count.item())
             assert total == len(global_tiles_xy), (total, len(global_tiles_xy))
         raster_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        for extra in scenes[1:]:
+            extra.free()
+        if slots > 1:  # the copies are gone: later callers of step() run on the first one
+            scenes[1:], outs[1:], lanes[1:] = [], [], []
+            slots = 1
         return {"elapsed": elapsed, "total_tiles": total, "raster_ms": raster_ms, "dl": dl, "scene": scene, "out": out, "step": step}
 
     # ---- headline ----------------------------------------------------------------------------------
@@ -390,7 +407,13 @@ def main():
     head = run_sharded(synth.config_tiles(n_global), 15, args.scale, args.n_poly, args.n_line, args.steps, args.warmup)
     dl, scene, out = head["dl"], head["scene"], head["out"]
     alg_bytes = dl.algorithmic_bytes()  # 16*N_pts + 64*N_ops + 8*N_dashes + 4*W*H per tile
-    raster_s = head["raster_ms"] / 1e3
+    raster_s = head["raster_ms"] / 1e3  # the kernel's own duration: always from the one-batch-at-a-time run (nothing overlaps it there)
+    sequential = {"ms_per_step": head["elapsed"] / args.steps * 1e3, "tiles_per_s": head["total_tiles"] * args.steps / head["elapsed"]}
+    if args.streams > 1:
+        piped = run_sharded(synth.config_tiles(n_global), 15, args.scale, args.n_poly, args.n_line, args.steps, args.warmup, slots=args.streams)
+        piped["scene"].free()
+        head = dict(head, elapsed=piped["elapsed"], total_tiles=piped["total_tiles"])
+        del piped
     achieved = alg_bytes / raster_s / 1e9
     named = args.n_poly == 50 and args.n_line == 40
     if strong:
@@ -398,7 +421,10 @@ def main():
                     f"y = 10000 + i / 100), tile i -> rank i mod {world}, RCCL sum of tile counts per step; synthetic 50-poly/200-segment geometry")
     else:
         workload = (f"BASELINE.json configs[1]: batch of {args.tiles} z=15 {dl.dim}x{dl.dim} tiles per GPU, synthetic 50-poly/200-segment "
-                    "geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input resident in HBM, RGBA8 framebuffers written to HBM")
+                    "geometry per tile (SplitMix64, SURVEY.md 8(d)), lat/lon f64 input resident in HBM, RGBA8 framebuffers written to HBM"
+                    + (f"; {args.streams} batches in flight (step i on resident copy / stream i mod {args.streams}: the pre-pass of one batch "
+                       "overlaps the raster stage of the previous one; one_batch_at_a_time = the same steps strictly one after the other)"
+                       if args.streams > 1 else ""))
     result = {
         "metric": "tiles/sec (256x256 z=15)",
         "value": head["total_tiles"] * args.steps / head["elapsed"],
@@ -423,7 +449,10 @@ def main():
             "sharding": "tile i -> rank i mod N; RCCL all-reduce(sum) of tile counts per step",
             "collective": collective,
             "rccl_nranks_seen": nranks_seen,
+            "batches_in_flight": args.streams,
         },
+        "one_batch_at_a_time": dict(sequential, what="the same K steps with ONE resident batch on ONE stream: every step waits for the one before; "
+                                                     "roofline.avg_launch_ms is measured in this run"),
         "roofline": {
             "kernel": "k_raster (fused fill/stroke/blend/to_rgb) — instruction-issue bound by construction, see roofline_issue; "
                       "the HBM fraction is reported because the metric asks for it, it is not this kernel's ceiling",
@@ -543,6 +572,22 @@ def main():
                     ctx.host_free(b)
                 return n_thr * calls * dl.n_jobs / dt
             pooled = {str(w): workers(w) for w in (2, 4)}
+            # ... and from ONE thread with the call split in two (osmt_render_batch_png_begin / _end): batch k + 1 is validated,
+            # uploaded and queued while the GPU works on batch k; two jobs in flight, two pinned output buffers
+            pb = [ctx.host_alloc((dl.n_jobs * 96 * 1024,)) for _ in range(2)]
+            n_pipe = 8
+            ctx.png_end(ctx.png_begin(dl), pb[0])
+            t0 = time.perf_counter()
+            prev = ctx.png_begin(dl)
+            for k in range(1, n_pipe):
+                cur = ctx.png_begin(dl)
+                ctx.png_end(prev, pb[(k - 1) & 1])
+                prev = cur
+            _, off_p = ctx.png_end(prev, pb[(n_pipe - 1) & 1])
+            pipe_s = (time.perf_counter() - t0) / n_pipe
+            assert int(off_p[-1]) == int(off[-1])
+            for b_ in pb:
+                ctx.host_free(b_)
             result["end_to_end"] = {
                 "what": "wall clock around one osmt_render_batch / osmt_render_batch_png call (validation + H2D of the display lists + all "
                         "kernels + D2H into pinned host memory), best of 3; never `value`",
@@ -551,6 +596,8 @@ def main():
                 "raw_rgb8_pinned_tiles_per_s": dl.n_jobs / rgb_s, "raw_rgb8_ms": rgb_s * 1e3,
                 "png_files_pinned_tiles_per_s": dl.n_jobs / png_s, "png_ms": png_s * 1e3, "png_bytes_per_tile": float(off[-1]) / dl.n_jobs,
                 "png_files_worker_threads_tiles_per_s": pooled,
+                "png_files_begin_end_tiles_per_s": dl.n_jobs / pipe_s, "png_begin_end_ms_per_batch": pipe_s * 1e3,
+                "png_begin_end_what": "one caller thread, osmt_render_batch_png_begin(k + 1) before osmt_render_batch_png_end(k), 8 batches",
             }
             ctx.host_free(pin)
             ctx.host_free(pbuf)
@@ -848,6 +895,7 @@ def main():
                        ("sustained_tiles_per_s", ("sustained", "tiles_per_s")), ("composite_hbm_frac", ("roofline_composite", "frac")),
                        ("raster_issue_frac", ("roofline_issue", "frac")), ("k_raster_ms", ("roofline", "avg_launch_ms")),
                        ("png_files_tiles_per_s", ("end_to_end", "png_files_pinned_tiles_per_s")),
+                       ("png_files_begin_end_tiles_per_s", ("end_to_end", "png_files_begin_end_tiles_per_s")),
                        ("png_bytes_per_tile", ("end_to_end", "png_bytes_per_tile")),
                        ("worker16_tiles_per_s", ("end_to_end", "worker_entry", "cases", "workers16", "tiles_per_s")),
                        ("worker16_p99_us", ("end_to_end", "worker_entry", "cases", "workers16", "p99_us")),

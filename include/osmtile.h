@@ -299,6 +299,18 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
  * is too small, so the call can be repeated with out_off[n_jobs] bytes). */
 int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off);
+/* The same call in two halves, for a caller thread that renders batch after batch (the reference answers request after
+ * request, src/http_server.rs:183-201): _begin validates, uploads and queues every kernel of the batch and returns
+ * without waiting; _end waits for the files, compacts them and copies them into out_png (same out_png / out_off
+ * contract as the one-piece call, same errors), and frees the job whatever it returns.  With batch k + 1 begun before
+ * batch k is ended, the validation and upload of k + 1 run on the host while the GPU renders and encodes k, and the
+ * read-back of k runs under the kernels of k + 1: one thread reaches what several threads of one-piece calls reach.
+ * The arrays of `batch` / `labels` must stay valid until _end returns (uploads are stream-ordered).  Every job holds its
+ * device buffers until it is ended: ~0.9 GB per 1024 tiles of 256 x 256 (PNG slots at 12 bits per filtered byte, the
+ * compacted blob, two chunks of framebuffers; kept in the context's buffer cache afterwards). */
+typedef struct osmt_png_job osmt_png_job;
+int osmt_render_batch_png_begin(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels /* may be NULL */, osmt_png_job** out_job);
+int osmt_render_batch_png_end(osmt_png_job* job, uint8_t* out_png, size_t out_capacity, uint64_t* out_off);
 
 /* ---- the per-request entry: one worker handle per server thread (SURVEY.md 8(b) "Threading") ----------------
  * The reference's server gives every request — ONE tile — to one of available_parallelism() worker threads, each
@@ -307,7 +319,7 @@ int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
  * (same arguments, same pixels, same errors, blocks until out_rgb holds the tiles), but requests of different
  * workers of one context that are in flight at the same moment are gathered into ONE launch sequence on the device:
  * a request that finds the device free starts at once, alone; requests that arrive while it renders wait and go out
- * together with the next one (at most 64 tiles per group, OSMT_WORKER_INFLIGHT = 4 groups on the device at a time).
+ * together with the next one (at most 64 tiles per group, OSMT_WORKER_INFLIGHT = 2 groups on the device at a time).
  * Sixteen threads calling the batch entry with one tile each queue up behind each other instead (round 3: 17 k
  * tiles/s at p99 9.6 ms).  Any thread may use any worker; a worker keeps its context alive like a scene does.
  * Batches of more than 64 tiles are rendered directly. */

@@ -142,10 +142,8 @@ struct osmt_scene {
     osmt_blk_bbox* d_blk = nullptr;
     double* d_rden = nullptr;
     uint32_t* d_op_job = nullptr;
-    uint32_t* d_vseg_base = nullptr;
-    uint32_t* d_stroke_op = nullptr;
-    uint32_t* d_vseg_blk_slot = nullptr;
-    uint32_t n_bin_slots = 0;
+    int4* d_vpts = nullptr;     /* per virtual segment: end points, op (k_opinfo -> k_prebin) */
+    uint32_t* d_vop = nullptr;
     uint32_t* d_cand_off = nullptr;
     unsigned long long* d_cursors = nullptr; /* 4 words; the per-sub-tile list counts follow (one memset) */
     uint32_t* d_cnt = nullptr;
@@ -161,7 +159,7 @@ struct osmt_scene {
     uint2* d_skey = nullptr;
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
-    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_vseg, h_op_job, h_vseg_base, h_stroke_op, h_vseg_blk_slot, h_lab_wide;
+    std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_vseg, h_op_job, h_lab_wide;
     std::vector<osmt_label_band> h_lab_bands;
     std::vector<osmt_labelinfo> h_lab_info;
     hipStream_t own_stream = nullptr; /* internal per-call scene: everything about it happens on this stream */
@@ -280,12 +278,17 @@ void err_slot_release(osmt_ctx* ctx, uint32_t* w) {
 void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
     bytes = align_up(bytes ? bytes : 1, (size_t)64 << 10);
     {
+        /* best fit, and never a buffer more than four times the request: first fit handed the megabyte-sized output
+         * staging of a gathered group to the next 20 KB upload, and the next group then had to hipHostMalloc (hundreds of
+         * microseconds) a new one — every time */
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        osmt_ctx::cached_buf* best = nullptr;
         for (auto& c : ctx->host_cache)
-            if (!c.used && c.bytes >= bytes) {
-                c.used = true;
-                return c.p;
-            }
+            if (!c.used && c.bytes >= bytes && c.bytes <= 4 * bytes && (!best || c.bytes < best->bytes)) best = &c;
+        if (best) {
+            best->used = true;
+            return best->p;
+        }
     }
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
@@ -379,6 +382,28 @@ void ctx_teardown(osmt_ctx* ctx) {
 
 void ctx_release(osmt_ctx* ctx) {
     if (ctx->refs.fetch_sub(1) == 1) ctx_teardown(ctx);
+}
+
+/* The wait at the end of a small request: the work behind it is ~100 us of kernels, and a thread that sleeps in the driver
+ * until the completion interrupt wakes it adds a noticeable share of that on top.  Poll the stream for a bounded time
+ * first (a request of the per-tile server loop is latency, not throughput), then fall back to the blocking wait.
+ * OSMT_SPIN_SYNC=0 turns the polling off. */
+hipError_t stream_sync_small(hipStream_t st) {
+    static const bool spin = [] {
+        const char* v = getenv("OSMT_SPIN_SYNC");
+        return !(v && v[0] == '0');
+    }();
+    if (spin) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if (std::chrono::steady_clock::now() >= t_end) break;
+        }
+        (void)hipGetLastError(); /* hipErrorNotReady is sticky in hipGetLastError */
+    }
+    return hipStreamSynchronize(st);
 }
 
 /* Device -> host copy of finished data on a private pooled stream: a NULL-stream hipMemcpy would order itself against
@@ -597,10 +622,8 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.op_job = sc->d_op_job;
     a.op_blk = sc->d_op_blk;
     a.op_vseg = sc->d_op_vseg;
-    a.vseg_base = sc->d_vseg_base;
-    a.stroke_op = sc->d_stroke_op;
-    a.vseg_blk_slot = sc->d_vseg_blk_slot;
-    a.n_strokes = sc->n_bin_slots;
+    a.vpts = sc->d_vpts;
+    a.vop = sc->d_vop;
     a.n_vsegs = sc->n_vsegs;
     a.scale = sc->scale;
     a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
@@ -637,10 +660,16 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     const uint32_t W = OSMT_TILE_SIZE * sc->scale;
     if ((stages & 4u) && !d_out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
     if ((stages & 4u) && !f64 && stride < (size_t)W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
-    if ((stages & 1u) && sc->coord_kind != OSMT_COORD_POINT_I32)
+    bool zeroed = false;
+    if ((stages & 1u) && sc->coord_kind != OSMT_COORD_POINT_I32) {
+        /* when the pre-pass follows in this call, the projection kernel clears its cursors and list counts on the way */
+        const osmt_prepass_args pa = prepass_args(sc, false);
+        zeroed = (stages & 2u) != 0u && sc->n_pts != 0u;
         HIP_TRY(osmt_launch_project(sc->d_jobs, sc->d_pt_job, sc->d_latlon, sc->coord_kind == OSMT_COORD_NODE_REF ? sc->d_node_refs : nullptr,
-                                    sc->n_pts, (double)sc->scale, sc->d_pts, st));
-    if (stages & 2u) HIP_TRY(osmt_launch_prepass(prepass_args(sc, false), st));
+                                    sc->n_pts, (double)sc->scale, sc->d_pts, st, zeroed ? reinterpret_cast<uint32_t*>(pa.cursors) : nullptr,
+                                    zeroed ? osmt_prepass_zero_words(pa) : 0));
+    }
+    if (stages & 2u) HIP_TRY(osmt_launch_prepass(prepass_args(sc, false), st, zeroed));
     const bool want_labels = sc->n_labels && !f64;
     if (want_labels && ((stages & 8u) || ((stages & 4u) && !(stages & 16u)))) {
         /* the label pass does not read the area canvas: coverage + collisions first, then
@@ -903,11 +932,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     /* op -> job; stroke slot -> op; first virtual segment (edges + the two cap stubs of Round/Square caps,
      * line.rs:33-57) of every stroke slot: k_stroke_bin runs one thread per virtual segment of the scene */
     std::vector<uint32_t>& op_job = s->h_op_job;
-    std::vector<uint32_t>& vseg_base = s->h_vseg_base;
-    std::vector<uint32_t>& stroke_op = s->h_stroke_op;
     op_job.assign(b->n_ops, 0u);
-    vseg_base.clear();
-    stroke_op.clear();
     uint32_t n_strokes = 0;
     size_t n_blk = 0; /* 64-edge blocks of the ops with more than 64 edges */
     size_t n_vsegs = 0, n_fills = 0;
@@ -931,12 +956,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             if (op.kind == OSMT_OP_STROKE) {
                 op_aux[job.op_off + k] = n_strokes++;
                 const size_t nv = ne + ((op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE) ? 2u : 0u);
-                if (nv) { /* only ops with segments enter the binning table: 64 consecutive segments then span <= 64 entries */
-                    stroke_op.push_back(job.op_off + k);
-                    op_vseg[job.op_off + k] = (uint32_t)n_vsegs;
-                    vseg_base.push_back((uint32_t)n_vsegs);
-                    n_vsegs += nv;
-                }
+                op_vseg[job.op_off + k] = (uint32_t)n_vsegs; /* k_opinfo writes the per-segment tables from here on */
+                n_vsegs += nv;
             } else {
                 ++n_fills;
             }
@@ -945,13 +966,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (n_vsegs >= 0xFFFFFFFFull) {
         delete s;
         return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices (stroke segments)");
-    }
-    vseg_base.push_back((uint32_t)n_vsegs);
-    std::vector<uint32_t>& blk_slot = s->h_vseg_blk_slot;
-    blk_slot.assign((n_vsegs + 63) / 64, 0u);
-    for (size_t e = 0, bk = 0; bk < blk_slot.size(); ++bk) {
-        while (vseg_base[e + 1] <= bk * 64) ++e; /* entry e owns segment 64 * bk */
-        blk_slot[bk] = (uint32_t)e;
     }
 
     s->ctx = ctx;
@@ -988,9 +1002,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_opblk = carve(b->n_ops * 4);
     const size_t o_opvseg = carve(b->n_ops * 4);
     const size_t o_opjob = carve(b->n_ops * 4);
-    const size_t o_vsegbase = carve(vseg_base.size() * 4);
-    const size_t o_strokeop = carve(((size_t)n_strokes + 1) * 4);
-    const size_t o_blkslot = carve((blk_slot.size() + 1) * 4);
     const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     /* per virtual segment (not per point: two stroke ops may share a ring, e.g. a casing and its stroke) */
@@ -1002,6 +1013,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
     const size_t o_rden = carve((n_vsegs + 1) * 8);
     const size_t o_candoff = carve((n_vsegs + 1) * 4);
+    const size_t o_vpts = carve((n_vsegs + 1) * sizeof(int4));
+    const size_t o_vop = carve((n_vsegs + 1) * 4);
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
@@ -1033,10 +1046,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_blk = (osmt_blk_bbox*)(s->d_base + o_blk);
     s->d_rden = (double*)(s->d_base + o_rden);
     s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
-    s->d_vseg_base = (uint32_t*)(s->d_base + o_vsegbase);
-    s->d_stroke_op = (uint32_t*)(s->d_base + o_strokeop);
-    s->d_vseg_blk_slot = (uint32_t*)(s->d_base + o_blkslot);
-    s->n_bin_slots = (uint32_t)stroke_op.size();
+    s->d_vpts = (int4*)(s->d_base + o_vpts);
+    s->d_vop = (uint32_t*)(s->d_base + o_vop);
     s->d_cand_off = (uint32_t*)(s->d_base + o_candoff);
     s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
     s->d_cnt = (uint32_t*)(s->d_base + o_cursors + 32);
@@ -1067,9 +1078,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         put(o_opblk, op_blk.data(), b->n_ops * 4);
         put(o_opvseg, op_vseg.data(), b->n_ops * 4);
         put(o_opjob, op_job.data(), b->n_ops * 4);
-        put(o_vsegbase, vseg_base.data(), vseg_base.size() * 4);
-        put(o_strokeop, stroke_op.data(), stroke_op.size() * 4);
-        put(o_blkslot, blk_slot.data(), blk_slot.size() * 4);
         s->h_stage = stage;
         err = hipMemcpyAsync(s->d_base, stage, front_bytes, hipMemcpyHostToDevice, st);
         if (err == hipSuccess && !host_pt_job) err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st);
@@ -1106,9 +1114,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_vseg, op_vseg.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
-    if (err == hipSuccess) err = up(s->d_vseg_base, vseg_base.data(), vseg_base.size() * 4);
-    if (err == hipSuccess) err = up(s->d_stroke_op, stroke_op.data(), stroke_op.size() * 4);
-    if (err == hipSuccess) err = up(s->d_vseg_blk_slot, blk_slot.data(), blk_slot.size() * 4);
     if (err != hipSuccess) {
         dev_free(ctx, s->d_base);
         scene_delete(s);
@@ -1569,7 +1574,7 @@ static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch,
             else
                 e = hipMemcpy2DAsync(out_rgba, stride, src, host_bytes, host_bytes, batch->n_jobs, hipMemcpyDeviceToHost, st);
         }
-        if (rc == OSMT_OK && e == hipSuccess) e = hipStreamSynchronize(st);
+        if (rc == OSMT_OK && e == hipSuccess) e = batch->n_jobs <= 64 ? stream_sync_small(st) : hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "readback failed: %s", hipGetErrorString(e));
     }
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
@@ -1632,134 +1637,197 @@ int osmt_encode_png_device(osmt_ctx* ctx, const void* d_rgba, size_t tile_stride
  * encode -> file lengths in CHUNKS on the call's stream, all enqueued up front.  The host walks the chunks behind the
  * GPU: as soon as a chunk's lengths are back it sums the file offsets and queues that chunk's compaction and read-back
  * on a second stream — the PCIe transfer of chunk c runs under the kernels of chunk c + 1. */
-static int osmt_render_batch_png_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
-                          uint64_t* out_off) {
-    if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = nullptr; /* the whole call lives on its own stream */
-    HIP_TRY(stream_acquire(ctx, &st));
+/* One batch on its way through the PNG pipeline: everything osmt_render_batch_png_begin queued and what
+ * osmt_render_batch_png_end needs to finish it. */
+struct osmt_png_job {
+    osmt_ctx* ctx = nullptr;
+    hipStream_t st = nullptr, s_c = nullptr; /* the job's own stream; the compaction / read-back stream (more than one chunk) */
     osmt_scene* sc = nullptr;
-    int rc = scene_upload_impl(ctx, batch, &sc, st);
-    if (rc != OSMT_OK) {
-        stream_release(ctx, st);
-        return rc;
+    char* d = nullptr;         /* framebuffers of two chunks, PNG slots, lengths, offsets, compacted blob */
+    uint32_t* h_len = nullptr; /* pinned: lengths come back asynchronously, offsets go out */
+    std::vector<hipEvent_t> ev;
+    uint32_t n = 0, W = 0, chunk = 0, n_chunks = 0;
+    size_t slot = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0;
+    int rc = OSMT_OK; /* a failure of the first half, reported by the second */
+    std::string err;
+};
+
+static void png_job_release(osmt_png_job* j) {
+    if (!j) return;
+    osmt_ctx* ctx = j->ctx;
+    for (hipEvent_t v : j->ev)
+        if (v) (void)hipEventDestroy(v);
+    if (j->sc) osmt_scene_free(j->sc); /* waits for the job's stream */
+    dev_free(ctx, j->d);
+    if (j->h_len) stage_release(ctx, j->h_len);
+    if (j->s_c) stream_release(ctx, j->s_c);
+    if (j->st) stream_release(ctx, j->st);
+    delete j;
+}
+
+/* First half.  The pre-pass runs once for the whole batch; then the tiles go through raster -> PNG encode -> file lengths
+ * in CHUNKS on the job's stream, all enqueued here; nothing is waited for. */
+static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, osmt_png_job** out_job) {
+    if (!ctx || !out_job) return fail(OSMT_INVALID_ARG, "NULL argument");
+    *out_job = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    osmt_png_job* j = new (std::nothrow) osmt_png_job();
+    if (!j) return fail(OSMT_OOM, "out of host memory");
+    j->ctx = ctx;
+    hipError_t e = stream_acquire(ctx, &j->st); /* the whole job lives on its own stream */
+    if (e != hipSuccess) {
+        delete j;
+        return fail(OSMT_HIP_ERROR, "stream: %s", hipGetErrorString(e));
     }
-    if (labels) rc = osmt_scene_set_labels(ctx, sc, labels);
-    const uint32_t n = (uint32_t)batch->n_jobs;
-    const uint32_t W = OSMT_TILE_SIZE * batch->scale;
-    const size_t tile_bytes = (size_t)W * W * 4, slot = osmt_png_device_bound(W, W);
-    /* the encoder is one workgroup per tile: below ~2 workgroups per CU it is latency-bound and a chunk costs more than
-     * its overlap brings (measured on 1024 tiles: 1 chunk 4.21 ms, 2 chunks 4.10, 4 chunks 4.82, 8 chunks 7.07) */
-    const uint32_t min_chunk = std::max<uint32_t>(1u, 512u / (batch->scale * batch->scale));
-    uint32_t chunk = n;
-    if (n >= 2u * min_chunk) chunk = std::max<uint32_t>(min_chunk, (n + 1u) / 2u);
-    /* OSMT_PNG_CHUNKS (diagnostic: force the number of chunks): read ONCE — getenv on every call from worker threads is
-     * not safe against a host that calls setenv — and clamped, so that a large value cannot turn one call into n events,
-     * n tiny encode launches and n copies */
-    static const int forced_chunks = [] {
-        const char* v = getenv("OSMT_PNG_CHUNKS");
-        return v ? std::min(std::max(atoi(v), 1), 16) : 0;
-    }();
-    if (forced_chunks) chunk = std::max<uint32_t>(1u, (n + (uint32_t)forced_chunks - 1u) / (uint32_t)forced_chunks);
-    const uint32_t n_chunks = n ? (n + chunk - 1u) / chunk : 0u;
-    char* d = nullptr;
-    uint32_t* h_len = nullptr;       /* pinned: lengths come back asynchronously, offsets go out */
-    size_t o_rgba = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0;
-    hipStream_t s_c = nullptr;
-    std::vector<hipEvent_t> ev(n_chunks, nullptr);
+    int rc = scene_upload_impl(ctx, batch, &j->sc, j->st);
+    if (rc == OSMT_OK && labels) rc = osmt_scene_set_labels(ctx, j->sc, labels);
+    const uint32_t n = j->n = batch ? (uint32_t)batch->n_jobs : 0u;
     if (rc == OSMT_OK && n) {
+        const uint32_t W = j->W = OSMT_TILE_SIZE * batch->scale;
+        const size_t tile_bytes = (size_t)W * W * 4, slot = j->slot = osmt_png_device_bound(W, W);
+        /* the encoder is one workgroup per tile: below ~2 workgroups per CU it is latency-bound and a chunk costs more than
+         * its overlap brings (measured on 1024 tiles: 1 chunk 4.21 ms, 2 chunks 4.10, 4 chunks 4.82, 8 chunks 7.07) */
+        const uint32_t min_chunk = std::max<uint32_t>(1u, 512u / (batch->scale * batch->scale));
+        uint32_t chunk = n;
+        if (n >= 2u * min_chunk) chunk = std::max<uint32_t>(min_chunk, (n + 1u) / 2u);
+        /* OSMT_PNG_CHUNKS (diagnostic: force the number of chunks): read ONCE — getenv on every call from worker threads is
+         * not safe against a host that calls setenv — and clamped, so that a large value cannot turn one call into n events,
+         * n tiny encode launches and n copies */
+        static const int forced_chunks = [] {
+            const char* v = getenv("OSMT_PNG_CHUNKS");
+            return v ? std::min(std::max(atoi(v), 1), 16) : 0;
+        }();
+        if (forced_chunks) chunk = std::max<uint32_t>(1u, (n + (uint32_t)forced_chunks - 1u) / (uint32_t)forced_chunks);
+        j->chunk = chunk;
+        const uint32_t n_chunks = j->n_chunks = (n + chunk - 1u) / chunk;
         size_t off = 0;
         auto carve = [&](size_t bytes) {
             const size_t o = off;
             off = align_up(off + bytes, 256);
             return o;
         };
-        o_rgba = carve((size_t)std::min<uint32_t>(2u, n_chunks) * chunk * tile_bytes); /* two chunks of framebuffers, alternating */
-        o_png = carve((size_t)n * slot);
-        o_len = carve((size_t)n * 4);
-        o_off = carve((size_t)n * 8);
-        o_blob = carve((size_t)n * slot);
-        hipError_t e = dev_alloc(ctx, (void**)&d, off);
+        const size_t o_rgba = carve((size_t)std::min<uint32_t>(2u, n_chunks) * chunk * tile_bytes); /* two chunks of framebuffers, alternating */
+        j->o_png = carve((size_t)n * slot);
+        j->o_len = carve((size_t)n * 4);
+        j->o_off = carve((size_t)n * 8);
+        j->o_blob = carve((size_t)n * slot);
+        e = dev_alloc(ctx, (void**)&j->d, off);
         if (e != hipSuccess) rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
         if (rc == OSMT_OK) {
-            h_len = (uint32_t*)stage_acquire(ctx, (size_t)n * 12 + 16);
-            if (!h_len) rc = fail(OSMT_OOM, "pinned staging for %u file lengths", n);
+            j->h_len = (uint32_t*)stage_acquire(ctx, (size_t)n * 12 + 16);
+            if (!j->h_len) rc = fail(OSMT_OOM, "pinned staging for %u file lengths", n);
         }
         if (rc == OSMT_OK && n_chunks > 1u) {
-            e = stream_acquire(ctx, &s_c);
+            e = stream_acquire(ctx, &j->s_c);
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "stream: %s", hipGetErrorString(e));
         }
+        j->ev.assign(n_chunks, nullptr);
         for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
-            e = hipEventCreateWithFlags(&ev[c], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&j->ev[c], hipEventDisableTiming);
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "event: %s", hipGetErrorString(e));
         }
-    }
-    std::vector<unsigned long long> offs((size_t)n + 1, 0ull);
-    unsigned long long* const h_off = h_len ? reinterpret_cast<unsigned long long*>(h_len + ((n + 1u) & ~1u)) : nullptr; /* chunk-relative offsets */
-    hipStream_t s_copy = s_c ? s_c : st;
-    hipError_t e = hipSuccess;
-    if (rc == OSMT_OK && n) {
         /* ---- everything the GPU has to do, queued at once ---- */
-        rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, st);
+        if (rc == OSMT_OK) rc = render_impl(ctx, j->sc, 1u | 2u | 8u, nullptr, tile_bytes, false, j->st);
         for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
             const uint32_t first = c * chunk, cnt = std::min(chunk, n - first);
-            char* rgba = d + o_rgba + (size_t)(c & 1u) * chunk * tile_bytes;
-            rc = render_impl(ctx, sc, 4u | 16u, rgba, tile_bytes, false, st, first, cnt);
+            char* rgba = j->d + o_rgba + (size_t)(c & 1u) * chunk * tile_bytes;
+            rc = render_impl(ctx, j->sc, 4u | 16u, rgba, tile_bytes, false, j->st, first, cnt);
             if (rc == OSMT_OK)
-                rc = osmt_encode_png_device(ctx, rgba, tile_bytes, cnt, W, W, d + o_png + (size_t)first * slot, slot, (uint32_t*)(d + o_len) + first, st);
+                rc = osmt_encode_png_device(ctx, rgba, tile_bytes, cnt, W, W, j->d + j->o_png + (size_t)first * slot, slot,
+                                            (uint32_t*)(j->d + j->o_len) + first, j->st);
             if (rc == OSMT_OK) {
-                e = hipMemcpyAsync(h_len + first, d + o_len + (size_t)first * 4, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipEventRecord(ev[c], st);
+                e = hipMemcpyAsync(j->h_len + first, j->d + j->o_len + (size_t)first * 4, (size_t)cnt * 4, hipMemcpyDeviceToHost, j->st);
+                if (e == hipSuccess) e = hipEventRecord(j->ev[c], j->st);
                 if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
             }
         }
-        /* ---- the host follows chunk by chunk ---- */
+    }
+    if (rc != OSMT_OK) {
+        const std::string msg = osmt_last_error();
+        png_job_release(j);
+        return fail(rc, "%s", msg.c_str());
+    }
+    *out_job = j;
+    return OSMT_OK;
+}
+
+/* Second half.  The host walks the chunks behind the GPU: as soon as a chunk's lengths are back it sums the file
+ * offsets and queues that chunk's compaction and read-back on a second stream — the PCIe transfer of chunk c runs under
+ * the kernels of chunk c + 1 (and under the kernels of the NEXT job, when the caller has already begun one).  Releases
+ * the job whatever happens. */
+static int png_end_body(osmt_png_job* j, uint8_t* out_png, size_t out_capacity, uint64_t* out_off) {
+    if (!j) return fail(OSMT_INVALID_ARG, "NULL job");
+    if (!out_off || (!out_png && out_capacity)) {
+        png_job_release(j);
+        return fail(OSMT_INVALID_ARG, "NULL argument");
+    }
+    osmt_ctx* ctx = j->ctx;
+    int rc = OSMT_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "hipSetDevice: %s", hipGetErrorString(e));
+    const uint32_t n = j->n, chunk = j->chunk;
+    std::vector<unsigned long long> offs((size_t)n + 1, 0ull);
+    if (rc == OSMT_OK && n) {
+        unsigned long long* const h_off = reinterpret_cast<unsigned long long*>(j->h_len + ((n + 1u) & ~1u)); /* chunk-relative offsets */
+        hipStream_t s_copy = j->s_c ? j->s_c : j->st;
+        char* const d = j->d;
+        const size_t slot = j->slot;
         bool fits = true;
-        for (uint32_t c = 0; rc == OSMT_OK && c < n_chunks; ++c) {
+        for (uint32_t c = 0; rc == OSMT_OK && c < j->n_chunks; ++c) {
             const uint32_t first = c * chunk, cnt = std::min(chunk, n - first);
-            e = hipEventSynchronize(ev[c]);
+            e = hipEventSynchronize(j->ev[c]);
             if (e != hipSuccess) {
                 rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
                 break;
             }
             for (uint32_t i = 0; i < cnt; ++i) {
                 h_off[first + i] = offs[first + i] - offs[first];
-                offs[first + i + 1] = offs[first + i] + h_len[first + i];
+                offs[first + i + 1] = offs[first + i] + j->h_len[first + i];
             }
             const size_t c_bytes = (size_t)(offs[first + cnt] - offs[first]);
             if (offs[first + cnt] > out_capacity) fits = false; /* keep summing: the caller learns the size it needs */
             if (!fits || c_bytes == 0) continue;
-            char* blob = d + o_blob + (size_t)first * slot;
-            e = hipMemcpyAsync(d + o_off + (size_t)first * 8, h_off + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s_copy);
+            char* blob = d + j->o_blob + (size_t)first * slot;
+            e = hipMemcpyAsync(d + j->o_off + (size_t)first * 8, h_off + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s_copy);
             if (e == hipSuccess)
-                e = osmt_launch_png_compact(d + o_png + (size_t)first * slot, slot, (const uint32_t*)(d + o_len) + first,
-                                            (const unsigned long long*)(d + o_off) + first, cnt, blob, s_copy);
+                e = osmt_launch_png_compact(d + j->o_png + (size_t)first * slot, slot, (const uint32_t*)(d + j->o_len) + first,
+                                            (const unsigned long long*)(d + j->o_off) + first, cnt, blob, s_copy);
             if (e == hipSuccess) e = hipMemcpyAsync(out_png + offs[first], blob, c_bytes, hipMemcpyDeviceToHost, s_copy);
             if (e != hipSuccess) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
         }
-        if (s_c) {
-            e = hipStreamSynchronize(s_c);
+        if (j->s_c) {
+            e = hipStreamSynchronize(j->s_c);
             if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "PNG readback failed: %s", hipGetErrorString(e));
         }
-        e = hipStreamSynchronize(st);
+        e = hipStreamSynchronize(j->st);
         if (e != hipSuccess && rc == OSMT_OK) rc = fail(OSMT_HIP_ERROR, "PNG pipeline: %s", hipGetErrorString(e));
         if (rc == OSMT_OK && !fits) rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %llu bytes of PNG data", out_capacity, offs[n]);
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
-    if (rc == OSMT_OK) rc = label_error_check(sc, st);
-    for (hipEvent_t v : ev)
-        if (v) (void)hipEventDestroy(v);
-    osmt_scene_free(sc); /* waits for the call's stream */
-    dev_free(ctx, d);
-    if (h_len) stage_release(ctx, h_len);
-    if (s_c) stream_release(ctx, s_c);
-    stream_release(ctx, st);
-    return rc;
+    if (rc == OSMT_OK) rc = label_error_check(j->sc, j->st);
+    const std::string msg = rc != OSMT_OK ? std::string(osmt_last_error()) : std::string();
+    png_job_release(j);
+    return rc != OSMT_OK ? fail(rc, "%s", msg.c_str()) : OSMT_OK;
 }
 
+int osmt_render_batch_png_begin(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, osmt_png_job** out_job) {
+    return guarded([&] { return png_begin_body(ctx, batch, labels, out_job); });
+}
+
+int osmt_render_batch_png_end(osmt_png_job* job, uint8_t* out_png, size_t out_capacity, uint64_t* out_off) {
+    return guarded([&] { return png_end_body(job, out_png, out_capacity, out_off); });
+}
+
+/* One call = its own pipeline: begin + end. */
 int osmt_render_batch_png(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_png, size_t out_capacity,
                           uint64_t* out_off) {
-    return guarded([&] { return osmt_render_batch_png_body(ctx, batch, labels, out_png, out_capacity, out_off); });
+    return guarded([&] {
+        if (!ctx || !out_off || (!out_png && out_capacity)) return fail(OSMT_INVALID_ARG, "NULL argument");
+        osmt_png_job* j = nullptr;
+        const int rc = png_begin_body(ctx, batch, labels, &j);
+        if (rc != OSMT_OK) return rc;
+        return png_end_body(j, out_png, out_capacity, out_off);
+    });
 }
 
 static int osmt_host_alloc_body(osmt_ctx* ctx, size_t bytes, void** out) {
@@ -2362,7 +2430,7 @@ constexpr size_t CO_MAX_TILES = 64;
 int co_max_in_flight() {
     static const int v = [] {
         const char* e = getenv("OSMT_WORKER_INFLIGHT");
-        return e ? std::min(std::max(atoi(e), 1), 16) : 4;
+        return e ? std::min(std::max(atoi(e), 1), 16) : 2;
     }();
     return v;
 }

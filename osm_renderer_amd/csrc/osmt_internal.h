@@ -61,17 +61,22 @@ struct osmt_opinfo {
     int32_t x0, y0, x1, y1; /* inclusive extent of the op's points (empty: x0 > x1) */
     uint32_t aux;           /* STROKE: index into the stroke_aux table */
     uint32_t n_edges;       /* total edges over all rings */
-    int32_t reach;          /* STROKE: max per-axis distance of a drawn pixel from its Bresenham centre */
-    int32_t reach_major;    /* STROKE: the same along the segment's major axis only (tighter) */
+    uint32_t first_pt;      /* first point of the op's FIRST ring: a one-ring polygon is binned without touching osmt_op / osmt_ring */
+    uint32_t n_rings;       /* osmt_op.n_rings */
     uint8_t kind, cap, color[3], _pad[3]; /* osmt_op.kind / cap / color */
     /* FILL: first 64-byte group (16 row words of one sub-tile) of the op's coverage masks in the fill arena;
      * STROKE: first record of the op in the stroke-record arena */
     uint32_t arena_off;
     uint32_t rec_cap;   /* STROKE: slots of the op in the stroke arena = sum over its virtual segments of the sub-tiles
                          * in each one's window; slot order = segment order (edges, then the two cap stubs), window row-major */
-    /* FILL: sub-tile window the masks cover: sr0 | c0 << 8 | ncols << 16 | nsr << 24 (nsr == 0: no covered row inside the tile) */
-    uint32_t fill_geom;
-    uint32_t image_id;  /* FILL_IMAGE: osmt_op.image_id */
+    union {
+        struct {
+            /* FILL: sub-tile window the masks cover: sr0 | c0 << 8 | ncols << 16 | nsr << 24 (nsr == 0: no covered row inside the tile) */
+            uint32_t fill_geom;
+            uint32_t image_id; /* FILL_IMAGE: osmt_op.image_id */
+        };
+        double stroke_ft; /* STROKE: max(|half_width| + 0.5, 1.0), the feather_to the binning bounds a run's reach with */
+    };
     double opacity;     /* osmt_op.opacity */
 };
 static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record");
@@ -243,11 +248,6 @@ struct osmt_prepass_args {
     const uint32_t* op_job;   /* op -> job */
     const uint32_t* op_blk;   /* op -> first 64-edge block bbox (0xFFFFFFFF: none) */
     const uint32_t* op_vseg;  /* op -> its first virtual segment (stroke ops that have segments) */
-    /* binning table of the stroke ops that HAVE virtual segments (edges + cap stubs), in op order */
-    const uint32_t* vseg_base; /* [n_strokes + 1]: first virtual segment of every entry; last = n_vsegs */
-    const uint32_t* stroke_op; /* [n_strokes]: entry -> op */
-    const uint32_t* vseg_blk_slot; /* [ceil(n_vsegs / 64)]: entry that owns virtual segment 64 * b */
-    uint32_t n_strokes;        /* entries of the binning table */
     uint32_t n_vsegs;
     uint32_t scale;
     uint32_t sub_rows;
@@ -260,6 +260,11 @@ struct osmt_prepass_args {
     osmt_blk_bbox* blk;
     uint32_t* submask;
     uint32_t* cand_off; /* per virtual segment: first slot (relative to the op) of the edge's sub-tile window */
+    /* per virtual segment too, so that the binning kernel starts from ONE level of loads (round 3 went vseg -> table slot ->
+     * op -> opinfo -> osmt_op -> ring -> points, seven dependent round trips for a latency-bound kernel): end points of
+     * the edge / cap stub (p1 == p2: draws nothing) and its op, bit 31 = the segment is a cap stub */
+    int4* vpts;
+    uint32_t* vop;
     unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries; zeroed by the launcher */
     uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
     uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */
@@ -278,14 +283,16 @@ struct osmt_prepass_args {
 #define OSMT_PREPASS_ERR_STROKE_ARENA 2u
 #define OSMT_PREPASS_ERR_LIST_ARENA 4u
 
+/* zero / n_zero (optional): 32-bit words the kernel clears on the way — the cursors and list counts of the pre-pass that follows */
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
-                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st);
+                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st, uint32_t* zero = nullptr, size_t n_zero = 0);
+size_t osmt_prepass_zero_words(const osmt_prepass_args& a);
 /* point -> job table on the device: pt_job[i] = j for the points of job j, 0xFFFFFFFF for points no job owns */
 hipError_t osmt_launch_ptjob(const osmt_tile_job* jobs, uint32_t n_jobs, uint32_t* pt_job, uint32_t n_pts, hipStream_t st);
 hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t zoom, uint32_t tx, uint32_t ty,
                                       double scale, int32_t* pts, hipStream_t st);
 /* k_opinfo -> k_fill_rows -> k_stroke_bin on `st` (sizing pass: k_opinfo only) */
-hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st);
+hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool zeroed = false);
 hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream_t st);
 /* label pass: cover (one wave per label) -> resolve (one workgroup per tile, labels in order) */
 hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st);

@@ -72,8 +72,11 @@ __device__ __forceinline__ void project_point(double lat, double lon, uint32_t z
 __global__ __launch_bounds__(256) void k_project(const osmt_tile_job* __restrict__ jobs,
                                                  const uint32_t* __restrict__ pt_job,
                                                  const double2* __restrict__ latlon, const uint32_t* __restrict__ refs,
-                                                 uint32_t n_pts, double scale, int2* __restrict__ pts) {
+                                                 uint32_t n_pts, double scale, int2* __restrict__ pts, uint32_t* __restrict__ zero,
+                                                 uint32_t n_zero) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    /* the pre-pass cursors and list counts of the step that follows (a memset node of its own was 4 us of a 90 us request) */
+    if (i < n_zero) zero[i] = 0u;
     if (i >= n_pts) return;
     const uint32_t j = pt_job[i];
     if (j == 0xFFFFFFFFu) {
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     oi.x1 = oi.y1 = INT32_MIN;
     oi.aux = a.op_aux[o];
     oi.n_edges = 0;
-    oi.reach = 0;
-    oi.reach_major = 0;
+    oi.first_pt = op.kind != OSMT_OP_NONE && op.n_rings ? rings[op.ring_off].first_pt : 0u;
+    oi.n_rings = op.kind != OSMT_OP_NONE ? op.n_rings : 0u;
     oi.kind = op.kind;
     oi.cap = op.cap;
     oi.color[0] = op.color[0];
@@ -299,6 +302,8 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     a.rden[e] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
                     traveled += len;
                     a.cand_off[e] = (uint32_t)min(cand, 0xFFFFFFFFull);
+                    a.vpts[e] = make_int4(prev.x, prev.y, p.x, p.y);
+                    a.vop[e] = o;
                     if (!(prev.x == p.x && prev.y == p.y)) { /* a degenerate edge draws nothing (line.rs:73-75) */
                         cand += window_count(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
                         /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
@@ -337,6 +342,20 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         }
         sa->cap_seg[0] = c0;
         sa->cap_seg[1] = c1;
+        if (caps) { /* the two stubs are the op's last two virtual segments; an invalid one is stored degenerate (p1 == p2) */
+            const osmt_cap_seg* cs[2] = {&c0, &c1};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t e = vbase + n_edges + (uint32_t)i;
+                const bool ok = cs[i]->valid != 0;
+                a.vpts[e] = ok ? make_int4(cs[i]->p1x, cs[i]->p1y, cs[i]->p2x, cs[i]->p2y) : make_int4(0, 0, 0, 0);
+                a.vop[e] = o | 0x80000000u;
+                a.trav[e] = 0.0;
+                a.den[e] = cs[i]->denom;
+                a.rden[e] = 1.0 / cs[i]->denom;
+                a.cand_off[e] = cs[i]->cand_off;
+            }
+        }
         sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
         sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
         sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
@@ -359,6 +378,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         sa->caps.n_segs = 1;
         if (cand > 0xFFFFFFFFull) cand = 0xFFFFFFFFull; /* cannot happen below 2^32 records per scene (checked by the host) */
         oi.rec_cap = (uint32_t)cand;
+        oi.stroke_ft = ft;
         want_s = cand;
     } else if (!none) {
         /* fills: rows ytop+1 .. ybot carry records (fill.rs:66-72), spans lie inside the points' x range */
@@ -947,11 +967,10 @@ __device__ __forceinline__ void fill_rows_body(FillShared& sh, const uint32_t gr
             if (kind == OSMT_OP_FILL_COLOR || kind == OSMT_OP_FILL_IMAGE) {
                 geom = oi->fill_geom; /* nsr == 0: no covered row inside the tile */
                 arena = oi->arena_off;
-                const osmt_op* __restrict__ op = &g_ops[o_first + k];
                 ne = 0xFFFFFFFFu;
-                if (op->n_rings == 1u && oi->n_edges <= 16u) {
+                if (oi->n_rings == 1u && oi->n_edges <= 16u) { /* everything about a small one-ring polygon is in its opinfo */
                     ne = oi->n_edges;
-                    pt0 = g_rings[op->ring_off].first_pt;
+                    pt0 = oi->first_pt;
                 }
             }
         }
@@ -1265,83 +1284,45 @@ struct StrokeBinSeg {
     uint32_t _pad;
 };
 struct StrokeBinShared {
-    uint32_t base[65];
     uint32_t incl[64]; /* inclusive pair count over the block's segments */
     StrokeBinSeg seg[64];
 };
 
 __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint32_t blk, const uint32_t lane,
-                                                const osmt_op* __restrict__ g_ops, const osmt_opinfo* __restrict__ g_info,
-                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
-                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
-                                                const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
-                                                const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_vseg_blk_slot,
-                                                const uint32_t* __restrict__ g_stroke_op, uint32_t n_strokes, uint32_t n_vsegs, uint32_t scale,
-                                                uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
+                                                const osmt_opinfo* __restrict__ g_info, const int4* __restrict__ g_vpts,
+                                                const uint32_t* __restrict__ g_vop, const double* __restrict__ g_trav,
+                                                const double* __restrict__ g_den, const double* __restrict__ g_rden, uint32_t n_vsegs,
+                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
                                                 osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
                                                 uint32_t* __restrict__ g_cnt) {
-    /* ---- step A, lane = virtual segment: its op, end points, sub-tile window.  The block's first segment lies in
-     * slot s0 of the host's binning table, the other 63 in the next <= 63 slots: one coalesced load of their bases,
-     * then a bisection in LDS. ---- */
+    /* ---- step A, lane = virtual segment: its op, end points, sub-tile window — everything k_opinfo left per segment
+     * comes in with ONE level of loads, the op's record with a second ---- */
     const uint32_t g = blk * 64u + lane;
-    const uint32_t s0 = g_vseg_blk_slot[blk];
-    sh.base[lane] = g_vseg_base[min(s0 + lane, n_strokes)];
-    if (lane == 0u) sh.base[64] = g_vseg_base[min(s0 + 64u, n_strokes)];
-    __syncthreads();
     const int32_t W = (int32_t)(OSMT_TILE_SIZE * scale);
     const int32_t n_sub_x = W / SUB, n_sub_y = (int32_t)sub_rows;
     uint32_t n_pairs = 0u;
     if (g < n_vsegs) {
-        /* largest j in 0..64 with base[j] <= g: holds for j = 0; entries past the table hold n_vsegs (> g); every slot of
-         * the (compressed) table owns at least one segment, so 64 consecutive segments span at most 64 slots */
-        uint32_t lo = 0u, hi = 65u;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (sh.base[mid] <= g) lo = mid; else hi = mid;
-        }
-        const uint32_t v = g - sh.base[lo];
-        lo += s0;
-        const uint32_t o = g_stroke_op[lo];
-        const osmt_opinfo oi = g_info[o];
+        const uint32_t vo = g_vop[g];
+        const int4 pp = g_vpts[g];
+        const uint32_t o = vo & 0x7FFFFFFFu;
         StrokeBinSeg sg;
-        sg.rec.traveled = 0.0;
-        sg.is_cap = 0u;
-        uint32_t cand_off = 0u;
-        bool valid = true;
-        if (v < oi.n_edges) {
-            /* (ring, edge) of running edge index v (point_pairs.rs:36-40) */
-            const osmt_op* __restrict__ op = &g_ops[o];
-            uint32_t r = 0, e = v;
-            osmt_ring ring = g_rings[op->ring_off];
-            while ((ring.n_pts < 2u || e >= ring.n_pts - 1u) && r + 1u < op->n_rings) {
-                if (ring.n_pts >= 2u) e -= ring.n_pts - 1u;
-                ring = g_rings[op->ring_off + ++r];
-            }
-            const int2 p1 = g_pts[ring.first_pt + e];
-            const int2 p2 = g_pts[ring.first_pt + e + 1];
-            sg.rec.p1x = p1.x; sg.rec.p1y = p1.y; sg.rec.p2x = p2.x; sg.rec.p2y = p2.y;
-            sg.rec.traveled = g_trav[g]; /* per virtual segment (k_opinfo) */
-            sg.rec.denom = g_den[g];
-            sg.rec.rdenom = g_rden[g];
-            cand_off = g_cand_off[g];
-        } else {
-            const osmt_cap_seg cs = g_aux[oi.aux].cap_seg[v - oi.n_edges];
-            valid = cs.valid != 0;
-            sg.rec.p1x = cs.p1x; sg.rec.p1y = cs.p1y; sg.rec.p2x = cs.p2x; sg.rec.p2y = cs.p2y;
-            sg.rec.denom = cs.denom;
-            sg.rec.rdenom = 1.0 / cs.denom;
-            sg.is_cap = 1u;
-            cand_off = cs.cand_off;
-        }
-        if (valid && !(sg.rec.p1x == sg.rec.p2x && sg.rec.p1y == sg.rec.p2y)) { /* line.rs:73-75 */
-            sg.ft = stroke_ft(g_aux[oi.aux].half_width);
+        sg.is_cap = vo >> 31;
+        sg.rec.p1x = pp.x; sg.rec.p1y = pp.y; sg.rec.p2x = pp.z; sg.rec.p2y = pp.w;
+        sg.rec.traveled = g_trav[g]; /* 0 for a cap stub */
+        sg.rec.denom = g_den[g];
+        sg.rec.rdenom = g_rden[g];
+        const uint32_t cand_off = g_cand_off[g];
+        if (!(sg.rec.p1x == sg.rec.p2x && sg.rec.p1y == sg.rec.p2y)) { /* line.rs:73-75; also how an invalid stub is stored */
+            const osmt_opinfo* __restrict__ oi = &g_info[o];
+            sg.ft = oi->stroke_ft;
+            const uint32_t rec_cap = oi->rec_cap, arena_off = oi->arena_off;
             const SubWindow w = vseg_window(sg.rec.p1x, sg.rec.p1y, sg.rec.p2x, sg.rec.p2y, sg.rec.denom, sg.ft, n_sub_x, n_sub_y);
             const uint32_t wc = window_count(w);
-            if (wc && (unsigned long long)cand_off + wc <= oi.rec_cap) { /* always: k_opinfo reserved this very window */
+            if (wc && (unsigned long long)cand_off + wc <= rec_cap) { /* always: k_opinfo reserved this very window */
                 sg.sx0 = w.sx0;
                 sg.sy0 = w.sy0;
                 sg.ncols = (uint32_t)(w.sx1 - w.sx0 + 1);
-                sg.slot0 = oi.arena_off + cand_off;
+                sg.slot0 = arena_off + cand_off;
                 sg.op = o;
                 sg.job = g_op_job[o];
                 sg._pad = 0u;
@@ -1398,10 +1379,9 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
 __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
-                                               const double* __restrict__ g_rden, const osmt_stroke_aux* __restrict__ g_aux,
-                                               const uint32_t* __restrict__ g_op_blk, const osmt_blk_bbox* __restrict__ g_blk,
-                                               const uint32_t* __restrict__ g_vseg_base, const uint32_t* __restrict__ g_vseg_blk_slot,
-                                               const uint32_t* __restrict__ g_stroke_op, uint32_t n_bin_slots, uint32_t n_vsegs, uint32_t n_vblk,
+                                               const double* __restrict__ g_rden, const int4* __restrict__ g_vpts,
+                                               const uint32_t* __restrict__ g_vop, const uint32_t* __restrict__ g_op_blk,
+                                               const osmt_blk_bbox* __restrict__ g_blk, uint32_t n_vsegs, uint32_t n_vblk,
                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
@@ -1418,9 +1398,8 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
     if (b >= n_vblk) return; /* ablation: no fill rows */
 #endif
     if (b < n_vblk)
-        stroke_bin_body(shu.bin, b, threadIdx.x, g_ops, g_info, g_rings, g_pts, g_trav, g_den, g_rden, g_aux,
-                        g_vseg_base, g_vseg_blk_slot, g_stroke_op, n_bin_slots, n_vsegs, scale, sub_rows, g_submask, g_cand_off, g_srec, g_skey,
-                        g_op_job, g_cnt);
+        stroke_bin_body(shu.bin, b, threadIdx.x, g_info, g_vpts, g_vop, g_trav, g_den, g_rden, n_vsegs, scale, sub_rows, g_submask, g_cand_off,
+                        g_srec, g_skey, g_op_job, g_cnt);
     else
         fill_rows_body(shu.fill, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
                        g_op_job, g_cnt);
@@ -2144,11 +2123,18 @@ hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, bool read_
 
 /* ---- launchers (C++ internal interface, see osmt_internal.h) ---------------- */
 hipError_t osmt_launch_project(const osmt_tile_job* jobs, const uint32_t* pt_job, const double* latlon, const uint32_t* refs,
-                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st) {
-    if (n_pts == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_project, dim3((n_pts + 255u) / 256u), dim3(256), 0, st, jobs, pt_job,
-                       reinterpret_cast<const double2*>(latlon), refs, n_pts, scale, reinterpret_cast<int2*>(pts));
+                               uint32_t n_pts, double scale, int32_t* pts, hipStream_t st, uint32_t* zero, size_t n_zero) {
+    const size_t n_thr = n_pts > n_zero ? n_pts : n_zero;
+    if (n_thr == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_project, dim3((uint32_t)((n_thr + 255u) / 256u)), dim3(256), 0, st, jobs, pt_job,
+                       reinterpret_cast<const double2*>(latlon), refs, n_pts, scale, reinterpret_cast<int2*>(pts), zero, (uint32_t)n_zero);
     return hipGetLastError();
+}
+
+size_t osmt_prepass_zero_words(const osmt_prepass_args& a) {
+    const uint32_t Wt = OSMT_TILE_SIZE * a.scale;
+    const size_t n_cnt = (a.fmask_cap || a.srec_cap) ? (size_t)a.n_jobs * (Wt / SUB) * (Wt / SUBH) : 0;
+    return 4 * sizeof(unsigned long long) / sizeof(uint32_t) + n_cnt;
 }
 
 hipError_t osmt_launch_ptjob(const osmt_tile_job* jobs, uint32_t n_jobs, uint32_t* pt_job, uint32_t n_pts, hipStream_t st) {
@@ -2167,18 +2153,18 @@ hipError_t osmt_launch_project_single(const double* latlon, uint32_t n, uint32_t
     return hipGetLastError();
 }
 
-hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st) {
-    /* the three cursors and, right behind them, the per-sub-tile list counts */
-    const uint32_t Wt = OSMT_TILE_SIZE * a.scale;
-    const size_t n_cnt = (a.fmask_cap || a.srec_cap) ? (size_t)a.n_jobs * (Wt / SUB) * (Wt / SUBH) : 0;
-    hipError_t e = hipMemsetAsync(a.cursors, 0, 4 * sizeof(unsigned long long) + n_cnt * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
+hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool zeroed) {
+    /* the three cursors and, right behind them, the per-sub-tile list counts (zeroed: k_project of this step has done it) */
+    if (!zeroed) {
+        const hipError_t e = hipMemsetAsync(a.cursors, 0, osmt_prepass_zero_words(a) * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
     if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + OPINFO_THREADS - 1u) / OPINFO_THREADS), dim3(OPINFO_THREADS), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
     if (a.n_ops)
         hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
-                           a.trav, a.den, a.rden, a.aux, a.op_blk, a.blk, a.vseg_base, a.vseg_blk_slot, a.stroke_op, a.n_strokes, a.n_vsegs, n_vblk,
+                           a.trav, a.den, a.rden, a.vpts, a.vop, a.op_blk, a.blk, a.n_vsegs, n_vblk,
                            a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
     if (a.n_jobs) /* also without a single op: k_raster reads the (empty) list headers */
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,

@@ -245,6 +245,19 @@ class TileBuilder:
             ring_off=off,
         )
 
+    def stroke_again(self, width, color, opacity=1.0, dashes=None, cap=abi.CAP_NONE, use_caps_for_dashes=False):
+        """A second draw_lines call over the rings of the PREVIOUS op (a casing and its stroke are drawn from one way's
+        points, drawer.rs:163-216): the two ops share their rings in the pools."""
+        prev = self._ops[-1]
+        off, n = int(prev["ring_off"]), int(prev["n_rings"])
+        d_off = len(self._dashes)
+        nd = 0
+        if dashes is not None:
+            self._dashes.extend(float(d) for d in dashes)
+            nd = len(dashes)
+        self._op(kind=abi.OP_STROKE, cap=cap, use_caps_for_dashes=int(bool(use_caps_for_dashes)), has_dashes=int(dashes is not None), color=color,
+                 opacity=opacity, width=width, n_dashes=nd, dashes_off=d_off, n_rings=n, ring_off=off)
+
     def nop(self):
         """An area whose style draws nothing still bumps the generation (drawer.rs:218)."""
         self._op(kind=abi.OP_NONE)

@@ -22,6 +22,7 @@ EXPORTS = [
     "osmt_scene_read_points", "osmt_project", "osmt_composite", "osmt_composite_device", "osmt_png_bound",
     "osmt_encode_png", "osmt_render_batch_labels", "osmt_render_batch_rgb", "osmt_scene_set_labels", "osmt_scene_read_label_status",
     "osmt_scene_check", "osmt_worker_create", "osmt_worker_destroy", "osmt_worker_render",
+    "osmt_render_batch_png_begin", "osmt_render_batch_png_end",
     "osmt_host_alloc", "osmt_host_free", "osmt_png_device_bound", "osmt_encode_png_device", "osmt_render_batch_png",
     "osmt_validate_batch", "osmt_batch_shard_create", "osmt_batch_shard_get", "osmt_batch_shard_free", "osmt_render_batch_multi",
     "osmt_render_batch_multi_ex",
@@ -93,6 +94,9 @@ def load():
         L.osmt_worker_destroy.argtypes = [vp]
         L.osmt_worker_destroy.restype = None
         L.osmt_worker_render.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), u8p, C.c_size_t]
+    if hasattr(L, "osmt_render_batch_png_begin"):
+        L.osmt_render_batch_png_begin.argtypes = [vp, C.POINTER(abi.Batch), C.POINTER(abi.LabelBatch), C.POINTER(vp)]
+        L.osmt_render_batch_png_end.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.osmt_png_device_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.osmt_png_device_bound.restype = C.c_size_t
     L.osmt_encode_png_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]

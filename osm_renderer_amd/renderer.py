@@ -247,6 +247,23 @@ class Context:
             return out, off
         return [out[int(off[i]) : int(off[i + 1])].tobytes() for i in range(dl.n_jobs)]
 
+    def png_begin(self, dl: DisplayList, labels=None):
+        """osmt_render_batch_png_begin: queues the whole batch, returns a job (keeps `dl` / `labels` alive until png_end)."""
+        b = dl.as_batch()
+        lb = labels.as_batch() if labels is not None else None
+        h = C.c_void_p()
+        check(load().osmt_render_batch_png_begin(self._h, C.byref(b), C.byref(lb) if lb is not None else None, C.byref(h)))
+        return (h, dl, labels, b, lb)
+
+    def png_end(self, job, out, as_bytes=False):
+        """osmt_render_batch_png_end: (out, offsets) — or the list of files with as_bytes=True."""
+        h, dl = job[0], job[1]
+        off = np.zeros(dl.n_jobs + 1, dtype=np.uint64)
+        check(load().osmt_render_batch_png_end(h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size, off.ctypes.data_as(C.POINTER(C.c_uint64))))
+        if not as_bytes:
+            return out, off
+        return [out[int(off[i]) : int(off[i + 1])].tobytes() for i in range(dl.n_jobs)]
+
     def hbm_copy_probe(self, nbytes=1 << 30, iters=20):
         """osmt_hbm_copy_probe: (copy GB/s counting read + write, read-only GB/s) of a 16-byte-per-lane device stream."""
         cp, rd = C.c_double(0.0), C.c_double(0.0)

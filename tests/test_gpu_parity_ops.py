@@ -332,3 +332,40 @@ def test_two_stroke_ops_share_one_ring(gpu_ctx, oracle):
     dl.ops["n_rings"][2] = 2  # op 2 = rings 0 and 1 in one draw_lines call: traveled runs on across the rings
     dl.ops["ring_off"][2] = 0
     assert_parity(gpu_ctx, oracle, dl, msg="shared rings, multi-ring op")
+
+
+@pytest.mark.parametrize("n_ops", [7, 8, 9, 31, 32, 33, 63, 64, 65, 97])
+def test_list_lengths_around_every_chunk_and_stage_boundary(gpu_ctx, oracle, n_ops):
+    """k_raster stages a sub-tile's list OPCHUNK = 32 entries at a time and keeps the coverage words / calculator constants
+    of the first STAGECAP = 8 fills / strokes of a chunk in LDS (the others read the arena: scalar loads for a fill's
+    words); the stroke slots of consecutive entries share a filter pass while they fit SEGCAP = 32 lanes.  Lists of
+    exactly, one fewer and one more than each of these lengths, all landing in ONE sub-tile, kinds interleaved in three
+    patterns (fills first, strokes first, alternating), image fills among the unstaged ones."""
+    rnd = np.random.default_rng(100 + n_ops)
+    icon = rnd.integers(0, 256, size=(7, 5, 4)).astype(np.uint8)
+    icon[:3, :, 3] = 255
+    img_id = gpu_ctx.register_image(icon)
+    images = [np.zeros((1, 1, 4), dtype=np.uint8)] * img_id + [icon]
+    tiles = []
+    for pattern in range(3):
+        tb = TileBuilder(x=pattern, canvas=(250, 248, 240))
+        for i in range(n_ops):
+            is_fill = (i < n_ops // 2) if pattern == 0 else (i >= n_ops // 2) if pattern == 1 else (i % 2 == 0)
+            col = tuple(int(v) for v in rnd.integers(0, 256, size=3))
+            # everything inside the sub-tile at (64..95, 32..47) and a little around it
+            cx, cy = int(rnd.integers(60, 100)), int(rnd.integers(28, 52))
+            if is_fill:
+                r = int(rnd.integers(3, 12))
+                ring = [(cx - r, cy - r), (cx + r, cy - r // 2), (cx + r // 2, cy + r), (cx - r, cy + r // 3), (cx - r, cy - r)]
+                if i % 7 == 3:
+                    tb.fill_image([ring], img_id)
+                else:
+                    tb.fill([ring], col, float(rnd.choice([1.0, 0.5, 0.25])))
+            else:
+                pts = [(cx, cy), (cx + int(rnd.integers(-14, 15)), cy + int(rnd.integers(-10, 11))), (cx + int(rnd.integers(-20, 21)), cy + 3)]
+                tb.stroke(pts, float(rnd.choice([0.5, 1.0, 2.0, 3.5])), col, float(rnd.choice([1.0, 0.6])),
+                          dashes=[3.0, 2.0] if i % 5 == 0 else None, cap=[abi.CAP_NONE, abi.CAP_ROUND, abi.CAP_SQUARE, abi.CAP_BUTT][i % 4])
+        tiles.append(tb.build())
+    from osm_renderer_amd.display_list import concat
+
+    assert_parity(gpu_ctx, oracle, concat(tiles), images=images, msg=f"{n_ops} ops in one sub-tile")

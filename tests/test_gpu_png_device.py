@@ -106,3 +106,32 @@ def test_png_fuzz_against_model(gpu_ctx):
             png = slots[i, : lens[i]].tobytes()
             assert png == _png_model.encode(imgs[i]), f"W={W} image {i}: bytes differ from the model"
             assert np.array_equal(_decode(png), imgs[i, :, :, :3])
+
+
+def test_png_begin_end_pipelined_equals_the_one_piece_call(gpu_ctx, oracle):
+    """osmt_render_batch_png_begin / _end: two jobs in flight from one thread (batch k + 1 begun before batch k is ended),
+    different batches, one of them split into chunks; every file equals the one the one-piece call writes and decodes to
+    the oracle's pixels.  A job whose second half gets a too small buffer reports the size and is released."""
+    from osm_renderer_amd.lib import OsmtError
+
+    lists = [synth.make_tiles(synth.config_tiles(n, x0=19000 + 11 * k, y0=10020 + k), n_poly=12, n_line=10) for k, n in enumerate((3, 1100, 7, 2))]
+    want = [gpu_ctx.render_batch_png(dl) for dl in lists]
+    bufs = [np.empty(dl.n_jobs * 96 * 1024, dtype=np.uint8) for dl in lists]
+    got = [None] * len(lists)
+    prev = gpu_ctx.png_begin(lists[0])
+    for k in range(1, len(lists)):
+        cur = gpu_ctx.png_begin(lists[k])
+        got[k - 1] = gpu_ctx.png_end(prev, bufs[k - 1], as_bytes=True)
+        prev = cur
+    got[-1] = gpu_ctx.png_end(prev, bufs[-1], as_bytes=True)
+    for k, dl in enumerate(lists):
+        assert got[k] == want[k], f"batch {k}"
+    ref = oracle.render_batch(lists[2], threads=4)
+    for i in range(lists[2].n_jobs):
+        assert np.array_equal(_decode(got[2][i]), ref[i][..., :3])
+    job = gpu_ctx.png_begin(lists[0])
+    with pytest.raises(OsmtError) as e:
+        gpu_ctx.png_end(job, np.empty(100, dtype=np.uint8))
+    assert "out_capacity" in str(e.value)
+    # the context is still usable and nothing of the failed job lingers
+    assert gpu_ctx.render_batch_png(lists[3]) == want[3]

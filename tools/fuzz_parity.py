@@ -33,7 +33,7 @@ def rand_pts(n, W, spread):
     return (p0 + np.cumsum(steps, axis=0)).tolist()
 
 
-def make_tile(scale):
+def make_tile(scale, image_ids=()):
     W = 256 * scale
     tb = TileBuilder(scale=scale, canvas=None if rnd.random() < 0.2 else tuple(rnd.integers(0, 256, size=3)))
     for _ in range(int(rnd.integers(1, 40))):
@@ -45,7 +45,10 @@ def make_tile(scale):
             for r in rings:
                 if rnd.random() < 0.8:
                     r.append(r[0])
-            tb.fill(rings, col, op)
+            if image_ids and rnd.random() < 0.15:  # Filler::Image; sometimes an id nobody registered (draws nothing)
+                tb.fill_image(rings, int(rnd.choice(image_ids)) if rnd.random() < 0.9 else 99999, op)
+            else:
+                tb.fill(rings, col, op)
         elif kind < 0.45:
             tb.nop()
         else:
@@ -56,6 +59,9 @@ def make_tile(scale):
             w = float(rnd.choice([0.0, 0.05, 0.2, 0.5, 0.99, 1.0, 1.01, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 12.5, 25.0, 40.0, -3.0, 1.3, 2e-101, 0.7])) * scale
             tb.stroke(rand_pts(int(rnd.integers(2, 9)), W, int(rnd.choice([3, 30, 90, 300]))), w, col, op, dashes=d,
                       cap=CAPS[int(rnd.integers(0, 4))], use_caps_for_dashes=bool(rnd.integers(0, 2)))
+            if rnd.random() < 0.2:  # a second stroke op over the SAME rings (casing + stroke of one way share their points)
+                tb.stroke_again(max(0.0, abs(w) - float(rnd.choice([0.5, 1.0, 2.0]))), tuple(rnd.integers(0, 256, size=3)), op,
+                                dashes=d if rnd.random() < 0.5 else None, cap=CAPS[int(rnd.integers(0, 4))])
     return tb.build()
 
 
@@ -122,7 +128,7 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
     rnd = np.random.default_rng(seed)
     ctx = ctx or Context(0)
     images, image_ids, sizes = [], [], ((16, 16), (9, 9), (5, 23))
-    if with_labels:
+    if True:  # icons for image fills (area runs) and label icons (label runs)
         arrays = []
         for h, w in sizes:
             img = rnd.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
@@ -136,7 +142,7 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
     n_tiles = n_bad = 0
     while time.time() - t0 < budget:
         scale = int(rnd.choice([1, 1, 2, 3]))
-        tiles = [make_tile(scale) for _ in range(12)]
+        tiles = [make_tile(scale, image_ids) for _ in range(12)]
         dl = display_list.concat(tiles)
         ll = make_labels(len(tiles), scale, image_ids, sizes) if with_labels else None
         if ll is not None:
@@ -150,7 +156,7 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
                 print(f"LABEL STATUS MISMATCH seed={seed} after {n_tiles} tiles: labels {np.nonzero(st != wst)[0][:8].tolist()}")
         else:
             got = ctx.render_batch_host(dl)
-            want = O.render_batch(dl, threads=12)
+            want = O.render_batch(dl, threads=12, images=images)
         n_tiles += len(tiles)
         if not np.array_equal(got, want):
             for i in range(len(tiles)):
