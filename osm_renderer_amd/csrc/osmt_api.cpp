@@ -109,6 +109,13 @@ struct osmt_ctx {
      * surfaces as OSMT_HIP_ERROR instead of blank tiles, and costs no copy and no extra wait. */
     uint32_t* err_page = nullptr;
     std::vector<uint16_t> err_free;
+    /* What the pre-pass arenas of recent big uploads needed per fill op / per virtual stroke segment, by scale: the next
+     * big upload of a host-buffer call takes its arenas from these densities (+ 25 %) instead of asking the device with a
+     * counting run of the pre-pass and a round trip; see scene_size_arenas (guarded by cache_mu). */
+    struct arena_density {
+        double groups_per_fill = 0.0, recs_per_vseg = 0.0;
+        uint32_t uploads = 0;
+    } density[OSMT_MAX_SCALE + 1];
     /* The gathering point of the per-request entry (osmt_worker_render): requests of concurrent worker threads wait here
      * and are rendered together, see the "coalescing worker" section. */
     std::mutex co_mu;
@@ -170,6 +177,7 @@ struct osmt_scene {
     std::vector<std::pair<hipStream_t, hipEvent_t>> last_use;
     void* h_stage = nullptr;          /* pinned staging of a packed upload, returned to the pool when the scene goes */
     uint32_t* h_err = nullptr;        /* the scene's word of osmt_ctx::err_page (NULL: none left, errors stay unreported) */
+    bool arena_guess = false;         /* the arenas were sized from osmt_ctx::density, not by the device: an overflow is a miss, not a bug */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
     char* d_lab_base = nullptr;
@@ -421,12 +429,21 @@ hipError_t copy_back(osmt_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 /* Host-buffer entry points: an internal error of the label coverage kernels (window overflow) must not return OSMT_OK
  * with wrong pixels.  Called after the call's work was enqueued on `st`; synchronises it. */
+/* set by prepass_error_check when the overflow it reports belongs to a scene with guessed arenas: the caller renders again
+ * with exact sizing instead of failing */
+thread_local bool g_arena_guess_missed = false;
+
 /* the pre-pass kernels' word: valid once the stream(s) the scene was rendered on have been synchronised */
 int prepass_error_check(osmt_scene* sc) {
     if (!sc->h_err) return OSMT_OK;
     const uint32_t code = *(volatile uint32_t*)sc->h_err;
     if (!code) return OSMT_OK;
     *(volatile uint32_t*)sc->h_err = 0u;
+    if (sc->arena_guess) {
+        g_arena_guess_missed = true;
+        std::lock_guard<std::mutex> lk(sc->ctx->cache_mu);
+        sc->ctx->density[sc->scale].uploads = 0; /* the next big upload measures again */
+    }
     return fail(OSMT_HIP_ERROR, "pre-pass arena overflow (internal error %u: %s arena)", code,
                 code == OSMT_PREPASS_ERR_FILL_ARENA ? "fill" : code == OSMT_PREPASS_ERR_STROKE_ARENA ? "stroke" : "list");
 }
@@ -805,14 +822,32 @@ int osmt_register_image(osmt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uin
  * sub-tile — without asking the device (a single-tile request must not pay a round trip); larger ones run the
  * projection and the sizing half of k_opinfo once, read the two totals back and allocate exactly.  Either way the
  * reservation logic of k_opinfo is the same code at render time, so the arenas cannot overflow. */
-static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
+static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool allow_guess) {
     const size_t W = (size_t)OSMT_TILE_SIZE * s->scale;
     const size_t nsub = (W / OSMT_SUB_W) * (W / OSMT_SUB_H);
     unsigned long long groups = (unsigned long long)n_fills * nsub, recs = (unsigned long long)s->n_vsegs * nsub;
     const unsigned long long worst_bytes = groups * 64ull + recs * (sizeof(osmt_srec) + 8ull) + ((unsigned long long)n_fills + s->n_strokes) * nsub * sizeof(osmt_ent);
     /* (taking the worst case up to 2 GB instead — 1.8 GB for 1024 config-2 tiles — was tried to save this sizing run,
      * 0.14 ms of a 0.84 ms upload: no gain on one thread, and four worker threads' arenas then outgrow the buffer cache) */
-    if (worst_bytes > ((unsigned long long)32 << 20)) {
+    bool guessed = false;
+    if (worst_bytes > ((unsigned long long)32 << 20) && allow_guess) {
+        /* A host-buffer call that follows others of its kind: the arenas from the densities the recent exact runs measured,
+         * a quarter on top.  The kernels reserve with the same code as ever; if the guess is too small for this batch they
+         * draw nothing for the ops that do not fit and say so in the scene's error word, and the call renders again with
+         * exact sizing (g_arena_guess_missed).  Every 64th upload measures again, so the densities follow the workload. */
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        osmt_ctx::arena_density& d = ctx->density[s->scale];
+        if (d.uploads != 0 && (d.uploads & 63u) != 0 && d.groups_per_fill > 0.0 && d.recs_per_vseg > 0.0) {
+            const unsigned long long g = (unsigned long long)(d.groups_per_fill * 1.25 * (double)n_fills) + 4096ull;
+            const unsigned long long r = (unsigned long long)(d.recs_per_vseg * 1.25 * (double)s->n_vsegs) + 4096ull;
+            groups = std::min(groups, g);
+            recs = std::min(recs, r);
+            guessed = true;
+            ++d.uploads;
+        }
+    }
+    s->arena_guess = guessed;
+    if (worst_bytes > ((unsigned long long)32 << 20) && !guessed) {
         hipStream_t st = s->own_stream;
         if (s->coord_kind != OSMT_COORD_POINT_I32)
             HIP_TRY(osmt_launch_project(s->d_jobs, s->d_pt_job, s->d_latlon, s->coord_kind == OSMT_COORD_NODE_REF ? s->d_node_refs : nullptr,
@@ -823,6 +858,13 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
         HIP_TRY(hipStreamSynchronize(st));
         groups = totals[0];
         recs = totals[1];
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        osmt_ctx::arena_density& d = ctx->density[s->scale];
+        if (n_fills) d.groups_per_fill = std::max(d.groups_per_fill * 0.98, (double)groups / (double)n_fills);
+        if (s->n_vsegs) d.recs_per_vseg = std::max(d.recs_per_vseg * 0.98, (double)recs / (double)s->n_vsegs);
+        if (d.groups_per_fill <= 0.0) d.groups_per_fill = 1e-9; /* a workload without fills (or strokes) still counts as measured */
+        if (d.recs_per_vseg <= 0.0) d.recs_per_vseg = 1e-9;
+        ++d.uploads;
     }
     if (groups >= 0xFFFFFFFFull || recs >= 0xFFFFFFFFull)
         return fail(OSMT_UNSUPPORTED, "scene needs %llu fill groups / %llu stroke records (> 2^32): split the batch", groups, recs);
@@ -858,7 +900,8 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills) {
 /* st == nullptr: blocking copies (the public osmt_scene_upload); otherwise stream-ordered on `st`, the caller
  * synchronises the stream before the batch's host arrays go away */
 /* trusted: the batch was built by the library itself from a batch it has already validated (the shards of osmt_render_batch_multi) */
-static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st, bool trusted = false) {
+static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** out_scene, hipStream_t st, bool trusted = false,
+                             bool allow_guess = false) {
     if (!ctx || !out_scene) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out_scene = nullptr;
     /* Big uploads: the O(n_pts) coordinate scan runs on helper threads while this one builds the index tables and feeds
@@ -1090,7 +1133,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         mark(3);
         rc = cc.join(); /* no kernel has seen the coordinates yet */
         mark(4);
-        if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
+        if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills, allow_guess);
         mark(5);
         report();
         if (rc != OSMT_OK) {
@@ -1122,7 +1165,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     mark(3);
     rc = cc.join(); /* no kernel has seen the coordinates yet */
     mark(4);
-    if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills);
+    if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills, allow_guess);
     mark(5);
     report();
     if (rc != OSMT_OK) {
@@ -1448,14 +1491,29 @@ int osmt_render_batch(osmt_ctx* ctx, const osmt_batch* batch, uint8_t* out_rgba,
     return osmt_render_batch_labels(ctx, batch, nullptr, out_rgba, stride);
 }
 
+static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba, size_t stride,
+                                         bool rgb, bool trusted, bool allow_guess);
+
+/* the host-buffer render: arenas guessed from the recent densities first; a miss renders again with exact sizing */
 static int osmt_render_batch_labels_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba,
-                             size_t stride, bool rgb = false, bool trusted = false) {
+                                         size_t stride, bool rgb = false, bool trusted = false) {
+    g_arena_guess_missed = false;
+    int rc = osmt_render_batch_labels_once(ctx, batch, labels, out_rgba, stride, rgb, trusted, true);
+    if (rc != OSMT_OK && g_arena_guess_missed) {
+        g_arena_guess_missed = false;
+        rc = osmt_render_batch_labels_once(ctx, batch, labels, out_rgba, stride, rgb, true, false); /* validated the first time */
+    }
+    return rc;
+}
+
+static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, uint8_t* out_rgba, size_t stride,
+                                         bool rgb, bool trusted, bool allow_guess) {
     if (!ctx || !out_rgba) return fail(OSMT_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = nullptr; /* the whole call lives on its own stream: concurrent callers overlap on the GPU */
     HIP_TRY(stream_acquire(ctx, &st));
     osmt_scene* sc = nullptr;
-    int rc = scene_upload_impl(ctx, batch, &sc, st, trusted);
+    int rc = scene_upload_impl(ctx, batch, &sc, st, trusted, allow_guess);
     if (rc != OSMT_OK) {
         stream_release(ctx, st);
         return rc;
@@ -1650,6 +1708,8 @@ struct osmt_png_job {
     size_t slot = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0;
     int rc = OSMT_OK; /* a failure of the first half, reported by the second */
     std::string err;
+    const osmt_batch* batch = nullptr; /* the caller's arrays (valid until _end returns): a missed arena guess renders them again */
+    const osmt_label_batch* labels = nullptr;
 };
 
 static void png_job_release(osmt_png_job* j) {
@@ -1667,7 +1727,7 @@ static void png_job_release(osmt_png_job* j) {
 
 /* First half.  The pre-pass runs once for the whole batch; then the tiles go through raster -> PNG encode -> file lengths
  * in CHUNKS on the job's stream, all enqueued here; nothing is waited for. */
-static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, osmt_png_job** out_job) {
+static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_label_batch* labels, osmt_png_job** out_job, bool allow_guess = true) {
     if (!ctx || !out_job) return fail(OSMT_INVALID_ARG, "NULL argument");
     *out_job = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1679,7 +1739,9 @@ static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
         delete j;
         return fail(OSMT_HIP_ERROR, "stream: %s", hipGetErrorString(e));
     }
-    int rc = scene_upload_impl(ctx, batch, &j->sc, j->st);
+    j->batch = batch;
+    j->labels = labels;
+    int rc = scene_upload_impl(ctx, batch, &j->sc, j->st, false, allow_guess);
     if (rc == OSMT_OK && labels) rc = osmt_scene_set_labels(ctx, j->sc, labels);
     const uint32_t n = j->n = batch ? (uint32_t)batch->n_jobs : 0u;
     if (rc == OSMT_OK && n) {
@@ -1804,9 +1866,20 @@ static int png_end_body(osmt_png_job* j, uint8_t* out_png, size_t out_capacity, 
         if (rc == OSMT_OK && !fits) rc = fail(OSMT_INVALID_ARG, "out_capacity %zu < %llu bytes of PNG data", out_capacity, offs[n]);
     }
     for (uint32_t i = 0; i <= n; ++i) out_off[i] = offs[i];
+    g_arena_guess_missed = false;
     if (rc == OSMT_OK) rc = label_error_check(j->sc, j->st);
     const std::string msg = rc != OSMT_OK ? std::string(osmt_last_error()) : std::string();
+    const bool missed = rc != OSMT_OK && g_arena_guess_missed;
+    const osmt_batch* batch = j->batch;
+    const osmt_label_batch* labels = j->labels;
     png_job_release(j);
+    if (missed) { /* the guessed arenas were too small for this batch: the whole job again with exact sizing */
+        g_arena_guess_missed = false;
+        osmt_png_job* again = nullptr;
+        rc = png_begin_body(ctx, batch, labels, &again, false);
+        if (rc != OSMT_OK) return rc;
+        return png_end_body(again, out_png, out_capacity, out_off);
+    }
     return rc != OSMT_OK ? fail(rc, "%s", msg.c_str()) : OSMT_OK;
 }
 
@@ -2430,7 +2503,7 @@ constexpr size_t CO_MAX_TILES = 64;
 int co_max_in_flight() {
     static const int v = [] {
         const char* e = getenv("OSMT_WORKER_INFLIGHT");
-        return e ? std::min(std::max(atoi(e), 1), 16) : 2;
+        return e ? std::min(std::max(atoi(e), 1), 16) : 3; /* 16 native threads: 36 k tiles/s with 1, 33-45 k with 2, 46 k with 3, 24-35 k with 4 and 8 */
     }();
     return v;
 }
@@ -2560,10 +2633,15 @@ void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
     for (const coalesce_req* r : reqs) n_tiles += r->b->n_jobs;
     int rc = OSMT_OK;
     void* stage = nullptr;
+    /* OSMT_TRACE_WORKER=1 (diagnostic): one stderr line per gathered group — requests, tiles, merge and render time */
+    static const bool trace_worker = getenv("OSMT_TRACE_WORKER") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto t1 = t0;
     try {
         merged_batch m;
         merge_requests(reqs, &m);
         stage = stage_acquire(ctx, n_tiles * tile_rgb);
+        t1 = std::chrono::steady_clock::now();
         if (!stage) {
             rc = OSMT_OOM;
         } else {
@@ -2571,6 +2649,11 @@ void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
         }
     } catch (...) {
         rc = OSMT_OOM;
+    }
+    if (trace_worker) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "osmt worker group: %zu requests, %zu tiles, merge+staging %.0f us, render %.0f us, rc %d\n", reqs.size(), n_tiles,
+                std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), rc);
     }
     if (rc != OSMT_OK) {
         /* whatever went wrong (one request's labels refused, no pinned memory): every request on its own, so that a bad

@@ -289,3 +289,44 @@ def test_big_upload_checks_coordinates_on_its_helper_threads(gpu_ctx, oracle):
             gpu_ctx.render_batch_host(bad)
     again = gpu_ctx.render_batch_host(dl)  # the context is fine afterwards
     np.testing.assert_array_equal(again, good)
+
+
+def test_guessed_arenas_that_turn_out_too_small_are_rendered_again(oracle):
+    """Big host-buffer uploads take their pre-pass arenas from the densities recent uploads measured (+ 25 %) instead of a
+    counting run and a round trip.  A batch that needs far more than the guess — same op counts, ten times the geometry —
+    must come back right all the same: the kernels report the overflow in the scene's error word and the call renders
+    again with exact sizing."""
+    import numpy as np
+
+    from osm_renderer_amd import synth
+    from osm_renderer_amd.renderer import Context
+
+    ctx = Context(0)  # its own density history
+    try:
+        small = synth.make_tiles(synth.config_tiles(96, x0=20000, y0=11000), radius=(1.0, 3.0), step=3.0)
+        big = synth.make_tiles(synth.config_tiles(96, x0=20000, y0=11000))
+        ctx.render_batch_host(small)  # measures: small densities
+        got_small = ctx.render_batch_host(small)  # guessed, fits
+        got_big = ctx.render_batch_host(big)  # guessed from the small batches: misses, rendered again
+        got_big2 = ctx.render_batch_host(big)  # measured again after the miss
+        scene = ctx.upload(big)  # public scenes are always sized exactly
+        want_big = ctx.render(scene).cpu().numpy()
+        scene.free()
+        assert np.array_equal(got_big, want_big) and np.array_equal(got_big2, want_big)
+        pick = [0, 17, 95]
+        assert np.array_equal(want_big[pick], oracle.render_batch(big.subset(pick), threads=3))
+        assert np.array_equal(got_small[pick], oracle.render_batch(small.subset(pick), threads=3))
+    finally:
+        ctx.close()
+    ctx = Context(0)  # the PNG pipeline guesses too, and recovers from a miss the same way (in its second half)
+    try:
+        from tests.test_gpu_png_device import _decode
+
+        ctx.render_batch_png(small)  # measures
+        files = ctx.render_batch_png(small)  # guessed, fits
+        files_big = ctx.render_batch_png(big)  # guessed from the small batches: misses, the job runs again
+        assert np.array_equal(_decode(files_big[17]), want_big[17][..., :3])
+        assert np.array_equal(_decode(files_big[95]), want_big[95][..., :3])
+        assert np.array_equal(_decode(files[17]), got_small[17][..., :3])
+    finally:
+        ctx.close()
