@@ -2621,7 +2621,10 @@ int label_batch_shape_ok(const osmt_batch* b, const osmt_label_batch* lb) {
 /* renders the requests of one group; fills rc / err / grp / src of every request (the caller marks them done) */
 void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
     auto run_alone = [&](coalesce_req* r) {
-        r->rc = osmt_render_batch_rgb(ctx, r->b, (r->lb && r->lb->n_labels) ? r->lb : nullptr, r->out, r->stride);
+        /* its requester has validated it: trusted, like the merged batch (no second pass over the ops and points) */
+        r->rc = guarded([&] {
+            return osmt_render_batch_labels_body(ctx, r->b, (r->lb && r->lb->n_labels) ? r->lb : nullptr, r->out, r->stride, true, true);
+        });
         if (r->rc != OSMT_OK) r->err = osmt_last_error();
     };
     if (reqs.size() == 1) {
