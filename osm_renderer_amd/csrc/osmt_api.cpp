@@ -1701,11 +1701,12 @@ struct osmt_png_job {
     osmt_ctx* ctx = nullptr;
     hipStream_t st = nullptr, s_c = nullptr; /* the job's own stream; the compaction / read-back stream (more than one chunk) */
     osmt_scene* sc = nullptr;
-    char* d = nullptr;         /* framebuffers of two chunks, PNG slots, lengths, offsets, compacted blob */
+    char* d = nullptr;         /* framebuffers of two chunks, PNG slots, lengths, offsets */
+    char* d_blob = nullptr;    /* compacted files, ONLY when a chunk's dead framebuffers cannot take them (see png_end_body) */
     uint32_t* h_len = nullptr; /* pinned: lengths come back asynchronously, offsets go out */
     std::vector<hipEvent_t> ev;
     uint32_t n = 0, W = 0, chunk = 0, n_chunks = 0;
-    size_t slot = 0, o_png = 0, o_len = 0, o_off = 0, o_blob = 0;
+    size_t slot = 0, tile_bytes = 0, o_rgba = 0, o_png = 0, o_len = 0, o_off = 0;
     int rc = OSMT_OK; /* a failure of the first half, reported by the second */
     std::string err;
     const osmt_batch* batch = nullptr; /* the caller's arrays (valid until _end returns): a missed arena guess renders them again */
@@ -1719,6 +1720,7 @@ static void png_job_release(osmt_png_job* j) {
         if (v) (void)hipEventDestroy(v);
     if (j->sc) osmt_scene_free(j->sc); /* waits for the job's stream */
     dev_free(ctx, j->d);
+    dev_free(ctx, j->d_blob);
     if (j->h_len) stage_release(ctx, j->h_len);
     if (j->s_c) stream_release(ctx, j->s_c);
     if (j->st) stream_release(ctx, j->st);
@@ -1768,11 +1770,11 @@ static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
             off = align_up(off + bytes, 256);
             return o;
         };
-        const size_t o_rgba = carve((size_t)std::min<uint32_t>(2u, n_chunks) * chunk * tile_bytes); /* two chunks of framebuffers, alternating */
+        const size_t o_rgba = j->o_rgba = carve((size_t)std::min<uint32_t>(2u, n_chunks) * chunk * tile_bytes); /* two chunks of framebuffers, alternating */
+        j->tile_bytes = tile_bytes;
         j->o_png = carve((size_t)n * slot);
         j->o_len = carve((size_t)n * 4);
         j->o_off = carve((size_t)n * 8);
-        j->o_blob = carve((size_t)n * slot);
         e = dev_alloc(ctx, (void**)&j->d, off);
         if (e != hipSuccess) rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
         if (rc == OSMT_OK) {
@@ -1849,7 +1851,21 @@ static int png_end_body(osmt_png_job* j, uint8_t* out_png, size_t out_capacity, 
             const size_t c_bytes = (size_t)(offs[first + cnt] - offs[first]);
             if (offs[first + cnt] > out_capacity) fits = false; /* keep summing: the caller learns the size it needs */
             if (!fits || c_bytes == 0) continue;
-            char* blob = d + j->o_blob + (size_t)first * slot;
+            /* The compacted files of a chunk go where its framebuffers were: they are dead once the chunk is encoded (the
+             * event above), each chunk has its own as long as there are at most two, and map tiles compress to a fifth of
+             * them.  Only files that would not fit (noise: the slot bound is 12 bits per byte) or a forced chunk count above
+             * two (framebuffers re-used by chunk c + 2) get a buffer of their own. */
+            char* blob = d + j->o_rgba + (size_t)(c & 1u) * chunk * j->tile_bytes;
+            if (j->n_chunks > 2u || c_bytes > (size_t)cnt * j->tile_bytes) {
+                if (!j->d_blob) {
+                    e = dev_alloc(ctx, (void**)&j->d_blob, (size_t)n * slot);
+                    if (e != hipSuccess) {
+                        rc = fail(OSMT_OOM, "hipMalloc(%zu) failed: %s", (size_t)n * slot, hipGetErrorString(e));
+                        break;
+                    }
+                }
+                blob = j->d_blob + (size_t)first * slot;
+            }
             e = hipMemcpyAsync(d + j->o_off + (size_t)first * 8, h_off + first, (size_t)cnt * 8, hipMemcpyHostToDevice, s_copy);
             if (e == hipSuccess)
                 e = osmt_launch_png_compact(d + j->o_png + (size_t)first * slot, slot, (const uint32_t*)(d + j->o_len) + first,

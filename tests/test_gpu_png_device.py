@@ -135,3 +135,27 @@ def test_png_begin_end_pipelined_equals_the_one_piece_call(gpu_ctx, oracle):
     assert "out_capacity" in str(e.value)
     # the context is still usable and nothing of the failed job lingers
     assert gpu_ctx.render_batch_png(lists[3]) == want[3]
+
+
+def test_compacted_files_in_dead_framebuffers_or_in_a_buffer_of_their_own(gpu_ctx):
+    """A chunk's files are compacted into that chunk's framebuffers (dead once encoded); with more than two chunks the
+    framebuffers are re-used, and the job takes a separate buffer (forced here with the diagnostic OSMT_PNG_CHUNKS, which
+    is read once per process: a child).  Same files either way."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dl = synth.make_tiles(synth.config_tiles(9, x0=19040, y0=10033), n_poly=14, n_line=12)
+    want = hashlib.sha256(b"".join(gpu_ctx.render_batch_png(dl))).hexdigest()
+    child = (
+        "import hashlib, sys; sys.path.insert(0, %r)\n"
+        "from osm_renderer_amd import synth\n"
+        "from osm_renderer_amd.renderer import Context\n"
+        "dl = synth.make_tiles(synth.config_tiles(9, x0=19040, y0=10033), n_poly=14, n_line=12)\n"
+        "print(hashlib.sha256(b''.join(Context(0).render_batch_png(dl))).hexdigest())\n" % root
+    )
+    out = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, OSMT_PNG_CHUNKS="4"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == want
