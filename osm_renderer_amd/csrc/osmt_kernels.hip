@@ -526,6 +526,7 @@ struct alignas(8) SegDer {
 static_assert(sizeof(SegDer) == 40, "five 8-byte LDS words");
 constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_CAP = 8u, SEGW_SLOW = 16u;
 
+constexpr uint32_t FILTCAP = 256; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
 struct RasterShared {
     OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [5] fill visits */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
@@ -535,13 +536,13 @@ struct RasterShared {
     StagedEnt ent[OPCHUNK];         /* ops of the chunk that draw into this sub-tile, in order */
     uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
     StrokeConst sconst[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
-    uint32_t farena[STAGECAP];      /* first coverage word of the staged fills */
-    uint8_t mark[64];               /* filter pass: mark[s] = chunk index of the stroke entry whose slots start at lane s */
 #ifdef OSMT_V_LDSPAD
     uint8_t occupancy_experiment_pad[OSMT_V_LDSPAD];
 #endif
 };
 static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
+static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP == 256u,
+              "the filter pass borrows seg[] for its entry marks (one 4-byte store per lane) and der[] for the kept slots");
 
 struct SubRect {
     int32_t x0, y0, x1, y1; /* inclusive */
@@ -1662,7 +1663,17 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             se.aux = e.aux;
             se.nv = e.nv;
             sh.ent[lane] = se;
-            if (!is_stroke && my_stage < (uint32_t)STAGECAP) sh.farena[my_stage] = e.arena;
+            if (!is_stroke && my_stage < (uint32_t)STAGECAP) {
+                /* the fill's 16 coverage words (one 64-byte line), requested by the lane that staged the entry — beside the
+                 * strokes' constants, not a round trip behind them */
+                const uint4* OSMT_R src = reinterpret_cast<const uint4*>(g_fmask + e.arena);
+                uint4* dst = reinterpret_cast<uint4*>(&sh.fmask[my_stage][0]);
+                const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                dst[0] = w0;
+                dst[1] = w1;
+                dst[2] = w2;
+                dst[3] = w3;
+            }
             if (is_stroke && my_stage < (uint32_t)STAGECAP) {
                 /* constants of the across test (second round trip, in parallel for all strokes of the chunk) */
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[e.aux];
@@ -1686,15 +1697,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             plane_clean = true;
         }
         __syncthreads();
-        {
-            /* coverage words of the chunk's fills: lane -> (staged fill, row), all in flight together */
-            const uint32_t n_fill_staged = min((uint32_t)__popcll(fbal), (uint32_t)STAGECAP);
-            for (uint32_t i = fresh_lane(); i < n_fill_staged * SUBH; i += NTHREADS) {
-                const uint32_t f = i / SUBH, row = i % SUBH;
-                sh.fmask[f][row] = g_fmask[(size_t)sh.farena[f] + row];
-            }
-        }
-        __syncthreads();
 
         uint32_t g0 = 0;
         while (g0 < total) {
@@ -1702,31 +1704,129 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
          * more slots forms a group of its own and is filtered SEGCAP slots at a time ---- */
         uint32_t gend = total, V = 0;
         bool big = false;
-        unsigned long long starts = 0ull; /* bit s: the slots of a stroke entry of the group start at lane s of the filter pass */
         uint32_t s_before = 0u;           /* slots of the chunk's entries in front of the group */
         if (any_stroke) {
             s_before = g0 ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)g0 - 1) : 0u;
-            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)SEGCAP);
+            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)FILTCAP);
             if (over) gend = (uint32_t)__builtin_ctzll(over);
-            if (gend == g0) { /* the first entry alone does not fit */
+            if (gend == g0) { /* the first entry alone has more slots than one filter pass looks at */
                 big = true;
                 gend = g0 + 1u;
             } else {
                 V = (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)gend - 1) - s_before;
-                const uint32_t t_ = fresh_lane();
-                sh.mark[t_] = 0xFFu;
-                __syncthreads();
-                {
-                    /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
-                    const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
-                    if (t_ >= g0 && t_ < gend && nv_incl != excl) sh.mark[excl - s_before] = (uint8_t)t_;
-                }
-                __syncthreads();
-                starts = __ballot(sh.mark[t_] != 0xFFu);
             }
         }
-        unsigned long long gbal = 0ull; /* lanes of the filter pass holding a record of this sub-tile */
-        bool records_ready = false;
+        if (V) {
+            /* ---- filter pass of the GROUP: every slot of every stroke entry of the group is looked at once, FILTCAP slots
+             * (four rounds of 64 lanes, all key loads in flight together); the records of THIS sub-tile are compacted in
+             * slot order (= op order, segment order).  Round 3 looked at SEGCAP slots per pass: an op of 90 slots — five
+             * edges and two stubs with windows of a dozen sub-tiles — took three passes (key -> record -> barrier each)
+             * and walked the two or three records it kept in up to three under-filled walks. ---- */
+            uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.seg);   /* mark[s]: list entry whose slots start at virtual slot s */
+            uint32_t* const tmp = reinterpret_cast<uint32_t*>(sh.der);  /* [c]: arena slot of kept record c, [SEGCAP + c]: its item count | cap flag */
+            const uint32_t t_ = fresh_lane();
+            reinterpret_cast<uint32_t*>(mark)[t_] = 0xFFFFFFFFu; /* FILTCAP = 256 bytes */
+            __syncthreads();
+            /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
+            const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
+            const bool mine = t_ >= g0 && t_ < gend && nv_incl != excl;
+            if (mine) mark[excl - s_before] = (uint8_t)t_;
+            __syncthreads();
+            constexpr uint32_t NR = FILTCAP / 64u;
+            uint32_t ridx[NR];
+            uint2 key[NR];
+            unsigned long long bal[NR];
+            uint32_t carry_pos = 0u, carry_ent = g0; /* the last entry start in the rounds so far */
+#pragma unroll
+            for (uint32_t r = 0; r < NR; ++r) {
+                ridx[r] = 0xFFFFFFFFu;
+                key[r] = make_uint2(0xFFFFFFFFu, 0u);
+                if (r * 64u < V) { /* uniform */
+                    const uint32_t vs = r * 64u + t_;
+                    const unsigned long long st = __ballot(mark[vs] != 0xFFu);
+                    const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
+                    const unsigned long long m = st & upto;
+                    uint32_t s0 = carry_pos, en = carry_ent;
+                    if (m) {
+                        s0 = r * 64u + 63u - (uint32_t)__builtin_clzll(m);
+                        en = mark[s0];
+                    }
+                    if (vs < V) {
+                        ridx[r] = sh.ent[en].arena + (vs - s0);
+                        key[r] = g_skey[ridx[r]]; /* (sub-tile, item count | cap flag << 31); hole: sub-tile 0xFFFFFFFF */
+                    }
+                    if (st) {
+                        carry_pos = r * 64u + 63u - (uint32_t)__builtin_clzll(st);
+                        carry_ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)mark[carry_pos]);
+                    }
+                }
+            }
+            uint32_t kept = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < NR; ++r) {
+                const bool keep = key[r].x == sub && (key[r].y & 0x7FFFFFFFu) != 0u;
+                bal[r] = __ballot(keep);
+                const uint32_t c = kept + (uint32_t)__popcll(bal[r] & ((1ull << fresh_lane()) - 1ull));
+                if (keep && c < (uint32_t)SEGCAP) {
+                    tmp[c] = ridx[r];
+                    tmp[(uint32_t)SEGCAP + c] = key[r].y;
+                }
+                kept += (uint32_t)__popcll(bal[r]);
+            }
+            /* lane e: kept records in front of entry e's slots, and among them */
+            uint32_t slot0_v, nslot_v;
+            {
+                const uint32_t a_ = excl - s_before, b_ = nv_incl - s_before;
+                uint32_t na = 0u, nb = 0u;
+#pragma unroll
+                for (uint32_t r = 0; r < NR; ++r) {
+                    const int32_t xa = (int32_t)a_ - (int32_t)(r * 64u), xb = (int32_t)b_ - (int32_t)(r * 64u);
+                    const unsigned long long ma = xa <= 0 ? 0ull : (xa >= 64 ? ~0ull : ((1ull << xa) - 1ull));
+                    const unsigned long long mb = xb <= 0 ? 0ull : (xb >= 64 ? ~0ull : ((1ull << xb) - 1ull));
+                    na += (uint32_t)__popcll(bal[r] & ma);
+                    nb += (uint32_t)__popcll(bal[r] & mb);
+                }
+                slot0_v = mine ? na : 0u;
+                nslot_v = mine ? nb - na : 0u;
+            }
+            if (kept > (uint32_t)SEGCAP) { /* more records than the LDS holds: the group ends in front of the entry that does not fit */
+                const unsigned long long ov = __ballot(slot0_v + nslot_v > (uint32_t)SEGCAP);
+                const uint32_t e_ov = (uint32_t)__builtin_ctzll(ov);
+                if (e_ov == g0) { /* an op with more than SEGCAP records in ONE sub-tile: filtered and walked SEGCAP slots at a time */
+                    big = true;
+                    gend = g0 + 1u;
+                    kept = 0u;
+                } else {
+                    gend = e_ov;
+                    kept = (uint32_t)__builtin_amdgcn_readlane((int)slot0_v, (int)e_ov);
+                }
+            }
+            /* where an entry's records sit among the compacted ones replaces its arena position, which nothing needs any more */
+            if (mine && t_ < gend && !big) {
+                sh.ent[t_].arena = slot0_v;
+                sh.ent[t_].nv = nslot_v;
+            }
+            __syncthreads();
+            {
+                const uint32_t c = fresh_lane();
+                uint32_t ky = 0u, at = 0u;
+                if (c < kept) {
+                    ky = tmp[(uint32_t)SEGCAP + c];
+                    at = tmp[c];
+                }
+                sh.pre[c & (uint32_t)(SEGCAP - 1)] = 0u; /* (any value: overwritten below; keeps the scan in front of the record load) */
+                const uint32_t incl = wave_incl_scan(ky & 0x7FFFFFFFu); /* inclusive prefix of the item counts */
+                __syncthreads(); /* tmp and mark are read: their memory takes the records now */
+                if (c < kept) {
+                    sh.pre[c] = incl;
+                    const osmt_srec r = g_srec[at];
+                    sh.seg[c] = r;
+                    sh.der[c] = seg_derive(r, (ky >> 31) != 0u);
+                }
+            }
+            __syncthreads();
+        }
+        unsigned long long gbal = 0ull; /* big ops: lanes of the filter pass holding a record of this sub-tile */
 
         for (uint32_t li = g0; li < gend; ++li) {
             const StagedEnt& en = sh.ent[li];
@@ -1767,32 +1867,23 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     n_rounds = (big_cap + (uint32_t)SEGCAP - 1u) / (uint32_t)SEGCAP;
                 }
                 for (uint32_t round = 0; round < n_rounds; ++round) {
-                    if (big || !records_ready) {
-                        /* ---- filter pass: lane -> (list entry, slot of that op); keep the records of THIS sub-tile,
-                         * compact them in lane order (= op order, segment order), prefix-sum their item counts and
-                         * derive what all runs of a record share ---- */
-                        if (big) __syncthreads(); /* previous round's records are consumed */
+                    uint32_t slot0 = 0u, nslot = 0u;
+                    if (big) {
+                        /* ---- filter pass of ONE big op, SEGCAP of its slots per round ---- */
+                        __syncthreads(); /* previous round's records are consumed */
                         uint32_t ridx = 0xFFFFFFFFu;
-                        if (big) {
-                            const uint32_t v = round * (uint32_t)SEGCAP + lane;
-                            if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
-                        } else if (lane < V) {
-                            /* the entry whose slots start at or below this lane, nearest first */
-                            const uint32_t t_ = fresh_lane();
-                            const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
-                            const uint32_t s0 = 63u - (uint32_t)__builtin_clzll(starts & upto);
-                            ridx = sh.ent[sh.mark[s0]].arena + (t_ - s0);
-                        }
+                        const uint32_t v = round * (uint32_t)SEGCAP + lane;
+                        if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
                         uint32_t cnt = 0, is_cap = 0;
                         if (ridx != 0xFFFFFFFFu) {
-                            const uint2 key = g_skey[ridx]; /* (sub-tile, item count | cap flag << 31); hole: sub-tile 0xFFFFFFFF */
+                            const uint2 key = g_skey[ridx];
                             if (key.x == sub) {
                                 cnt = key.y & 0x7FFFFFFFu;
                                 is_cap = key.y >> 31;
                             }
                         }
                         gbal = __ballot(cnt > 0u);
-                        const uint32_t incl = wave_incl_scan(cnt); /* inclusive prefix of the item counts over the lanes */
+                        const uint32_t incl = wave_incl_scan(cnt);
                         if (cnt > 0u) {
                             const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << fresh_lane()) - 1ull));
                             const osmt_srec r = g_srec[ridx];
@@ -1800,20 +1891,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             sh.der[slot] = seg_derive(r, is_cap != 0u);
                             sh.pre[slot] = incl;
                         }
-                        records_ready = true;
                         __syncthreads();
+                        nslot = (uint32_t)__popcll(gbal);
+                    } else {
+                        slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
+                        nslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
                     }
-                    /* the op's records are lanes [va, vb) of the filter pass */
-                    uint32_t va = 0, vb = (uint32_t)SEGCAP;
-                    if (!big) {
-                        vb = (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)li) - s_before;
-                        va = li ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)li - 1) - s_before : 0u;
-                    }
-                    if (vb > va) {
-                        const unsigned long long lanes_ab =
-                            ((vb >= 64u) ? ~0ull : ((1ull << vb) - 1ull)) & ~((1ull << va) - 1ull);
-                        const uint32_t slot0 = (uint32_t)__popcll(gbal & ((1ull << va) - 1ull));
-                        const uint32_t nslot = (uint32_t)__popcll(gbal & lanes_ab);
+                    {
                         if (nslot) {
                             const uint32_t item_lo = slot0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 - 1u]) : 0u;
                             const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.pre[slot0 + nslot - 1u]);
