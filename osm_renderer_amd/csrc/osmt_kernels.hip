@@ -461,10 +461,13 @@ constexpr int NTHREADS = 64;       /* one wave per sub-tile: no cross-wave barri
 constexpr int PXT = SUB * SUBH / NTHREADS; /* pixels per thread */
 constexpr int ROWSTEP = NTHREADS / SUB;    /* rows between a thread's consecutive pixels */
 #ifndef OSMT_V_OPCHUNK
-#define OSMT_V_OPCHUNK 32
+#define OSMT_V_OPCHUNK 16
 #endif
-constexpr int OPCHUNK = OSMT_V_OPCHUNK; /* list entries staged per pass (config 2: ~5 per sub-tile, config 5: ~107) */
-static_assert(OPCHUNK == 32 || OPCHUNK == 64, "a chunk is staged by one wave");
+/* list entries staged per pass (config 2: ~5 per sub-tile, config 5: ~155).  16 with STAGECAP 16: every fill and every
+ * stroke of a chunk has its words / constants staged (with 32 and 8, two in five of config 5's fills fetched theirs with
+ * a scalar load of their own in the middle of the per-op loop: 1.38 -> 1.32 ms on 64 config-5 tiles, config 2 unchanged) */
+constexpr int OPCHUNK = OSMT_V_OPCHUNK;
+static_assert(OPCHUNK == 16 || OPCHUNK == 32 || OPCHUNK == 64, "a chunk is staged by one wave");
 #ifndef OSMT_V_SEGCAP
 #define OSMT_V_SEGCAP 32
 #endif
@@ -508,7 +511,7 @@ __device__ __forceinline__ uint32_t stroke_flags(const osmt_stroke_aux* __restri
            (sa->mul0 >= 1e-100 ? 0u : STROKE_TINY_MUL);
 }
 #ifndef OSMT_V_STAGECAP
-#define OSMT_V_STAGECAP 8
+#define OSMT_V_STAGECAP 16
 #endif
 constexpr int STAGECAP = OSMT_V_STAGECAP; /* fills / strokes of one chunk whose data is staged in LDS; the rest reads global memory */
 
@@ -526,7 +529,10 @@ struct alignas(8) SegDer {
 static_assert(sizeof(SegDer) == 40, "five 8-byte LDS words");
 constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_CAP = 8u, SEGW_SLOW = 16u;
 
-constexpr uint32_t FILTCAP = 256; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
+#ifndef OSMT_V_FILTCAP
+#define OSMT_V_FILTCAP 256
+#endif
+constexpr uint32_t FILTCAP = OSMT_V_FILTCAP; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
 struct RasterShared {
     OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [5] fill visits */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
@@ -541,7 +547,7 @@ struct RasterShared {
 #endif
 };
 static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
-static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP == 256u,
+static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP % 256u == 0u,
               "the filter pass borrows seg[] for its entry marks (one 4-byte store per lane) and der[] for the kept slots");
 
 struct SubRect {
@@ -1633,7 +1639,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * chunk's entries a chunk ahead cost eight registers for the whole chunk: 21 more spilled registers at 128, whose
      * scratch stores more than doubled the kernel's HBM writes.) */
     const uint2 hdr = a.hdr[(size_t)tile * nsub + sub];
+#if defined(OSMT_ABL) && OSMT_ABL == 8
+    const uint32_t n_ent = hdr.y > 0xFFFFFFF0u ? 1u : 0u; /* ablation: the list is not even staged */
+#else
     const uint32_t n_ent = hdr.y;
+#endif
     const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
 
     for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
@@ -1699,6 +1709,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         __syncthreads();
 
         uint32_t g0 = 0;
+#if defined(OSMT_ABL) && OSMT_ABL == 7
+        if (total < 1000u) g0 = total; /* ablation: the chunk is staged, no group is filtered or drawn */
+#endif
         while (g0 < total) {
         /* ---- group = consecutive list entries whose stroke slots fit in the SEGCAP lanes of ONE filter pass; an op with
          * more slots forms a group of its own and is filtered SEGCAP slots at a time ---- */
@@ -1725,7 +1738,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.seg);   /* mark[s]: list entry whose slots start at virtual slot s */
             uint32_t* const tmp = reinterpret_cast<uint32_t*>(sh.der);  /* [c]: arena slot of kept record c, [SEGCAP + c]: its item count | cap flag */
             const uint32_t t_ = fresh_lane();
-            reinterpret_cast<uint32_t*>(mark)[t_] = 0xFFFFFFFFu; /* FILTCAP = 256 bytes */
+#pragma unroll
+            for (uint32_t i = 0; i < FILTCAP; i += 256u) reinterpret_cast<uint32_t*>(mark + i)[t_] = 0xFFFFFFFFu;
             __syncthreads();
             /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
             const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
@@ -1764,6 +1778,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             uint32_t kept = 0u;
 #pragma unroll
             for (uint32_t r = 0; r < NR; ++r) {
+                bal[r] = 0ull;
+                if (r * 64u >= V) continue; /* uniform */
                 const bool keep = key[r].x == sub && (key[r].y & 0x7FFFFFFFu) != 0u;
                 bal[r] = __ballot(keep);
                 const uint32_t c = kept + (uint32_t)__popcll(bal[r] & ((1ull << fresh_lane()) - 1ull));
@@ -1773,21 +1789,28 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 kept += (uint32_t)__popcll(bal[r]);
             }
-            /* lane e: kept records in front of entry e's slots, and among them */
+            /* lane e: kept records in front of entry e's slots, and among them.  A bound lies in one round: that round's
+             * ballot and the count of the rounds before it are selected per lane (a popcount per bound, not one per round) */
             uint32_t slot0_v, nslot_v;
             {
-                const uint32_t a_ = excl - s_before, b_ = nv_incl - s_before;
-                uint32_t na = 0u, nb = 0u;
+                auto kept_below = [&](uint32_t x) { /* kept records among virtual slots [0, x), x <= V */
+                    const uint32_t rr = x >> 6;
+                    unsigned long long bsel = 0ull;
+                    uint32_t csel = kept, cum = 0u;
 #pragma unroll
-                for (uint32_t r = 0; r < NR; ++r) {
-                    const int32_t xa = (int32_t)a_ - (int32_t)(r * 64u), xb = (int32_t)b_ - (int32_t)(r * 64u);
-                    const unsigned long long ma = xa <= 0 ? 0ull : (xa >= 64 ? ~0ull : ((1ull << xa) - 1ull));
-                    const unsigned long long mb = xb <= 0 ? 0ull : (xb >= 64 ? ~0ull : ((1ull << xb) - 1ull));
-                    na += (uint32_t)__popcll(bal[r] & ma);
-                    nb += (uint32_t)__popcll(bal[r] & mb);
-                }
-                slot0_v = mine ? na : 0u;
-                nslot_v = mine ? nb - na : 0u;
+                    for (uint32_t r = 0; r < NR; ++r) {
+                        if (rr == r) {
+                            bsel = bal[r];
+                            csel = cum;
+                        }
+                        cum += (uint32_t)__popcll(bal[r]);
+                    }
+                    return csel + (uint32_t)__popcll(bsel & ((1ull << (x & 63u)) - 1ull));
+                };
+                const uint32_t na = kept_below(mine ? excl - s_before : 0u);
+                const uint32_t nb = kept_below(mine ? nv_incl - s_before : 0u);
+                slot0_v = na;
+                nslot_v = nb - na;
             }
             if (kept > (uint32_t)SEGCAP) { /* more records than the LDS holds: the group ends in front of the entry that does not fit */
                 const unsigned long long ov = __ballot(slot0_v + nslot_v > (uint32_t)SEGCAP);
