@@ -534,7 +534,8 @@ constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_
 #endif
 constexpr uint32_t FILTCAP = OSMT_V_FILTCAP; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
 struct RasterShared {
-    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [5] fill visits */
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] filter passes of groups [4] groups ended by the
+                                * 33rd kept record [5] fill visits [6] ops with more than SEGCAP records in the sub-tile [7] ops with more than FILTCAP slots */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     SegDer der[SEGCAP];
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
@@ -1723,6 +1724,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)FILTCAP);
             if (over) gend = (uint32_t)__builtin_ctzll(over);
             if (gend == g0) { /* the first entry alone has more slots than one filter pass looks at */
+                OSMT_DBG(if (lane == 0) sh.dbg[7] += 1u;)
                 big = true;
                 gend = g0 + 1u;
             } else {
@@ -1730,6 +1732,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             }
         }
         if (V) {
+            OSMT_DBG(if (lane == 0) sh.dbg[3] += 1u;)
             /* ---- filter pass of the GROUP: every slot of every stroke entry of the group is looked at once, FILTCAP slots
              * (four rounds of 64 lanes, all key loads in flight together); the records of THIS sub-tile are compacted in
              * slot order (= op order, segment order).  Round 3 looked at SEGCAP slots per pass: an op of 90 slots — five
@@ -1816,10 +1819,12 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const unsigned long long ov = __ballot(slot0_v + nslot_v > (uint32_t)SEGCAP);
                 const uint32_t e_ov = (uint32_t)__builtin_ctzll(ov);
                 if (e_ov == g0) { /* an op with more than SEGCAP records in ONE sub-tile: filtered and walked SEGCAP slots at a time */
+                    OSMT_DBG(if (lane == 0) sh.dbg[6] += 1u;)
                     big = true;
                     gend = g0 + 1u;
                     kept = 0u;
                 } else {
+                    OSMT_DBG(if (lane == 0) sh.dbg[4] += 1u;)
                     gend = e_ov;
                     kept = (uint32_t)__builtin_amdgcn_readlane((int)slot0_v, (int)e_ov);
                 }

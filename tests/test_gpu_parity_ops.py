@@ -369,3 +369,44 @@ def test_list_lengths_around_every_chunk_and_stage_boundary(gpu_ctx, oracle, n_o
     from osm_renderer_amd.display_list import concat
 
     assert_parity(gpu_ctx, oracle, concat(tiles), images=images, msg=f"{n_ops} ops in one sub-tile")
+
+
+def test_filter_groups_cut_by_slots_and_by_kept_records(gpu_ctx, oracle):
+    """k_raster filters the stroke slots of a GROUP of list entries in one pass (256 slots, 32 kept records).  Every way
+    a group can end: (a) many small ops whose records all sit in ONE sub-tile (the 33rd kept record ends the group in front
+    of its entry), (b) one op with more than 32 records in one sub-tile (filtered and walked 32 slots at a time), (c) ops
+    with more than 256 slots (long ways) between small ones, (d) fills and no-ops between the strokes of a group, dashed
+    and capped ops among them, more ops than a chunk holds."""
+    rnd = np.random.default_rng(11)
+
+    def squiggle(x0, y0, n, reach):
+        p = np.array([x0, y0]) + np.cumsum(rnd.integers(-reach, reach + 1, size=(n + 1, 2)), axis=0)
+        return p.tolist()
+
+    tb = TileBuilder(canvas=(240, 236, 225))
+    # (a) 14 ops x 7 tiny edges inside the sub-tile (32..63, 16..31); widths / opacities / colours differ, two are dashed
+    for i in range(14):
+        pts = [(40 + int(rnd.integers(0, 16)), 20 + int(rnd.integers(0, 8))) for _ in range(8)]
+        tb.stroke(pts, float(rnd.choice([0.7, 1.0, 2.0, 3.0])), tuple(rnd.integers(0, 256, size=3)), float(rnd.choice([1.0, 0.6, 0.3])),
+                  dashes=[3.0, 2.0] if i in (3, 9) else None, cap=CAPS[i % 4])
+        if i % 4 == 1:
+            tb.fill([(36, 18), (60, 19), (50, 30), (36, 18)], tuple(rnd.integers(0, 256, size=3)), 0.4)
+        if i % 5 == 2:
+            tb.nop()
+    # (b) one op with 45 tiny edges in one sub-tile, then one with 70 edges spread over two
+    tb.stroke([(100 + int(rnd.integers(0, 20)), 70 + int(rnd.integers(0, 9))) for _ in range(46)], 1.5, (10, 80, 200), 0.7)
+    tb.stroke([(130 + int(rnd.integers(0, 50)), 100 + int(rnd.integers(0, 12))) for _ in range(71)], 1.0, (200, 80, 10), 0.9, cap=abi.CAP_ROUND)
+    # (c) long ways with hundreds of slots, small ops in front of, between and behind them
+    tb.stroke(squiggle(20, 200, 5, 6), 2.0, (0, 0, 0), 1.0)
+    tb.stroke([(int(x), int(128 + 100 * np.sin(x / 23.0))) for x in range(-40, 300, 9)], 2.5, (120, 20, 160), 0.8, dashes=[9.0, 5.0])
+    tb.stroke(squiggle(200, 40, 6, 5), 1.0, (20, 120, 20), 0.5, cap=abi.CAP_SQUARE)
+    tb.stroke([(int(128 + (10 + 3.5 * t) * np.cos(t)), int(128 + (10 + 3.5 * t) * np.sin(t))) for t in np.linspace(0, 8 * np.pi, 120)], 4.0, (250, 200, 0), 0.6)
+    tb.stroke(squiggle(128, 128, 7, 4), 3.0, (0, 90, 90), 0.75)
+    # (d) many more small strokes over the same few sub-tiles: several chunks per list, groups of every size
+    for i in range(60):
+        x0, y0 = 32 * int(rnd.integers(1, 4)) + int(rnd.integers(0, 32)), 16 * int(rnd.integers(1, 4)) + int(rnd.integers(0, 16))
+        tb.stroke(squiggle(x0, y0, int(rnd.integers(1, 7)), 5), float(rnd.choice([0.5, 1.0, 1.5, 4.0])), tuple(rnd.integers(0, 256, size=3)),
+                  float(rnd.choice([1.0, 0.5])), cap=CAPS[int(rnd.integers(0, 4))])
+        if i % 7 == 0:
+            tb.fill([(x0 - 9, y0 - 7), (x0 + 12, y0 - 3), (x0 + 2, y0 + 11), (x0 - 9, y0 - 7)], tuple(rnd.integers(0, 256, size=3)), 0.5)
+    assert_parity(gpu_ctx, oracle, tb.build(), msg="filter groups")
