@@ -1856,7 +1856,11 @@ static int png_end_body(osmt_png_job* j, uint8_t* out_png, size_t out_capacity, 
              * them.  Only files that would not fit (noise: the slot bound is 12 bits per byte) or a forced chunk count above
              * two (framebuffers re-used by chunk c + 2) get a buffer of their own. */
             char* blob = d + j->o_rgba + (size_t)(c & 1u) * chunk * j->tile_bytes;
-            if (j->n_chunks > 2u || c_bytes > (size_t)cnt * j->tile_bytes) {
+            static const bool own_blob = [] { /* diagnostic: OSMT_PNG_OWN_BLOB=1 always compacts into a buffer of its own */
+                const char* v = getenv("OSMT_PNG_OWN_BLOB");
+                return v && atoi(v) != 0;
+            }();
+            if (own_blob || j->n_chunks > 2u || c_bytes > (size_t)cnt * j->tile_bytes) {
                 if (!j->d_blob) {
                     e = dev_alloc(ctx, (void**)&j->d_blob, (size_t)n * slot);
                     if (e != hipSuccess) {
