@@ -401,6 +401,10 @@ hipError_t stream_sync_small(hipStream_t st) {
         const char* v = getenv("OSMT_SPIN_SYNC");
         return !(v && v[0] == '0');
     }();
+    /* (Several groups in flight = several threads polling, and hipStreamQuery takes the runtime's lock every time: with six
+     * groups in flight a two-tile group takes 520 us instead of 200.  Waiting on a word of pinned memory that the stream
+     * writes behind the copy — hipStreamWriteValue32 — removes that contention (6 in flight: 20 k -> 42 k tiles/s) but the
+     * write itself is slow: 2 in flight 33 k against 45 k.  Two groups in flight and the query it is.) */
     if (spin) {
         const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
         for (;;) {
@@ -676,7 +680,10 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
     hipStream_t st = (hipStream_t)stream;
     const uint32_t W = OSMT_TILE_SIZE * sc->scale;
     if ((stages & 4u) && !d_out) return fail(OSMT_INVALID_ARG, "output pointer is NULL");
-    if ((stages & 4u) && !f64 && stride < (size_t)W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    const bool rgb8 = (stages & 32u) != 0u; /* stage bit 32 (internal): k_raster writes packed RGB8 */
+    if ((stages & 4u) && !f64 && !rgb8 && stride < (size_t)W * W * 4) return fail(OSMT_INVALID_ARG, "out_tile_stride_bytes < W*H*4");
+    if ((stages & 4u) && rgb8 && (f64 || stride < (size_t)W * W * 3 || (stride & 3u) || ((uintptr_t)d_out & 3u)))
+        return fail(OSMT_INVALID_ARG, "RGB8 output: tile stride below W*H*3 or not a multiple of 4");
     bool zeroed = false;
     if ((stages & 1u) && sc->coord_kind != OSMT_COORD_POINT_I32) {
         /* when the pre-pass follows in this call, the projection kernel clears its cursors and list counts on the way */
@@ -740,6 +747,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.n_images = img.n;
         a.out = d_out;
         a.out_tile_stride = stride;
+        a.out_rgb8 = rgb8 ? 1u : 0u;
         if (want_labels) {
             a.labels.info = sc->d_lab;
             a.labels.n_labels = sc->n_labels;
@@ -1555,7 +1563,8 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
             if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
         }
         char* d_rgb = nullptr;
-        if (e == hipSuccess) e = dev_alloc(ctx, (void**)&d_out, 2 * (size_t)chunk * tile_bytes);
+        /* RGB8: k_raster packs the triples itself (no RGBA8 framebuffer, no packing kernel) */
+        if (e == hipSuccess && !rgb) e = dev_alloc(ctx, (void**)&d_out, 2 * (size_t)chunk * tile_bytes);
         if (e == hipSuccess && rgb) e = dev_alloc(ctx, (void**)&d_rgb, 2 * (size_t)chunk * host_bytes);
         if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "pipeline setup failed: %s", hipGetErrorString(e));
         if (rc == OSMT_OK) rc = render_impl(ctx, sc, 1u | 2u | 8u, nullptr, tile_bytes, false, s_k);
@@ -1563,16 +1572,11 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
         for (uint32_t first = 0; rc == OSMT_OK && first < batch->n_jobs; first += chunk, ++c) {
             const uint32_t cnt = (uint32_t)std::min<size_t>(chunk, batch->n_jobs - first);
             const int k = (int)(c & 1u);
-            char* dst = d_out + (size_t)k * chunk * tile_bytes;
+            char* dst = rgb ? d_rgb + (size_t)k * chunk * host_bytes : d_out + (size_t)k * chunk * tile_bytes;
             if (c >= 2) e = hipStreamWaitEvent(s_k, freed[k], 0);
-            if (e == hipSuccess) rc = render_impl(ctx, sc, 4u | 16u, dst, tile_bytes, false, s_k, first, cnt);
+            if (e == hipSuccess) rc = render_impl(ctx, sc, 4u | 16u | (rgb ? 32u : 0u), dst, host_bytes, false, s_k, first, cnt);
             if (rc != OSMT_OK) break;
             const char* src = dst;
-            if (rgb && e == hipSuccess) { /* packed on the device, behind the chunk's raster */
-                char* pk = d_rgb + (size_t)k * chunk * host_bytes;
-                e = osmt_launch_rgba_to_rgb(dst, pk, (size_t)cnt * W * W, s_k);
-                src = pk;
-            }
             if (e == hipSuccess) e = hipEventRecord(done[k], s_k);
             if (e == hipSuccess) e = hipStreamWaitEvent(s_c, done[k], 0);
             if (e == hipSuccess) {
@@ -1603,29 +1607,18 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
         return rc;
     }
     void* d_out = nullptr;
-    void* d_rgb = nullptr;
     if (batch->n_jobs) {
-        hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * tile_bytes);
+        hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * host_bytes); /* RGB8: written by k_raster as packed triples */
         if (e != hipSuccess) {
             osmt_scene_free(sc);
             stream_release(ctx, st);
             return fail(OSMT_OOM, "hipMalloc(output) failed: %s", hipGetErrorString(e));
         }
     }
-    rc = render_impl(ctx, sc, 7u, d_out ? d_out : (void*)1, tile_bytes, false, st);
+    rc = render_impl(ctx, sc, 7u | (rgb ? 32u : 0u), d_out ? d_out : (void*)4, host_bytes, false, st);
     if (rc == OSMT_OK && batch->n_jobs) {
         hipError_t e = hipSuccess;
         const void* src = d_out;
-        if (rgb) {
-            e = dev_alloc(ctx, &d_rgb, batch->n_jobs * host_bytes);
-            if (e != hipSuccess) {
-                rc = fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(RGB8 output) failed: %s", hipGetErrorString(e));
-                e = hipSuccess;
-            } else {
-                e = osmt_launch_rgba_to_rgb(d_out, d_rgb, batch->n_jobs * W * W, st);
-            }
-            src = d_rgb;
-        }
         if (rc == OSMT_OK && e == hipSuccess) {
             if (stride == host_bytes)
                 e = hipMemcpyAsync(out_rgba, src, batch->n_jobs * host_bytes, hipMemcpyDeviceToHost, st);
@@ -1638,7 +1631,6 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
     osmt_scene_free(sc); /* waits for the call's stream */
     dev_free(ctx, d_out);
-    dev_free(ctx, d_rgb);
     stream_release(ctx, st);
     return rc;
 }
@@ -2523,7 +2515,10 @@ constexpr size_t CO_MAX_TILES = 64;
 int co_max_in_flight() {
     static const int v = [] {
         const char* e = getenv("OSMT_WORKER_INFLIGHT");
-        return e ? std::min(std::max(atoi(e), 1), 16) : 3; /* 16 native threads: 36 k tiles/s with 1, 33-45 k with 2, 46 k with 3, 24-35 k with 4 and 8 */
+        /* 16 / 32 native threads, one-tile requests: 48 / 64 k tiles/s with 1, 45 / 72 k with 2, 35 / 53 k with 3, 28 / 49 k with 4,
+         * 20 / 37 k with 6 (profiles/r04_j_worker_inflight.txt): every group in flight is a host thread in the runtime, and
+         * they queue up behind each other's calls */
+        return e ? std::min(std::max(atoi(e), 1), 16) : 2;
     }();
     return v;
 }

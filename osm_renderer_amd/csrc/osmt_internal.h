@@ -229,9 +229,9 @@ struct osmt_raster_args {
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
-    uint32_t _pad;
+    uint32_t out_rgb8;       /* 1: packed RGB8 (the memory of to_rgb_triples' Vec<(u8, u8, u8)>) instead of RGBA8; tile stride a multiple of 4 */
     void* out;
-    size_t out_tile_stride; /* bytes (RGBA8 output) */
+    size_t out_tile_stride; /* bytes (RGBA8 / RGB8 output) */
     osmt_label_args labels;  /* info == NULL: no label pass */
 };
 
@@ -299,7 +299,6 @@ hipError_t osmt_launch_labels(const osmt_label_launch& a, hipStream_t st);
 /* RGBA8 framebuffers -> complete RGB8 PNG files, one per tile, out_len[i] bytes at out + i * out_stride */
 hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uint32_t W, uint32_t H, uint32_t ihdr_crc, void* out,
                            size_t out_stride, uint32_t* out_len, hipStream_t st);
-hipError_t osmt_launch_rgba_to_rgb(const void* rgba, void* rgb, size_t n_px, hipStream_t st);
 hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
                                    void* blob, hipStream_t st);
 hipError_t osmt_launch_copy16(const void* src, void* dst, size_t n16, bool read_only, hipStream_t st);

@@ -2092,6 +2092,33 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const size_t g_out_tile_stride = late_args()->out_tile_stride;
     const uint32_t t_out = fresh_lane();
     const uint32_t lx_o = t_out & (SUB - 1), ly_o = t_out / SUB;
+    if (!OUT_F64 && late_args()->out_rgb8) {
+        /* packed RGB8: the sub-tile's 16 rows of 96 bytes go through LDS (the alpha plane is free now) — three byte
+         * stores per pixel in, six dwords per lane out, every row a contiguous 96-byte piece of the tile's row — instead
+         * of a second kernel that reads the RGBA8 framebuffers back and packs them */
+        uint8_t* const stg = reinterpret_cast<uint8_t*>(sh.plane);
+        static_assert(sizeof(sh.plane) >= (size_t)SUB * SUBH * 3, "RGB8 staging fits the alpha plane");
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;
+            uint8_t* px = stg + (row * SUB + lx_o) * 3u;
+            px[0] = (uint8_t)f64_as_u8(255.0 * acc[j][0]);
+            px[1] = (uint8_t)f64_as_u8(255.0 * acc[j][1]);
+            px[2] = (uint8_t)f64_as_u8(255.0 * acc[j][2]);
+        }
+        __syncthreads();
+        constexpr uint32_t ROW_DW = SUB * 3 / 4; /* 24 dwords per row */
+        uint8_t* const tile_out = reinterpret_cast<uint8_t*>(g_out) + (size_t)tile * g_out_tile_stride;
+#pragma unroll
+        for (uint32_t q = 0; q < ROW_DW * SUBH / NTHREADS; ++q) {
+            const uint32_t d = q * NTHREADS + t_out;
+            const uint32_t row = d / ROW_DW, k = d % ROW_DW;
+            const uint32_t v = reinterpret_cast<const uint32_t*>(stg)[d];
+            *reinterpret_cast<uint32_t*>(tile_out + ((size_t)(rc.y0 + (int32_t)row) * W + (size_t)rc.x0) * 3u + 4u * k) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;

@@ -698,27 +698,6 @@ __global__ __launch_bounds__(256) void k_png_compact(const uint8_t* __restrict__
     for (uint32_t i = threadIdx.x; i < L; i += 256u) dst[i] = src[i];
 }
 
-/* RGBA8 framebuffers -> packed RGB8 (the reference's RgbTriples, tile_pixels.rs:46,164-181): a thread turns four
- * pixels (one 16-byte load) into three words; 0.75 of the bytes cross PCIe and the host gets Vec<(u8, u8, u8)>'s
- * memory layout without touching a pixel. */
-__global__ __launch_bounds__(256) void k_rgba_to_rgb(const uint4* __restrict__ in, uint32_t* __restrict__ out, size_t n_quads) {
-    for (size_t q = (size_t)blockIdx.x * 256u + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * 256u) {
-        const uint4 p = in[q]; /* little endian: byte 0 = r */
-        const uint32_t a = p.x & 0xFFFFFFu, b = p.y & 0xFFFFFFu, c = p.z & 0xFFFFFFu, d = p.w & 0xFFFFFFu;
-        out[3 * q] = a | (b << 24);
-        out[3 * q + 1] = (b >> 8) | (c << 16);
-        out[3 * q + 2] = (c >> 16) | (d << 8);
-    }
-}
-
-hipError_t osmt_launch_rgba_to_rgb(const void* rgba, void* rgb, size_t n_px, hipStream_t st) {
-    const size_t n_quads = n_px / 4u; /* (256 * scale)^2 pixels per tile: a multiple of 4 */
-    if (!n_quads) return hipSuccess;
-    const uint32_t blocks = (uint32_t)std::min<size_t>((n_quads + 255u) / 256u, 65535u * 4u);
-    hipLaunchKernelGGL(k_rgba_to_rgb, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(rgba), reinterpret_cast<uint32_t*>(rgb), n_quads);
-    return hipGetLastError();
-}
-
 hipError_t osmt_launch_png_compact(const void* slots, size_t slot_stride, const uint32_t* len, const unsigned long long* off, uint32_t n,
                                    void* blob, hipStream_t st) {
     if (n == 0) return hipSuccess;
