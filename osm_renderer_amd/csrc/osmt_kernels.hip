@@ -1421,7 +1421,10 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
  * once — and, column by column, the lanes whose op draws there are compacted in order (ballot + popcount: order is
  * semantics, `over` is not commutative) and write the op's entry, arena position resolved for that sub-tile, at
  * their rank. */
-constexpr uint32_t SUBLIST_THREADS = 1024;
+#ifndef OSMT_V_SUBLIST_THREADS
+#define OSMT_V_SUBLIST_THREADS 1024
+#endif
+constexpr uint32_t SUBLIST_THREADS = OSMT_V_SUBLIST_THREADS;
 constexpr uint32_t SUBLIST_MAX_SUB = (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_W) * (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_H);
 __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job* __restrict__ g_jobs, uint32_t g_scale,
                                                              const osmt_opinfo* __restrict__ g_info, const uint32_t* __restrict__ g_submask,
