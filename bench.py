@@ -576,8 +576,11 @@ def main():
             # ... and from ONE thread with the call split in two (osmt_render_batch_png_begin / _end): batch k + 1 is validated,
             # uploaded and queued while the GPU works on batch k; two jobs in flight, two pinned output buffers
             pb = [ctx.host_alloc((dl.n_jobs * 96 * 1024,)) for _ in range(2)]
-            n_pipe = 8
-            for n_round in (3, n_pipe):  # an untimed round of three first (the second job's buffers come out of the caches), then the timed one
+            n_pipe = 16
+            # an untimed round of the same length first: the second job's buffers come out of the context's caches and the
+            # runtime's own staging for the pageable display lists settles (a cold round runs at 3.0 ms per batch, every
+            # later one at 2.1: tools/bench_png_begin_end.py); then the timed one
+            for n_round in (n_pipe, n_pipe):
                 t0 = time.perf_counter()
                 prev = ctx.png_begin(dl)
                 for k in range(1, n_round):
@@ -598,8 +601,8 @@ def main():
                 "png_files_pinned_tiles_per_s": dl.n_jobs / png_s, "png_ms": png_s * 1e3, "png_bytes_per_tile": float(off[-1]) / dl.n_jobs,
                 "png_files_worker_threads_tiles_per_s": pooled,
                 "png_files_begin_end_tiles_per_s": dl.n_jobs / pipe_s, "png_begin_end_ms_per_batch": pipe_s * 1e3,
-                "png_begin_end_what": "one caller thread, osmt_render_batch_png_begin(k + 1) before osmt_render_batch_png_end(k), 8 batches "
-                                      "after an untimed round of 3 (steady state: both jobs' buffers are in the context's caches)",
+                "png_begin_end_what": "one caller thread, osmt_render_batch_png_begin(k + 1) before osmt_render_batch_png_end(k), 16 batches "
+                                      "after an untimed round of 16 (steady state)",
             }
             ctx.host_free(pin)
             ctx.host_free(pbuf)

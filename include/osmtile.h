@@ -319,7 +319,7 @@ int osmt_render_batch_png_end(osmt_png_job* job, uint8_t* out_png, size_t out_ca
  * (same arguments, same pixels, same errors, blocks until out_rgb holds the tiles), but requests of different
  * workers of one context that are in flight at the same moment are gathered into ONE launch sequence on the device:
  * a request that finds the device free starts at once, alone; requests that arrive while it renders wait and go out
- * together with the next one (at most 64 tiles per group, OSMT_WORKER_INFLIGHT = 3 groups on the device at a time).
+ * together with the next one (at most 64 tiles per group, OSMT_WORKER_INFLIGHT = 2 groups on the device at a time).
  * Sixteen threads calling the batch entry with one tile each queue up behind each other instead (round 3: 17 k
  * tiles/s at p99 9.6 ms).  Any thread may use any worker; a worker keeps its context alive like a scene does.
  * Batches of more than 64 tiles are rendered directly. */

@@ -80,9 +80,11 @@ struct osmt_ctx {
         void* p;
         size_t bytes;
         bool used;
+        uint64_t tick; /* when it was last handed out: the idle buffers given back to the driver are the least recently used */
     };
     std::mutex cache_mu;
     std::vector<cached_buf> cache;
+    uint64_t cache_tick = 0;
     /* idle non-blocking streams: every host-buffer call runs on its own stream, so calls from the reference's N
      * worker threads (http_server.rs:50-83) overlap on the GPU instead of queueing behind the NULL stream */
     std::vector<hipStream_t> idle_streams;
@@ -201,7 +203,18 @@ struct osmt_scene {
 namespace {
 
 constexpr double OSMT_MAX_ABS_LAT = 85.06; /* Web-Mercator limit 85.0511..., with a little slack */
-constexpr size_t CACHE_KEEP_BYTES = (size_t)8 << 30; /* idle buffers beyond this are returned to the driver */
+/* Idle buffers beyond this are returned to the driver, least recently used first.  hipFree waits for the device: a process
+ * that has rendered a few big batches (a 10 000-tile call leaves 5 GB idle) and then runs pipelined jobs must not free —
+ * and malloc again — a buffer on every call (round 4: 8 GB, oldest ALLOCATION first: the PNG begin / end leg of bench.py ran
+ * at 3.6 ms per batch behind the other legs and at 2.1 ms on its own).  288 GB of HBM: 32 GB, OSMT_CACHE_GB overrides. */
+size_t cache_keep_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("OSMT_CACHE_GB");
+        const long gb = e ? atol(e) : 32;
+        return (size_t)std::min<long>(std::max<long>(gb, 0), 256) << 30;
+    }();
+    return v;
+}
 
 hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
     bytes = align_up(bytes ? bytes : 1, (size_t)2 << 20);
@@ -212,6 +225,7 @@ hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
             if (!c.used && c.bytes >= bytes && c.bytes <= 2 * bytes && (!best || c.bytes < best->bytes)) best = &c;
         if (best) {
             best->used = true;
+            best->tick = ++ctx->cache_tick;
             *out = best->p;
             return hipSuccess;
         }
@@ -232,7 +246,7 @@ hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
     }
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
-    ctx->cache.push_back({*out, bytes, true});
+    ctx->cache.push_back({*out, bytes, true, ++ctx->cache_tick});
     return hipSuccess;
 }
 
@@ -323,14 +337,14 @@ void dev_free(osmt_ctx* ctx, void* p) {
         if (c.p == p) c.used = false;
         if (!c.used) idle += c.bytes;
     }
-    for (size_t i = 0; idle > CACHE_KEEP_BYTES && i < ctx->cache.size();) {
-        if (!ctx->cache[i].used) {
-            idle -= ctx->cache[i].bytes;
-            (void)hipFree(ctx->cache[i].p);
-            ctx->cache.erase(ctx->cache.begin() + (long)i);
-        } else {
-            ++i;
-        }
+    while (idle > cache_keep_bytes()) {
+        size_t lru = ctx->cache.size();
+        for (size_t i = 0; i < ctx->cache.size(); ++i)
+            if (!ctx->cache[i].used && (lru == ctx->cache.size() || ctx->cache[i].tick < ctx->cache[lru].tick)) lru = i;
+        if (lru == ctx->cache.size()) break;
+        idle -= ctx->cache[lru].bytes;
+        (void)hipFree(ctx->cache[lru].p);
+        ctx->cache.erase(ctx->cache.begin() + (long)lru);
     }
 }
 
