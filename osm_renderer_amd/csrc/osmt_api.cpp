@@ -179,6 +179,7 @@ struct osmt_scene {
     std::vector<std::pair<hipStream_t, hipEvent_t>> last_use;
     void* h_stage = nullptr;          /* pinned staging of a packed upload, returned to the pool when the scene goes */
     uint32_t* h_err = nullptr;        /* the scene's word of osmt_ctx::err_page (NULL: none left, errors stay unreported) */
+    uint32_t max_job_ops = 0;         /* most ops of any of the scene's tiles: at most OSMT_FOLD_MAX_OPS = no list kernel */
     bool arena_guess = false;         /* the arenas were sized from osmt_ctx::density, not by the device: an overflow is a miss, not a bug */
     /* label pass (osmt_scene_set_labels): its own allocation */
     uint32_t n_labels = 0, n_label_segs = 0;
@@ -660,6 +661,8 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.vpts = sc->d_vpts;
     a.vop = sc->d_vop;
     a.n_vsegs = sc->n_vsegs;
+    a.max_job_ops = sc->max_job_ops;
+    a.fold_max_ops = sc->n_jobs <= OSMT_FOLD_MAX_JOBS ? OSMT_FOLD_MAX_OPS : 0u;
     a.scale = sc->scale;
     a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
     a.info = sc->d_info;
@@ -756,6 +759,9 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
+        a.info = sc->d_info;
+        a.submask = sc->d_submask;
+        a.fold_max_ops = sc->n_jobs <= OSMT_FOLD_MAX_JOBS ? OSMT_FOLD_MAX_OPS : 0u; /* the same rule as the pre-pass (prepass_args) */
         a.images = img.desc;
         a.image_pool = img.pool;
         a.n_images = img.n;
@@ -1001,8 +1007,10 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     uint32_t n_strokes = 0;
     size_t n_blk = 0; /* 64-edge blocks of the ops with more than 64 edges */
     size_t n_vsegs = 0, n_fills = 0;
+    uint32_t max_job_ops = 0;
     for (size_t j = 0; j < b->n_jobs; ++j) {
         const osmt_tile_job& job = b->jobs[j];
+        max_job_ops = std::max(max_job_ops, job.n_ops);
         if (host_pt_job)
             for (uint32_t i = 0; i < job.n_pts; ++i) pt_job[job.pt_off + i] = (uint32_t)j;
         for (uint32_t k = 0; k < job.n_ops; ++k) {
@@ -1037,6 +1045,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     ctx->refs.fetch_add(1);
     s->h_err = err_slot_acquire(ctx);
     s->n_jobs = (uint32_t)b->n_jobs;
+    s->max_job_ops = max_job_ops;
     s->n_ops = (uint32_t)b->n_ops;
     s->n_rings = (uint32_t)b->n_rings;
     s->n_pts = (uint32_t)b->n_pts;

@@ -216,6 +216,13 @@ struct osmt_label_args {
     const double* plane;           /* A pool after k_label_cover: min(a + s_acc, 1.0) per cell, 0 where no key */
 };
 
+/* SMALL batches (the one-tile request, a gathered worker group): a tile with at most this many ops gets no per-sub-tile lists
+ * from k_sublist — one word of op bits per lane (two rounds) and a ballot give a sub-tile wave its list in op order directly,
+ * and a launch (8 us of a 105 us request) is saved.  Big batches keep the lists: there the scattered reads of the op bits by
+ * 131 072 waves cost k_raster more (0.615 -> 0.670 ms on config 2) than the list kernel does (0.032 ms). */
+#define OSMT_FOLD_MAX_OPS 128u
+#define OSMT_FOLD_MAX_JOBS 64u
+
 struct osmt_raster_args {
     const osmt_tile_job* jobs;
     uint32_t n_jobs;
@@ -225,6 +232,11 @@ struct osmt_raster_args {
     const osmt_ent* ent;     /* the lists */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
+    /* tiles of at most fold_max_ops ops have no lists: their sub-tile waves read the op bits and the op records themselves */
+    uint32_t fold_max_ops;   /* 0: every tile has lists */
+    uint32_t _pad1;
+    const osmt_opinfo* info;
+    const uint32_t* submask; /* [op][sub-tile row]: bit sx = the op draws into sub-tile (sx, row) */
     const uint2* skey;       /* per stroke slot: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
     const osmt_image_desc* images;
     const double4* image_pool;
@@ -251,6 +263,8 @@ struct osmt_prepass_args {
     uint32_t n_vsegs;
     uint32_t scale;
     uint32_t sub_rows;
+    uint32_t max_job_ops;  /* most ops of any tile */
+    uint32_t fold_max_ops; /* tiles of at most this many ops get no lists (0: all do); max_job_ops <= fold_max_ops = no k_sublist launch */
     osmt_opinfo* info;
     /* per VIRTUAL SEGMENT (index = op_vseg[op] + running edge index), so ops that share rings do not collide */
     double* trav;

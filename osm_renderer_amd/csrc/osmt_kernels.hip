@@ -1430,11 +1430,13 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              const osmt_opinfo* __restrict__ g_info, const uint32_t* __restrict__ g_submask,
                                                              uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
                                                              unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
-                                                             osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err) {
+                                                             osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err,
+                                                             uint32_t g_fold_max_ops) {
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
+    if (g_jobs[tile].n_ops <= g_fold_max_ops) return; /* k_raster's waves build the lists of such a tile themselves */
     const uint32_t W = OSMT_TILE_SIZE * g_scale;
     const uint32_t nsx = W / SUB;
     const uint32_t nsub = nsx * g_sub_rows;
@@ -1575,7 +1577,7 @@ __device__ __forceinline__ void blend_masked(double& r, double& g, double& b, do
         : "scc");
 }
 
-template <bool OUT_F64, bool LABELS>
+template <bool OUT_F64, bool LABELS, bool FOLD>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* ONE by-value argument block.  The tables of the hot loops (lists, coverage words, stroke records, calculator
      * constants) are taken from it once and live in SGPRs; everything that is needed only at one point — the job record
@@ -1642,7 +1644,34 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* this sub-tile's own list (k_sublist): the ops that draw here, in order, OPCHUNK at a time.  (Fetching the next
      * chunk's entries a chunk ahead cost eight registers for the whole chunk: 21 more spilled registers at 128, whose
      * scratch stores more than doubled the kernel's HBM writes.) */
-    const uint2 hdr = a.hdr[(size_t)tile * nsub + sub];
+    /* Small batches: a tile of at most fold_max_ops (<= 128) ops has no lists (k_sublist skips it): lane l looks at the bits of ops l and
+     * l + 64 for this sub-tile's row, two ballots give the ops that draw here IN OP ORDER, and a chunk's entries are put
+     * together from the op records by the lanes of their ops — the same two dependent loads as header -> entries, one
+     * kernel (32 us of a config-2 step, 8 us of a one-tile request) fewer. */
+    /* FOLD: the instantiation small batches are rendered with (osmt_launch_raster); the other one is the kernel big batches
+     * have always had — not an instruction of it differs */
+    const bool fold = FOLD && job.n_ops <= OSMT_FOLD_MAX_OPS;
+    /* the op bits of this sub-tile, asked for again by every chunk (one chunk per sub-tile on config 2): a word that stayed
+     * in a register across the chunk loop is a register the kernel does not have */
+    auto op_bits = [&](unsigned long long* b0, unsigned long long* b1) {
+        const osmt_raster_args* la = late_args();
+        const osmt_tile_job* OSMT_R jb = &la->jobs[tile];
+        const uint32_t n_ops = jb->n_ops, sub_rows = W / SUBH;
+        const uint32_t* OSMT_R sm = la->submask + (size_t)jb->op_off * sub_rows + sub / subs_per_row;
+        const uint32_t t_ = fresh_lane(), sx_ = sub % subs_per_row;
+        const uint32_t w0 = t_ < n_ops ? sm[(size_t)t_ * sub_rows] : 0u;
+        const uint32_t w1 = t_ + 64u < n_ops ? sm[(size_t)(t_ + 64u) * sub_rows] : 0u;
+        *b0 = __ballot((w0 >> sx_) & 1u);
+        *b1 = __ballot((w1 >> sx_) & 1u);
+    };
+    uint2 hdr = make_uint2(0u, 0u);
+    if (fold) {
+        unsigned long long b0, b1;
+        op_bits(&b0, &b1);
+        hdr.y = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+    } else {
+        hdr = a.hdr[(size_t)tile * nsub + sub];
+    }
 #if defined(OSMT_ABL) && OSMT_ABL == 8
     const uint32_t n_ent = hdr.y > 0xFFFFFFF0u ? 1u : 0u; /* ablation: the list is not even staged */
 #else
@@ -1654,7 +1683,40 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
         const bool hit = lane < total;
         osmt_ent e = {};
-        if (hit) e = my_ent[base + lane];
+        if (FOLD && late_args()->jobs[tile].n_ops <= OSMT_FOLD_MAX_OPS) { /* (asked again: a flag kept across the loop is a register) */
+            osmt_ent* const tmp = reinterpret_cast<osmt_ent*>(sh.seg); /* the previous chunk's records are consumed */
+            static_assert(sizeof(osmt_ent) * OPCHUNK <= sizeof(sh.seg), "a chunk's entries fit the record array");
+            const osmt_opinfo* OSMT_R g_info = late_args()->info + late_args()->jobs[tile].op_off;
+            unsigned long long bb[2];
+            op_bits(&bb[0], &bb[1]);
+            const uint32_t n0 = (uint32_t)__popcll(bb[0]);
+#pragma unroll
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t t_ = fresh_lane();
+                const uint32_t r = (half ? n0 : 0u) + (uint32_t)__popcll(bb[half] & ((1ull << t_) - 1ull));
+                if (((bb[half] >> t_) & 1ull) && r >= base && r < base + (uint32_t)OPCHUNK) {
+                    const osmt_opinfo* OSMT_R hi = &g_info[t_ + 64u * half];
+                    const uint32_t kind = hi->kind;
+                    const bool strk = kind == OSMT_OP_STROKE;
+                    const uint32_t geom = hi->fill_geom, arena0 = hi->arena_off;
+                    osmt_ent t;
+                    t.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
+                    t.opacity = hi->opacity;
+                    t.aux = strk ? hi->aux : hi->image_id;
+                    t.nv = strk ? hi->rec_cap : 0u;
+                    /* FILL: word index of this sub-tile's 16 rows (sr0 | c0 << 8 | ncols << 16); STROKE: the op's first slot */
+                    t.arena = strk ? arena0
+                                   : (arena0 + (sub / subs_per_row - (geom & 255u)) * ((geom >> 16) & 255u) + (sub % subs_per_row - ((geom >> 8) & 255u))) * SUBH;
+                    t.stage = 0u;
+                    t._pad = 0u;
+                    tmp[r - base] = t;
+                }
+            }
+            __syncthreads();
+            if (hit) e = tmp[fresh_lane()];
+        } else if (hit) {
+            e = my_ent[base + lane];
+        }
         const uint32_t e_kind = e.kind_color & 255u;
         const bool is_stroke = hit && e_kind == OSMT_OP_STROKE;
         const unsigned long long sbal = __ballot(is_stroke), fbal = __ballot(hit && !is_stroke);
@@ -2314,9 +2376,10 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
         hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
                            a.trav, a.den, a.rden, a.vpts, a.vop, a.op_blk, a.blk, a.n_vsegs, n_vblk,
                            a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
-    if (a.n_jobs) /* also without a single op: k_raster reads the (empty) list headers */
+    /* lists only for tiles with more than OSMT_FOLD_MAX_OPS ops (k_raster's waves put the others' together themselves) */
+    if (a.n_jobs && (a.fold_max_ops == 0u || a.max_job_ops > a.fold_max_ops))
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
-                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err);
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops);
     return hipGetLastError();
 }
 
@@ -2326,7 +2389,13 @@ hipError_t osmt_launch_raster(const osmt_raster_args& a, bool out_f64, hipStream
     const uint32_t nsub = (W / SUB) * (W / SUBH);
     const uint32_t groups = (a.n_jobs + 7u) / 8u;
     const dim3 grid(groups * 8u * nsub);
-#define OSMT_LAUNCH_RASTER(F64, LAB) hipLaunchKernelGGL((k_raster<F64, LAB>), grid, dim3(NTHREADS), 0, st, a)
+#define OSMT_LAUNCH_RASTER(F64, LAB)                                                                \
+    do {                                                                                            \
+        if (a.fold_max_ops)                                                                         \
+            hipLaunchKernelGGL((k_raster<F64, LAB, true>), grid, dim3(NTHREADS), 0, st, a);  \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_raster<F64, LAB, false>), grid, dim3(NTHREADS), 0, st, a); \
+    } while (0)
     if (out_f64) /* the raw canvas is the one BEFORE labels (osmt_render_scene_f64) */
         OSMT_LAUNCH_RASTER(true, false);
     else if (a.labels.info)
