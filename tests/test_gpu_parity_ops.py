@@ -410,3 +410,38 @@ def test_filter_groups_cut_by_slots_and_by_kept_records(gpu_ctx, oracle):
         if i % 7 == 0:
             tb.fill([(x0 - 9, y0 - 7), (x0 + 12, y0 - 3), (x0 + 2, y0 + 11), (x0 - 9, y0 - 7)], tuple(rnd.integers(0, 256, size=3)), 0.5)
     assert_parity(gpu_ctx, oracle, tb.build(), msg="filter groups")
+
+
+def test_small_batches_build_their_lists_in_the_raster_kernel(gpu_ctx, oracle):
+    """Batches of at most 64 tiles: tiles with at most 128 ops get no lists from k_sublist, their sub-tile waves read the op
+    bits themselves (k_raster<FOLD>).  One batch with tiles on both sides of the limit — 0, 1, 64, 65, 127, 128, 129 and 300
+    ops, fills, strokes and no-ops mixed so that list order matters — and the same tiles in a batch of 70 (lists for all)."""
+    from osm_renderer_amd import display_list
+
+    rnd = np.random.default_rng(23)
+
+    def tile(n_ops):
+        tb = TileBuilder(canvas=(250, 245, 230))
+        for i in range(n_ops):
+            p = rnd.integers(10, 246, size=2)
+            k = i % 4
+            if k == 0:
+                q = p + rnd.integers(-60, 61, size=2)
+                tb.stroke([p.tolist(), q.tolist()], float(rnd.choice([1.0, 2.5, 5.0])), tuple(rnd.integers(0, 256, size=3)), float(rnd.choice([1.0, 0.5])))
+            elif k == 1:
+                r = int(rnd.integers(5, 40))
+                tb.fill([(p[0] - r, p[1] - r), (p[0] + r, p[1] - r // 3), (p[0] + r // 2, p[1] + r), (p[0] - r, p[1] - r)],
+                        tuple(rnd.integers(0, 256, size=3)), float(rnd.choice([1.0, 0.6])))
+            elif k == 2:
+                tb.nop()
+            else:
+                pts = (p + np.cumsum(rnd.integers(-25, 26, size=(4, 2)), axis=0)).tolist()
+                tb.stroke(pts, 3.0, tuple(rnd.integers(0, 256, size=3)), 0.8, dashes=[6.0, 3.0], cap=CAPS[i % 4])
+        return tb.build()
+
+    tiles = [tile(n) for n in (0, 1, 64, 65, 127, 128, 129, 300)]
+    small = display_list.concat(tiles)
+    got_small = assert_parity(gpu_ctx, oracle, small, msg="small batch, lists folded")
+    big = display_list.concat(tiles + [tile(3) for _ in range(62)])  # 70 tiles: every tile has lists
+    got_big = assert_parity(gpu_ctx, oracle, big, f64_jobs=[5, 6], msg="the same tiles with lists")
+    assert np.array_equal(got_small, got_big[: len(tiles)])
