@@ -319,7 +319,7 @@ void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
         return nullptr; /* the caller falls back to per-array copies */
     }
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
-    ctx->host_cache.push_back({p, bytes, true});
+    ctx->host_cache.push_back({p, bytes, true, 0});
     return p;
 }
 
