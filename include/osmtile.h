@@ -385,6 +385,12 @@ int osmt_allreduce_tile_count_local(osmt_ctx* const* ctxs, uint32_t n_ctx, const
  * = the same stream read only — the ceiling of a read-dominated pass such as the layer composite.  bench.py quotes
  * roofline fractions against these next to the 8 TB/s datasheet figure. */
 int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy_gb_per_s, double* out_read_gb_per_s);
+/* 1 when the process runs with OSMT_POISON_ALLOC=1: every device buffer and every pinned staging buffer the library hands
+ * out — fresh or recycled from its caches — is filled with 0xA5 first.  The reference resets every pixel and pending entry
+ * per tile (src/draw/tile_pixels.rs:89-105); the library recycles buffers un-zeroed, so a kernel may only read what this
+ * render wrote.  The GPU tests and the fuzz run under it (tests/conftest.py); production leaves it off (one memset per
+ * allocation). */
+int osmt_debug_poison_enabled(void);
 
 #ifdef __cplusplus
 }

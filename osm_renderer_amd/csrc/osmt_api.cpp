@@ -217,7 +217,42 @@ size_t cache_keep_bytes() {
     return v;
 }
 
+/* OSMT_POISON_ALLOC=1 (tests/conftest.py, tools/fuzz_parity.py): every device buffer handed out — fresh from the driver or
+ * recycled from the cache — is filled with 0xA5 first, and every pinned staging buffer too.  The reference resets every
+ * pixel and every pending entry per tile (tile_pixels.rs:89-105); this library recycles its buffers un-zeroed, so whatever a
+ * kernel reads it must have been written by this render.  A fresh process sees zero pages from hipMalloc and hides a missing
+ * write (round 4's empty-tile list headers); under poison it reads 0xA5A5A5A5 and fails at once. */
+bool poison_alloc() {
+    static const bool v = [] {
+        const char* e = getenv("OSMT_POISON_ALLOC");
+        return e && *e && *e != '0';
+    }();
+    return v;
+}
+
+hipError_t stream_acquire(osmt_ctx* ctx, hipStream_t* out);
+void stream_release(osmt_ctx* ctx, hipStream_t st);
+
+hipError_t dev_poison(osmt_ctx* ctx, void* p, size_t bytes) {
+    hipStream_t st = nullptr;
+    hipError_t e = stream_acquire(ctx, &st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(p, 0xA5, bytes, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    stream_release(ctx, st);
+    return e;
+}
+
+hipError_t dev_alloc_raw(osmt_ctx* ctx, void** out, size_t bytes, size_t* got);
+
 hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
+    size_t got = 0;
+    hipError_t e = dev_alloc_raw(ctx, out, bytes, &got);
+    if (e == hipSuccess && poison_alloc()) e = dev_poison(ctx, *out, got);
+    return e;
+}
+
+hipError_t dev_alloc_raw(osmt_ctx* ctx, void** out, size_t bytes, size_t* got) {
     bytes = align_up(bytes ? bytes : 1, (size_t)2 << 20);
     {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
@@ -228,6 +263,7 @@ hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
             best->used = true;
             best->tick = ++ctx->cache_tick;
             *out = best->p;
+            *got = best->bytes;
             return hipSuccess;
         }
     }
@@ -248,6 +284,7 @@ hipError_t dev_alloc(osmt_ctx* ctx, void** out, size_t bytes) {
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     ctx->cache.push_back({*out, bytes, true, ++ctx->cache_tick});
+    *got = bytes;
     return hipSuccess;
 }
 
@@ -310,6 +347,7 @@ void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
             if (!c.used && c.bytes >= bytes && c.bytes <= 4 * bytes && (!best || c.bytes < best->bytes)) best = &c;
         if (best) {
             best->used = true;
+            if (poison_alloc()) memset(best->p, 0xA5, best->bytes);
             return best->p;
         }
     }
@@ -318,6 +356,7 @@ void* stage_acquire(osmt_ctx* ctx, size_t bytes) {
         (void)hipGetLastError();
         return nullptr; /* the caller falls back to per-array copies */
     }
+    if (poison_alloc()) memset(p, 0xA5, bytes);
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     ctx->host_cache.push_back({p, bytes, true, 0});
     return p;
@@ -858,7 +897,9 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool 
     /* (taking the worst case up to 2 GB instead — 1.8 GB for 1024 config-2 tiles — was tried to save this sizing run,
      * 0.14 ms of a 0.84 ms upload: no gain on one thread, and four worker threads' arenas then outgrow the buffer cache) */
     bool guessed = false;
-    if (worst_bytes > ((unsigned long long)32 << 20) && allow_guess) {
+    /* a guess needs the scene's error word: without one (more than ERR_SLOTS live scenes, or no pinned page) an overflow
+     * could not be seen and the call would return OSMT_OK with geometry missing — such a scene is sized exactly */
+    if (worst_bytes > ((unsigned long long)32 << 20) && allow_guess && s->h_err != nullptr) {
         /* A host-buffer call that follows others of its kind: the arenas from the densities the recent exact runs measured,
          * a quarter on top.  The kernels reserve with the same code as ever; if the guess is too small for this batch they
          * draw nothing for the ops that do not fit and say so in the scene's error word, and the call renders again with
@@ -2520,7 +2561,7 @@ struct coalesce_req {
     const osmt_label_batch* lb = nullptr;
     uint8_t* out = nullptr;
     size_t stride = 0;
-    bool taken = false, done = false;
+    bool taken = false, done = false, ran = false; /* ran: rendered on its own (rc is its verdict) */
     int rc = OSMT_OK;
     std::string err;
     coalesce_group* grp = nullptr; /* where the pixels are (NULL: already in `out`, or failed) */
@@ -2653,6 +2694,11 @@ int label_batch_shape_ok(const osmt_batch* b, const osmt_label_batch* lb) {
         if (lb->job_label_off[j + 1] < lb->job_label_off[j] || lb->job_label_off[j + 1] > lb->n_labels)
             return fail(OSMT_INVALID_ARG, "job_label_off not monotonic / out of range at tile %zu", j);
     if (lb->job_label_off[b->n_jobs] != lb->n_labels) return fail(OSMT_INVALID_ARG, "job_label_off[n_jobs] != n_labels");
+    /* a label's draw_line calls must lie in ITS request's pool: re-based into the merged pool an out-of-range seg_off would
+     * land in another request's calls and pass the merged check instead of failing alone */
+    for (size_t i = 0; i < lb->n_labels; ++i)
+        if ((unsigned long long)lb->labels[i].seg_off + lb->labels[i].n_segs > lb->n_segs)
+            return fail(OSMT_INVALID_ARG, "label %zu: seg_off + n_segs beyond the batch's draw_line calls", i);
     return OSMT_OK;
 }
 
@@ -2663,6 +2709,7 @@ void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
         r->rc = guarded([&] {
             return osmt_render_batch_labels_body(ctx, r->b, (r->lb && r->lb->n_labels) ? r->lb : nullptr, r->out, r->stride, true, true);
         });
+        r->ran = true;
         if (r->rc != OSMT_OK) r->err = osmt_last_error();
     };
     if (reqs.size() == 1) {
@@ -2703,7 +2750,12 @@ void coalesce_run_group(osmt_ctx* ctx, const std::vector<coalesce_req*>& reqs) {
         for (coalesce_req* r : reqs) run_alone(r);
         return;
     }
-    coalesce_group* g = new coalesce_group();
+    coalesce_group* g = new (std::nothrow) coalesce_group();
+    if (!g) {
+        stage_release(ctx, stage);
+        for (coalesce_req* r : reqs) run_alone(r);
+        return;
+    }
     g->ctx = ctx;
     g->stage = stage;
     g->pending.store((int)reqs.size());
@@ -2734,6 +2786,7 @@ int worker_render_body(osmt_worker* w, const osmt_batch* batch, const osmt_label
     me.out = out_rgb;
     me.stride = stride;
     std::vector<coalesce_req*> group;
+    group.reserve(CO_MAX_TILES); /* every request has at least one tile: push_back below cannot throw */
     {
         std::unique_lock<std::mutex> lk(ctx->co_mu);
         ctx->co_queue.push_back(&me);
@@ -2742,11 +2795,20 @@ int worker_render_body(osmt_worker* w, const osmt_batch* batch, const osmt_label
             if (!me.taken && ctx->co_in_flight < co_max_in_flight()) {
                 /* leader: everything that waits and fits, in arrival order (its own request is in there) */
                 size_t tiles = 0;
+                /* the merged pools are indexed with 32 bits and rendered without a second validation: a request that
+                 * would take any pool past 2^31 entries waits for the next leader (alone it is what its own validation saw) */
+                unsigned long long pool[7] = {0, 0, 0, 0, 0, 0, 0};
                 const osmt_batch* b0 = ctx->co_queue.front()->b;
                 while (!ctx->co_queue.empty()) {
                     coalesce_req* r = ctx->co_queue.front();
                     if (r->b->scale != b0->scale || r->b->coord_kind != b0->coord_kind) break; /* the next leader's */
                     if (!group.empty() && tiles + r->b->n_jobs > CO_MAX_TILES) break;
+                    const unsigned long long add[7] = {r->b->n_ops, r->b->n_rings, r->b->n_pts, r->b->n_nodes, r->b->n_dashes,
+                                                       r->lb ? r->lb->n_labels : 0ull, r->lb ? r->lb->n_segs : 0ull};
+                    bool fits32 = true;
+                    for (int k = 0; k < 7; ++k) fits32 = fits32 && pool[k] + add[k] < 0x7FFFFFFFull;
+                    if (!group.empty() && !fits32) break;
+                    for (int k = 0; k < 7; ++k) pool[k] += add[k];
                     tiles += r->b->n_jobs;
                     r->taken = true;
                     group.push_back(r);
@@ -2754,7 +2816,14 @@ int worker_render_body(osmt_worker* w, const osmt_batch* batch, const osmt_label
                 }
                 ++ctx->co_in_flight;
                 lk.unlock();
-                coalesce_run_group(ctx, group);
+                /* whatever happens in there, the group's members are marked done and the slot is given back: followers
+                 * wait on co_cv with no timeout */
+                try {
+                    coalesce_run_group(ctx, group);
+                } catch (...) {
+                    for (coalesce_req* r : group)
+                        if (!r->grp && !r->ran) r->rc = OSMT_OOM; /* (err stays empty: assigning a string could throw again) */
+                }
                 lk.lock();
                 --ctx->co_in_flight;
                 for (coalesce_req* r : group) r->done = true;
@@ -2841,6 +2910,8 @@ static int hbm_copy_probe_body(osmt_ctx* ctx, size_t bytes, uint32_t iters, doub
     if (out_read) *out_read = (double)(n16 * 16) * iters / ((double)ms_read * 1e-3) / 1e9;
     return OSMT_OK;
 }
+
+int osmt_debug_poison_enabled(void) { return poison_alloc() ? 1 : 0; }
 
 int osmt_hbm_copy_probe(osmt_ctx* ctx, size_t bytes, uint32_t iters, double* out_copy, double* out_read) {
     return guarded([&] { return hbm_copy_probe_body(ctx, bytes, iters, out_copy, out_read); });

@@ -1436,7 +1436,9 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
-    if (g_jobs[tile].n_ops <= g_fold_max_ops) return; /* k_raster's waves build the lists of such a tile themselves */
+    /* fold mode only (small batches): k_raster's waves build the lists of such a tile themselves.  With g_fold_max_ops == 0 EVERY
+     * tile gets its headers written here — an empty tile too (0 <= 0 used to skip it and k_raster read recycled memory) */
+    if (g_fold_max_ops != 0u && g_jobs[tile].n_ops <= g_fold_max_ops) return;
     const uint32_t W = OSMT_TILE_SIZE * g_scale;
     const uint32_t nsx = W / SUB;
     const uint32_t nsub = nsx * g_sub_rows;
@@ -1669,7 +1671,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         unsigned long long b0, b1;
         op_bits(&b0, &b1);
         hdr.y = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-    } else {
+    } else if (job.n_ops != 0u) {
+        /* a tile without ops is plain canvas (drawer.rs:60-131 with no areas): its headers are never looked at — a scene
+         * without any op has no list kernel launch at all */
         hdr = a.hdr[(size_t)tile * nsub + sub];
     }
 #if defined(OSMT_ABL) && OSMT_ABL == 8

@@ -28,6 +28,7 @@ EXPORTS = [
     "osmt_render_batch_multi_ex",
     "osmt_comm_unique_id", "osmt_comm_init_rank", "osmt_comm_init_local", "osmt_allreduce_tile_count",
     "osmt_allreduce_tile_count_local", "osmt_allreduce_tile_count_enqueue", "osmt_allreduce_tile_count_result", "osmt_hbm_copy_probe",
+    "osmt_debug_poison_enabled",
 ]
 
 

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# Every GPU test runs on POISONED device memory (include/osmtile.h: osmt_debug_poison_enabled): buffers the library hands
+# out are filled with 0xA5 first, so a kernel that reads something this render did not write cannot pass by reading the zero
+# pages of a fresh process (round 4's list headers of empty tiles).  Set before libosmtile.so is loaded; an explicit
+# OSMT_POISON_ALLOC=0 in the environment switches it off (timing runs).
+os.environ.setdefault("OSMT_POISON_ALLOC", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

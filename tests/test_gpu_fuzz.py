@@ -11,6 +11,8 @@ def test_fuzz_short(gpu_ctx, oracle):
 
     tiles, bad = fuzz_parity.run(budget=60.0, seed=2026, ctx=gpu_ctx, dump=False)
     assert tiles >= 60 and bad == 0
+    st = fuzz_parity.run.last_stats  # both raster instantiations, the list kernel and empty tiles were all in the run
+    assert st["folded_tiles"] > 0 and st["listed_tiles"] > 0 and st["empty_tiles"] > 0 and st["batches"].get(65, 0) > 0
 
 
 def test_fuzz_short_with_labels(gpu_ctx, oracle):

@@ -5,8 +5,14 @@
 
 Random tiles with adversarial parameters: widths 0..40, all directions, tiny / huge dashes, every
 cap, use_caps_for_dashes, scales 1..3, far-away and huge coordinates, self-intersecting and
-multi-ring fills, many ops.  Any differing pixel is printed with the op that was drawn last."""
+multi-ring fills, many ops.  Any differing pixel is printed with the op that was drawn last.
+
+Round 5: the batch size cycles through 1, 12, 64, 65 and 130 tiles, a tile has 0 .. 300 ops (one tile in ten has none), so
+every run drives BOTH raster instantiations — k_raster<FOLD> (batches of at most 64 tiles: tiles of at most 128 ops build
+their lists in the raster kernel, bigger ones get them from k_sublist) and k_sublist -> k_raster<false> (batches of more
+than 64 tiles) — and it runs on poisoned device memory (OSMT_POISON_ALLOC=1 unless the environment says otherwise)."""
 import os, sys, time
+os.environ.setdefault("OSMT_POISON_ALLOC", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from osm_renderer_amd import abi, display_list
@@ -33,10 +39,24 @@ def rand_pts(n, W, spread):
     return (p0 + np.cumsum(steps, axis=0)).tolist()
 
 
-def make_tile(scale, image_ids=()):
+BATCH_SIZES = (1, 12, 64, 65, 130)
+
+
+def rand_op_count():
+    u = rnd.random()
+    if u < 0.10:
+        return 0  # plain canvas (drawer.rs:60-131 with no areas)
+    if u < 0.80:
+        return int(rnd.integers(1, 40))
+    if u < 0.95:
+        return int(rnd.integers(40, 141))  # both sides of OSMT_FOLD_MAX_OPS = 128
+    return int(rnd.integers(141, 301))
+
+
+def make_tile(scale, image_ids=(), n_ops=None):
     W = 256 * scale
     tb = TileBuilder(scale=scale, canvas=None if rnd.random() < 0.2 else tuple(rnd.integers(0, 256, size=3)))
-    for _ in range(int(rnd.integers(1, 40))):
+    for _ in range(int(rnd.integers(1, 40)) if n_ops is None else n_ops):
         kind = rnd.random()
         col = tuple(rnd.integers(0, 256, size=3))
         op = float(rnd.choice([1.0, 1.0, 0.5, 0.25, 0.9, 0.0, 1.0 / 3.0]))
@@ -140,9 +160,21 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
             images[i] = img
     t0 = time.time()
     n_tiles = n_bad = 0
+    stats = {"batches": {}, "empty_tiles": 0, "folded_tiles": 0, "listed_tiles": 0}
+    it = 0
     while time.time() - t0 < budget:
-        scale = int(rnd.choice([1, 1, 2, 3]))
-        tiles = [make_tile(scale, image_ids) for _ in range(12)]
+        sizes_now = BATCH_SIZES[:4] if with_labels else BATCH_SIZES  # (the label oracle is the slow side: no 130-tile label batches)
+        bs = sizes_now[it % len(sizes_now)]
+        it += 1
+        scale = int(rnd.choice([1, 1, 2, 3])) if bs <= 12 else int(rnd.choice([1, 1, 1, 2]))
+        counts = [rand_op_count() for _ in range(bs)]
+        if bs > 12:  # the oracle renders these too: mostly short lists in the big batches, a few long ones
+            counts = [c if (c <= 40 or k % 9 == 0) else c % 40 for k, c in enumerate(counts)]
+        tiles = [make_tile(scale, image_ids, c) for c in counts]
+        stats["batches"][bs] = stats["batches"].get(bs, 0) + 1
+        stats["empty_tiles"] += sum(1 for c in counts if c == 0)
+        stats["folded_tiles"] += sum(1 for c in counts if bs <= 64 and c <= 128)
+        stats["listed_tiles"] += sum(1 for c in counts if bs > 64 or c > 128)
         dl = display_list.concat(tiles)
         ll = make_labels(len(tiles), scale, image_ids, sizes) if with_labels else None
         if ll is not None:
@@ -176,7 +208,12 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
                         one = ll.subset([i])
                         np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_labels.npy", one.labels)
                         np.save(f"gpurun_out/fuzz_bad_{seed}_{n_tiles}_{i}_segs.npy", one.segs)
-    print(f"fuzz: {n_tiles} tiles in {time.time() - t0:.0f} s, {n_bad} mismatching tiles (seed {seed})")
+    from osm_renderer_amd.lib import load as _load
+
+    print(f"fuzz: {n_tiles} tiles in {time.time() - t0:.0f} s, {n_bad} mismatching tiles (seed {seed}, labels {bool(with_labels)}, "
+          f"poison {_load().osmt_debug_poison_enabled()}); batches by size {dict(sorted(stats['batches'].items()))}, "
+          f"{stats['empty_tiles']} empty tiles, {stats['folded_tiles']} tiles through k_raster<FOLD>, {stats['listed_tiles']} through k_sublist")
+    run.last_stats = stats
     return n_tiles, n_bad
 
 
