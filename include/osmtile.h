@@ -246,7 +246,8 @@ int osmt_render_scene_stages(osmt_ctx* ctx, osmt_scene* scene, uint32_t stage_ma
  * BEFORE labels. */
 int osmt_scene_set_labels(osmt_ctx* ctx, osmt_scene* scene, const osmt_label_batch* labels);
 /* Label statuses of the last osmt_render_scene (label_generation_statuses,
- * tile_pixels.rs:160-162): ok[i] = 1 if label i succeeded.  Synchronises the stream. */
+ * tile_pixels.rs:160-162): ok[i] = 1 if label i succeeded.  Synchronises the stream.  Before the first render after
+ * osmt_scene_set_labels every status is 0 (nothing has been placed yet). */
 int osmt_scene_read_label_status(osmt_ctx* ctx, osmt_scene* scene, uint8_t* ok);
 /* Waits for the launches that read the scene (not for the device) and reports what they could not report themselves:
  * osmt_render_scene is asynchronous, so a kernel-side internal error — a pre-pass arena that does not fit, which the

@@ -1478,7 +1478,12 @@ static int osmt_scene_set_labels_body(osmt_ctx* ctx, osmt_scene* sc, const osmt_
     if (e == hipSuccess) e = up(sc->d_lab_segs, lb->segs, lb->n_segs * 32);
     if (e == hipSuccess) e = up(sc->d_lab_wide, wide.data(), wide.size() * 4);
     if (e == hipSuccess) e = up(sc->d_lab_bands, bands.data(), bands.size() * sizeof(osmt_label_band));
-    /* the verdicts and the error word are cleared by the label stage itself, on the render stream (osmt_launch_labels) */
+    /* The verdicts and the error word are cleared by the label stage itself, on the render stream (osmt_launch_labels).
+     * Until the first render with these labels they read "no label has been placed, no error": a status read between
+     * osmt_scene_set_labels and the next render used to return whatever the recycled buffer held (found by the poisoned
+     * allocator in round 5: error word 0xA5A5A5A5). */
+    if (e == hipSuccess)
+        e = st ? hipMemsetAsync(base + o_ok, 0, o_err + 4 - o_ok, st) : hipMemset(base + o_ok, 0, o_err + 4 - o_ok);
     if (e != hipSuccess) {
         dev_free(ctx, sc->d_lab_base);
         sc->d_lab_base = nullptr;

@@ -167,3 +167,22 @@ def test_reference_icons_as_fill_patterns_and_label_icons(gpu_ctx, oracle):
     got, st = _check(gpu_ctx, oracle, dl, tl.build(), all_imgs, "reference icons")
     assert st.tolist() == [1, 1, 0, 1]
     assert len(np.unique(got[0].reshape(-1, 4), axis=0)) > 50
+
+
+def test_label_status_before_the_first_render_is_all_zero(gpu_ctx, oracle):
+    """osmt_scene_read_label_status between osmt_scene_set_labels and the next render: nothing has been placed yet, so
+    every status is 0 and there is no error — not whatever the recycled label buffer held (the poisoned allocator of
+    tests/conftest.py turned that into "label coverage window overflow (internal error 0xA5A5A5A5)" in round 5)."""
+    dl = synth.config2(3)
+    ll = labels.make_labels(3, labels_per_tile=7, seed=5)
+    scene = gpu_ctx.upload(dl)
+    gpu_ctx.render(scene).cpu()
+    scene.set_labels(ll)
+    st0 = scene.label_status()
+    assert st0.shape == (len(ll.labels),) and not st0.any()
+    got = gpu_ctx.render(scene).cpu().numpy()
+    want, wst = oracle.render_batch(dl, threads=3, labels=ll, want_status=True)
+    assert np.array_equal(scene.label_status(), wst) and np.array_equal(got, want)
+    scene.set_labels(ll)  # attached again: the old verdicts are gone with the old buffers
+    assert not scene.label_status().any()
+    scene.free()
