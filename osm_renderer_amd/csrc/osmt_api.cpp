@@ -145,6 +145,7 @@ struct osmt_scene {
     double* d_trav = nullptr;
     double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
+    osmt_dash_seg* d_dseg = nullptr;
     uint32_t* d_submask = nullptr;
     uint32_t* d_op_blk = nullptr;
     uint32_t* d_op_vseg = nullptr; /* op -> its first virtual segment (stroke ops with segments) */
@@ -166,6 +167,7 @@ struct osmt_scene {
     uint32_t* d_fmask = nullptr;
     osmt_srec* d_srec = nullptr;
     uint2* d_skey = nullptr;
+    uint32_t* d_cellcnt = nullptr;    /* per (stroke op, cell of its window): records in that sub-tile's region (sorted layout) */
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
     std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_vseg, h_op_job, h_lab_wide;
@@ -709,6 +711,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.den = sc->d_den;
     a.rden = sc->d_rden;
     a.aux = sc->d_aux;
+    a.dseg = sc->d_dseg;
     a.blk = sc->d_blk;
     a.submask = sc->d_submask;
     a.cand_off = sc->d_cand_off;
@@ -720,6 +723,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.fmask = sc->d_fmask;
     a.srec = sc->d_srec;
     a.skey = sc->d_skey;
+    a.cellcnt = sc->d_cellcnt;
     a.fmask_cap = sizing ? 0ull : sc->fmask_cap;
     a.srec_cap = sizing ? 0ull : sc->srec_cap;
     a.err = sizing ? nullptr : sc->h_err; /* hipHostMallocMapped memory: one address on both sides (unified addressing) */
@@ -790,6 +794,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.n_jobs = n_render;
         a.scale = sc->scale;
         a.aux = sc->d_aux;
+        a.dseg = sc->d_dseg;
         {
             const uint32_t Wt = OSMT_TILE_SIZE * sc->scale;
             a.hdr = sc->d_hdr + (size_t)first_job * (Wt / OSMT_SUB_W) * (Wt / OSMT_SUB_H);
@@ -798,6 +803,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
+        a.cellcnt = sc->d_cellcnt;
         a.info = sc->d_info;
         a.submask = sc->d_submask;
         a.fold_max_ops = sc->n_jobs <= OSMT_FOLD_MAX_JOBS ? OSMT_FOLD_MAX_OPS : 0u; /* the same rule as the pre-pass (prepass_args) */
@@ -950,6 +956,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool 
     const size_t o_f = carve((size_t)(groups + 1) * 64);
     const size_t o_r = carve((size_t)(recs + 1) * sizeof(osmt_srec));
     const size_t o_k = carve((size_t)(recs + 1) * 8);
+    const size_t o_c = carve((size_t)(recs + 1) * 4); /* cell counters of the sorted stroke layout: an op has at most as many cells as records */
     const size_t o_e = carve((size_t)(ents + 1) * sizeof(osmt_ent));
     hipError_t e = dev_alloc(ctx, (void**)&s->d_arena, off + 256);
     if (e != hipSuccess) {
@@ -959,6 +966,7 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool 
     s->d_fmask = (uint32_t*)(s->d_arena + o_f);
     s->d_srec = (osmt_srec*)(s->d_arena + o_r);
     s->d_skey = (uint2*)(s->d_arena + o_k);
+    s->d_cellcnt = (uint32_t*)(s->d_arena + o_c);
     s->d_ent = (osmt_ent*)(s->d_arena + o_e);
     s->ent_cap = ents + 1;
     s->fmask_cap = groups + 1; /* never 0: 0 means "sizing pass" to the kernels */
@@ -1123,6 +1131,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t o_trav = carve((n_vsegs + 1) * 8);
     const size_t o_den = carve((n_vsegs + 1) * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
+    const size_t o_dseg = carve((size_t)(n_strokes + 1) * OSMT_MAX_DASH_SEGS * sizeof(osmt_dash_seg)); /* touched by dashed ops only */
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
@@ -1155,6 +1164,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_trav = (double*)(s->d_base + o_trav);
     s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
+    s->d_dseg = (osmt_dash_seg*)(s->d_base + o_dseg);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
     s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
     s->d_op_vseg = (uint32_t*)(s->d_base + o_opvseg);

@@ -25,40 +25,55 @@ struct osmt_dash_seg {
     double r_start, r_end; /* RN(1 / (start_to - start_from)), RN(1 / (end_to - end_from)): the two ramp divisions as osmt_div_exact */
 };
 
-/* OpacityCalculator minus half_line_width/traveled (opacity_calculator.rs:3-8) */
-struct osmt_dash_table {
-    int32_t n_segs;
-    int32_t has_orig; /* line cap is Round: original_endpoints = Some(..) */
-    double total_len;
-    double r_total;   /* RN(1 / total_len): quotient estimate of the exact `dist_rem % total_len` */
-    osmt_dash_seg segs[OSMT_MAX_DASH_SEGS];
-};
-
-/* the two calculators of draw_lines (line.rs:21-22) */
-/* A cap stub of draw_lines (line.rs:33-57): p1 -> p1.push_away_from(p2, half_width) of the first
- * edge, p2 -> p2.push_away_from(p1, half_width) of the last one; computed once per op. */
+/* A cap stub of draw_lines (line.rs:33-57): p1 -> p1.push_away_from(p2, half_width) of the first edge, p2 ->
+ * p2.push_away_from(p1, half_width) of the last one; k_opinfo's working record (the stubs reach the binning kernel as the op's
+ * last two virtual segments). */
 struct osmt_cap_seg {
     int32_t p1x, p1y, p2x, p2y;
     int32_t valid; /* the edge is not degenerate and the cap is Round/Square */
-    uint32_t cand_off; /* first slot of the stub's sub-tile window in the op's slice of the stroke arena */
+    uint32_t cand_off; /* first slot of the stub's sub-tile window in the op's slice of the stroke arena (legacy layout) */
     double denom;  /* center_dist_denom of the stub */
 };
 
-struct osmt_stroke_aux {
+/* The per-op constants of a STROKE op (k_opinfo -> k_raster): 192 bytes, written as three whole 64-byte lines.
+ * draw_lines builds two OpacityCalculators (line.rs:21-22): `main` for the edges — its DashSegments (up to
+ * OSMT_MAX_DASH_SEGS, only when the op has dashes) live in a table of their own, osmt_*_args::dseg[aux index][..], so that an
+ * un-dashed op writes and reads nothing of it — and the one for the outer cap stubs, which always has exactly ONE segment
+ * (compute_segments over dashes = [0.0]) and total_len 0.  (Until round 4 the record held both tables in full, 1608 bytes,
+ * and the cap stubs a second time: k_opinfo wrote five partial cache lines per stroke op — most of its 1.9 GB on config 5.) */
+struct alignas(64) osmt_stroke_aux {
     double half_width;
-    osmt_cap_seg cap_seg[2];
     /* get_opacity_by_center_distance terms for cap_dist == 0 (opacity_calculator.rs:36,171-176):
      * hlw0 = sqrt(h*h - 0*0), feather_from/to/dist and opacity_mul of hlw0 */
     double hlw0, ff0, ft0, fd0, mul0;
     double rfd0; /* RN(1 / fd0): the feather division of the walk becomes osmt_div_exact */
-    osmt_dash_table main;
-    osmt_dash_table caps;
+    /* OpacityCalculator `main` minus half_line_width / traveled (opacity_calculator.rs:3-8) */
+    int32_t main_n_segs;
+    int32_t main_has_orig; /* line cap is Round and use_caps_for_dashes: original_endpoints = Some(..) */
+    double main_total_len;
+    double main_r_total;   /* RN(1 / total_len): quotient estimate of the exact `dist_rem % total_len` */
+    /* opacity_calculator_for_outer_caps: n_segs == 1, total_len == 0 */
+    int32_t caps_has_orig;
+    int32_t _pad;
+    osmt_dash_seg caps_seg;
 };
+static_assert(sizeof(osmt_stroke_aux) == 192, "three 64-byte lines");
 
 /* Everything k_raster needs to start on an op, in ONE 64-byte record (one s_load_dwordx16): the op header fields it
  * uses and the results of the pre-pass — k_raster never touches ops, rings or points. */
 struct osmt_opinfo {
-    int32_t x0, y0, x1, y1; /* inclusive extent of the op's points (empty: x0 > x1) */
+    union {
+        struct {
+            int32_t x0, y0, x1, y1; /* FILL: inclusive extent of the op's points (empty: x0 > x1) */
+        };
+        struct {
+            /* STROKE with the SORTED record layout (swin != 0): the op's sub-tile window — the union of its segments'
+             * windows — wx0 | wy0 << 8 | wcols << 16 | wrows << 24, the first of its wcols * wrows cell counters
+             * (osmt_prepass_args::cellcnt) and the records every cell's region has room for (= the op's virtual segments:
+             * a segment leaves at most one record per sub-tile).  swin == 0: the legacy slot layout (see osmt_srec). */
+            uint32_t swin, cell_off, stride, _spare;
+        };
+    };
     uint32_t aux;           /* STROKE: index into the stroke_aux table */
     uint32_t n_edges;       /* total edges over all rings */
     uint32_t first_pt;      /* first point of the op's FIRST ring: a one-ring polygon is binned without touching osmt_op / osmt_ring */
@@ -87,11 +102,23 @@ static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record
  * fill.rs:23-45).  Group index = arena_off + (sr - sr0) * ncols + (c - c0).  Written by k_fill_rows once per op — the
  * rows of an op are evaluated ONCE per tile, not once per sub-tile column.
  *
- * Stroke arena: one SLOT per (virtual segment, sub-tile of its window), written by k_stroke_bin: the step ranges of
- * the segment's perpendicular runs for that sub-tile when it can draw there, a hole otherwise.  The slots of one op
- * are contiguous (arena_off .. + rec_cap) and in segment order — no atomics, the layout is a pure function of the
- * scene; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
- * one coalesced load. */
+ * Stroke arena, SORTED layout (round 5; every op whose window cells x virtual segments fit OSMT_SORT_MAX_SLOTS): the
+ * op owns one REGION of `stride` records per sub-tile (cell) of its window, region of cell c = arena_off + c * stride.
+ * The lane of k_prebin that finds that a segment draws into a sub-tile takes the next free record of that cell's region
+ * (atomicAdd on the cell's counter: inside one op — one generation, set_pixel keeps the larger alpha — the order of
+ * the records is irrelevant) and writes it there; nothing is written for a sub-tile the segment cannot reach.  k_sublist
+ * puts (region, count) into the op's list entry for that sub-tile, so k_raster fetches exactly the records of its own
+ * sub-tile with ONE level of loads — until round 4 it read the 8-byte keys of ALL slots of the op (a polyline of five
+ * edges and two stubs: ~90, two or three of them its own) and then the records: two dependent round trips and ~330
+ * instructions per group of ops, a quarter of the kernel.  A cap stub's record carries traveled = -0.0 (an edge's is
+ * >= +0.0; -0.0 + sd == +0.0 + sd for every sd >= 0, so the arithmetic of the walk cannot tell).
+ *
+ * LEGACY layout (long ways: an op of 60 segments across a whole tile would reserve 128 regions of 62 records): one SLOT
+ * per (virtual segment, sub-tile of its window): the step ranges of the segment's perpendicular runs for that sub-tile
+ * when it can draw there, a hole otherwise.  The slots of one op are contiguous (arena_off .. + rec_cap) and in segment
+ * order; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
+ * one coalesced load (k_raster: SEGCAP slots per round). */
+#define OSMT_SORT_MAX_SLOTS 4096u
 struct alignas(16) osmt_srec {
     int32_t p1x, p1y, p2x, p2y;
     double traveled;      /* line.rs:31, before this edge (0 for a cap stub) */
@@ -115,15 +142,16 @@ struct osmt_blk_bbox {
  * k_raster needs to start on it resolved for THAT sub-tile.  k_raster then streams its own short list instead of
  * scanning the op bits of the whole tile (config 5: 9000 bits for ~100 drawing ops) and never touches osmt_opinfo. */
 struct alignas(16) osmt_ent {
-    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first slot of the op */
+    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first record of THIS sub-tile's region (legacy layout: first slot of the op) */
     uint32_t kind_color; /* kind | r << 8 | g << 16 | b << 24 */
     double opacity;
     uint32_t aux;        /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
-    uint32_t nv;         /* STROKE: slots of the op in the stroke arena (rec_cap) */
+    uint32_t nv;         /* STROKE: records of the op in THIS sub-tile (legacy layout: slots of the op in the stroke arena, rec_cap) */
     uint32_t stage;      /* k_raster's own use while the entry sits in LDS */
-    uint32_t _pad;
+    uint32_t flags;      /* OSMT_ENT_LEGACY */
 };
 static_assert(sizeof(osmt_ent) == 32, "osmt_ent is two 16-byte loads");
+#define OSMT_ENT_LEGACY 1u /* STROKE: slots + keys instead of per-sub-tile regions */
 
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
@@ -228,6 +256,7 @@ struct osmt_raster_args {
     uint32_t n_jobs;
     uint32_t scale;
     const osmt_stroke_aux* aux;
+    const osmt_dash_seg* dseg; /* [stroke][OSMT_MAX_DASH_SEGS]: DashSegments of the `main` calculators (dashed ops only) */
     const uint2* hdr;        /* [n_jobs][nsub]: (first entry, entry count) of the sub-tile's list (k_sublist) */
     const osmt_ent* ent;     /* the lists */
     const uint32_t* fmask;   /* fill arena (words) */
@@ -237,7 +266,8 @@ struct osmt_raster_args {
     uint32_t _pad1;
     const osmt_opinfo* info;
     const uint32_t* submask; /* [op][sub-tile row]: bit sx = the op draws into sub-tile (sx, row) */
-    const uint2* skey;       /* per stroke slot: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
+    const uint2* skey;       /* legacy stroke slots: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
+    const uint32_t* cellcnt; /* sorted stroke layout: records per (op, cell of its window) */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -271,6 +301,7 @@ struct osmt_prepass_args {
     double* den;
     double* rden;
     osmt_stroke_aux* aux;
+    osmt_dash_seg* dseg; /* [stroke][OSMT_MAX_DASH_SEGS] */
     osmt_blk_bbox* blk;
     uint32_t* submask;
     uint32_t* cand_off; /* per virtual segment: first slot (relative to the op) of the edge's sub-tile window */
@@ -279,7 +310,7 @@ struct osmt_prepass_args {
      * the edge / cap stub (p1 == p2: draws nothing) and its op, bit 31 = the segment is a cap stub */
     int4* vpts;
     uint32_t* vop;
-    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries; zeroed by the launcher */
+    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries, [3] cell counters; zeroed by the launcher */
     uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
     uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */
     osmt_ent* ent;      /* list arena */
@@ -287,6 +318,7 @@ struct osmt_prepass_args {
     uint32_t* fmask;
     osmt_srec* srec;
     uint2* skey;
+    uint32_t* cellcnt;  /* [srec_cap]: per (stroke op, cell of its sub-tile window) the records written so far (sorted layout); zeroed by k_opinfo */
     unsigned long long fmask_cap, srec_cap; /* arena capacities (groups / records); 0 = sizing pass: only the cursors are produced */
     /* host-mapped (pinned, coherent) word of the scene, or NULL: a kernel whose arena reservation does not fit — it cannot,
      * the arenas are sized by the same code; a future change to the binning that breaks the invariant must not show as

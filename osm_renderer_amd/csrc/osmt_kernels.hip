@@ -126,9 +126,10 @@ __device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by)
     return r;
 }
 
-/* opacity_calculator.rs:98-143 compute_segments, for one calculator. */
-__device__ void compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap,
-                                 osmt_dash_table* t) {
+/* opacity_calculator.rs:98-143 compute_segments, for one calculator: the first `max_out` segments go to `segs`, the number
+ * of segments the reference pushes is returned. */
+__device__ __forceinline__ int compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap, osmt_dash_seg* segs, int max_out,
+                                double* total_len) {
     double len_before = 0.0;
     int n = 0;
     for (int it = 0; it <= n_dashes; ++it) {
@@ -153,12 +154,11 @@ __device__ void compute_segments(double hlw, const double* __restrict__ dashes, 
         s.opacity_mul = fmin(end - start, 1.0);
         s.r_start = 1.0 / (s.start_to - s.start_from); /* both ramps are 1 px long up to a rounding: finite */
         s.r_end = 1.0 / (s.end_to - s.end_from);
-        t->segs[n++] = s;
+        if (n < max_out) segs[n] = s;
+        ++n;
     }
-    t->n_segs = n;
-    t->has_orig = (cap == OSMT_CAP_ROUND) ? 1 : 0;
-    t->total_len = len_before;
-    t->r_total = 1.0 / len_before; /* used only when total_len > 0 */
+    *total_len = len_before;
+    return n;
 }
 
 /* Sub-tiles a virtual segment (an edge or a cap stub) can draw into: every pixel it sets lies within t_extra pixels
@@ -252,6 +252,17 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     const bool caps = is_stroke && (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
     osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0u, 1.0}, c1 = {0, 0, 0, 0, 0, 0u, 1.0};
     unsigned long long cand = 0ull; /* slots reserved so far: one per (virtual segment, sub-tile of its window) */
+    int32_t ux0 = INT32_MAX, uy0 = INT32_MAX, ux1 = INT32_MIN, uy1 = INT32_MIN; /* union of the segments' sub-tile windows */
+    auto add_window = [&](const SubWindow& w) -> uint32_t {
+        const uint32_t wc = window_count(w);
+        if (wc) {
+            ux0 = min(ux0, w.sx0);
+            ux1 = max(ux1, w.sx1);
+            uy0 = min(uy0, w.sy0);
+            uy1 = max(uy1, w.sy1);
+        }
+        return wc;
+    };
     double traveled = 0.0;
     uint32_t seen = 0; /* running edge index + 1 over all rings (point_pairs.rs:36-40) */
     /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     a.vpts[e] = make_int4(prev.x, prev.y, p.x, p.y);
                     a.vop[e] = o;
                     if (!(prev.x == p.x && prev.y == p.y)) { /* a degenerate edge draws nothing (line.rs:73-75) */
-                        cand += window_count(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
+                        cand += add_window(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
                         /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
                          * degenerate (`first` is consumed by a degenerate first edge) */
                         if (caps && seen == 1u) {
@@ -327,21 +338,18 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
      * offsets from a prefix scan): 2.3 M single-lane atomics on two addresses were what bounded this kernel on the
      * dense config (~1 atomic per clock at the L2) ---- */
     unsigned long long want_f = 0ull, want_s = 0ull; /* fill groups / stroke slots this op reserves */
+    uint32_t want_c = 0u;                             /* cell counters (sorted stroke layout) */
     uint32_t fill_geom_ok = 0u;
     if (is_stroke) {
-        osmt_stroke_aux* sa = &a.aux[oi.aux];
-        sa->half_width = hw;
         /* a stub that push_away_from rounds back onto its own start draws nothing (line.rs:73-75) */
         if (c0.valid && (c0.p1x != c0.p2x || c0.p1y != c0.p2y)) {
             c0.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-            cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
+            cand += add_window(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
         }
         if (c1.valid && (c1.p1x != c1.p2x || c1.p1y != c1.p2y)) {
             c1.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-            cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
+            cand += add_window(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
         }
-        sa->cap_seg[0] = c0;
-        sa->cap_seg[1] = c1;
         if (caps) { /* the two stubs are the op's last two virtual segments; an invalid one is stored degenerate (p1 == p2) */
             const osmt_cap_seg* cs[2] = {&c0, &c1};
 #pragma unroll
@@ -356,30 +364,57 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                 a.cand_off[e] = cs[i]->cand_off;
             }
         }
-        sa->hlw0 = sqrt(hw * hw - 0.0 * 0.0);
-        sa->ff0 = fmax(sa->hlw0 - 0.5, 0.0);
-        sa->ft0 = fmax(sa->hlw0 + 0.5, 1.0);
-        sa->fd0 = sa->ft0 - sa->ff0;
-        sa->rfd0 = 1.0 / sa->fd0;
-        sa->mul0 = fmin(2.0 * sa->hlw0, 1.0);
+        /* the op's constants: built in registers, stored as three whole lines */
+        osmt_stroke_aux sv;
+        sv.half_width = hw;
+        sv.hlw0 = sqrt(hw * hw - 0.0 * 0.0);
+        sv.ff0 = fmax(sv.hlw0 - 0.5, 0.0);
+        sv.ft0 = fmax(sv.hlw0 + 0.5, 1.0);
+        sv.fd0 = sv.ft0 - sv.ff0;
+        sv.rfd0 = 1.0 / sv.fd0;
+        sv.mul0 = fmin(2.0 * sv.hlw0, 1.0);
         const int cap_for_dashes = op.use_caps_for_dashes ? op.cap : OSMT_CAP_NONE;
+        sv.main_n_segs = 0;
+        sv.main_has_orig = 0;
+        sv.main_total_len = 0.0;
+        sv.main_r_total = 0.0;
         if (op.has_dashes) {
-            compute_segments(hw, a.dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes, &sa->main);
-        } else {
-            sa->main.n_segs = 0;
-            sa->main.has_orig = 0;
-            sa->main.total_len = 0.0;
-            sa->main.r_total = 0.0;
+            sv.main_n_segs = compute_segments(hw, a.dashes + op.dashes_off, (int)op.n_dashes, cap_for_dashes,
+                                              a.dseg + (size_t)oi.aux * OSMT_MAX_DASH_SEGS, OSMT_MAX_DASH_SEGS, &sv.main_total_len);
+            sv.main_has_orig = (cap_for_dashes == OSMT_CAP_ROUND) ? 1 : 0;
+            sv.main_r_total = 1.0 / sv.main_total_len; /* used only when total_len > 0 */
         }
+        /* the chained (0..1) pass of compute_segments pushes the same segment twice for dashes = [0.0]; max / min over two
+         * equal entries equals one entry: one is kept */
         const double zero = 0.0;
-        compute_segments(hw, &zero, 1, op.cap, &sa->caps);
-        /* the chained (0..1) pass pushes the same segment twice; max/min over two equal
-         * entries equals one entry, keep one */
-        sa->caps.n_segs = 1;
+        double caps_total;
+        (void)compute_segments(hw, &zero, 1, op.cap, &sv.caps_seg, 1, &caps_total);
+        sv.caps_has_orig = (op.cap == OSMT_CAP_ROUND) ? 1 : 0;
+        sv._pad = 0;
+        a.aux[oi.aux] = sv;
         if (cand > 0xFFFFFFFFull) cand = 0xFFFFFFFFull; /* cannot happen below 2^32 records per scene (checked by the host) */
         oi.rec_cap = (uint32_t)cand;
         oi.stroke_ft = ft;
         want_s = cand;
+        /* Record layout (osmt_internal.h): SORTED — one region of `stride` records per sub-tile of the op's window, so that
+         * k_raster finds the records of its sub-tile without looking at the others' — whenever the regions stay small;
+         * long ways keep the slot + key layout.  The extent fields of the record are a fill's: a stroke keeps its window there. */
+        oi.swin = 0u;
+        oi.cell_off = 0u;
+        oi.stride = 0u;
+        oi._spare = 0u;
+        if (cand != 0ull && ux0 <= ux1) {
+            const uint32_t wcols = (uint32_t)(ux1 - ux0 + 1), wrows = (uint32_t)(uy1 - uy0 + 1);
+            const uint32_t n_vs = n_edges + (caps ? 2u : 0u);
+            const unsigned long long slots = (unsigned long long)wcols * wrows * n_vs;
+            if (slots <= (unsigned long long)OSMT_SORT_MAX_SLOTS) {
+                oi.swin = (uint32_t)ux0 | ((uint32_t)uy0 << 8) | (wcols << 16) | (wrows << 24);
+                oi.stride = n_vs;
+                oi.rec_cap = (uint32_t)slots;
+                want_s = slots;
+                want_c = wcols * wrows;
+            }
+        }
     } else if (!none) {
         /* fills: rows ytop+1 .. ybot carry records (fill.rs:66-72), spans lie inside the points' x range */
         const int32_t ylo = max(oi.y0 + 1, 0), yhi = min(oi.y1, W - 1);
@@ -398,14 +433,19 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         const uint32_t s_lo = (uint32_t)want_s & 0xFFFFu, s_hi = (uint32_t)(want_s >> 16);
         const uint32_t f_incl = wave_incl_scan(f);
         const unsigned long long s_incl = ((unsigned long long)wave_incl_scan(s_hi) << 16) + wave_incl_scan(s_lo);
+        const uint32_t c_incl = wave_incl_scan(want_c); /* at most 2048 cells per op */
+        const uint32_t c_tot = (uint32_t)__builtin_amdgcn_readlane((int)c_incl, OPINFO_THREADS - 1);
         const uint32_t f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_incl, OPINFO_THREADS - 1);
         const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), OPINFO_THREADS - 1) << 32) |
                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, OPINFO_THREADS - 1);
-        unsigned long long f_base = 0ull, s_base = 0ull;
+        unsigned long long f_base = 0ull, s_base = 0ull, c_base = 0ull;
         if (lane == 0u) {
             if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
             if (s_tot) s_base = atomicAdd(&a.cursors[1], s_tot);
+            if (c_tot) c_base = atomicAdd(&a.cursors[3], (unsigned long long)c_tot);
         }
+        c_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c_base >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c_base);
         f_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f_base >> 32)) << 32) |
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f_base);
         s_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_base >> 32)) << 32) |
@@ -413,9 +453,15 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         if (want_s) {
             const unsigned long long off = s_base + (s_incl - want_s);
             oi.arena_off = (uint32_t)off;
-            if (a.srec_cap && off + want_s > a.srec_cap) { /* never: the arena was sized by this same code */
+            /* the cell counters share the arena's capacity: an op has at most as many cells as records */
+            const unsigned long long c_off = c_base + (c_incl - want_c);
+            if (a.srec_cap && (off + want_s > a.srec_cap || c_off + want_c > a.srec_cap)) { /* never: the arena was sized by this same code */
                 oi.rec_cap = 0;
                 if (a.err) *(volatile uint32_t*)a.err = OSMT_PREPASS_ERR_STROKE_ARENA;
+            } else if (want_c) {
+                oi.cell_off = (uint32_t)c_off;
+                if (a.srec_cap) /* (not in the sizing pass) every cell starts empty */
+                    for (uint32_t i = 0; i < want_c; ++i) a.cellcnt[c_off + i] = 0u;
             }
         }
         if (want_f) {
@@ -507,7 +553,7 @@ constexpr uint32_t STROKE_PLAIN_MAIN = 1u; /* the main calculator has no dash se
 constexpr uint32_t STROKE_UNIT_FD = 2u;    /* feather_dist == 1.0 exactly */
 constexpr uint32_t STROKE_TINY_MUL = 4u;   /* opacity_mul below 1e-100 (or NaN): no shortcut may assume mul0 * v > 0 */
 __device__ __forceinline__ uint32_t stroke_flags(const osmt_stroke_aux* __restrict__ sa) {
-    return (sa->main.n_segs == 0 ? STROKE_PLAIN_MAIN : 0u) | (sa->fd0 == 1.0 ? STROKE_UNIT_FD : 0u) |
+    return (sa->main_n_segs == 0 ? STROKE_PLAIN_MAIN : 0u) | (sa->fd0 == 1.0 ? STROKE_UNIT_FD : 0u) |
            (sa->mul0 >= 1e-100 ? 0u : STROKE_TINY_MUL);
 }
 #ifndef OSMT_V_STAGECAP
@@ -529,13 +575,9 @@ struct alignas(8) SegDer {
 static_assert(sizeof(SegDer) == 40, "five 8-byte LDS words");
 constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_CAP = 8u, SEGW_SLOW = 16u;
 
-#ifndef OSMT_V_FILTCAP
-#define OSMT_V_FILTCAP 256
-#endif
-constexpr uint32_t FILTCAP = OSMT_V_FILTCAP; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
 struct RasterShared {
-    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] filter passes of groups [4] groups ended by the
-                                * 33rd kept record [5] fill visits [6] ops with more than SEGCAP records in the sub-tile [7] ops with more than FILTCAP slots */
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] record fetches of groups [5] fill visits
+                                * [7] entries walked alone (legacy layout, or more than SEGCAP records in the sub-tile) */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     SegDer der[SEGCAP];
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
@@ -548,8 +590,6 @@ struct RasterShared {
 #endif
 };
 static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
-static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP % 256u == 0u,
-              "the filter pass borrows seg[] for its entry marks (one 4-byte store per lane) and der[] for the kept slots");
 
 struct SubRect {
     int32_t x0, y0, x1, y1; /* inclusive */
@@ -569,6 +609,30 @@ __device__ __forceinline__ void blend_rgb(double* acc, double sr, double sg, dou
     acc[0] = sr + k * acc[0];
     acc[1] = sg + k * acc[1];
     acc[2] = sb + k * acc[2];
+}
+
+/* The lane id as a value the compiler cannot connect to its earlier uses: addresses derived from it (output pixel,
+ * staging slots, plane cells) are then computed WHERE they are used instead of once in the prologue and carried — or,
+ * at 128 registers, spilled: nine such values cost 300 MB of scratch stores per launch. */
+__device__ __forceinline__ uint32_t fresh_lane() {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+/* The kernel's own argument block, re-read from the kernel-argument segment at the point of use: the empty asm makes
+ * the pointer opaque, so the compiler can neither hoist the (invariant) loads to the top of the kernel nor keep their
+ * results alive across the loops in between. */
+/* a (uniform) index the compiler cannot connect to the loads it already made with it */
+__device__ __forceinline__ uint32_t late_index(uint32_t i) {
+    asm volatile("" : "+s"(i));
+    return i;
+}
+
+__device__ __forceinline__ const osmt_raster_args* late_args() {
+    const osmt_raster_args* p = (const osmt_raster_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
 
 /* ---- perpendicular runs (line.rs:108-137) --------------------------------------------------------------------------
@@ -732,12 +796,9 @@ __device__ __forceinline__ void walk_plain(RunState& st, const StrokeConst& kc, 
 /* A run of a calculator WITH dash segments — a dashed edge, or a cap stub (opacity_calculator_for_outer_caps,
  * line.rs:22) — opacity_calculator.rs:32-80 in full.  `t` is wave-uniform (edges and stubs are walked in separate
  * passes), so the table is read with scalar loads. */
-__device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc, const osmt_dash_table* __restrict__ t,
-                                            double half_width, double traveled, double initial_opacity,
-                                            unsigned long long* __restrict__ plane) {
-    const int n = t->n_segs;
-    const bool has_orig = t->has_orig != 0;
-    const double total = t->total_len, r_total = t->r_total;
+__device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc, const int n, const bool has_orig, const double total,
+                                            const double r_total, const osmt_dash_seg* __restrict__ segs, double half_width, double traveled,
+                                            double initial_opacity, unsigned long long* __restrict__ plane) {
     const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
     for (;;) {
         const double cd = osmt_div_exact(fabs(st.raw), st.denom, st.rdenom);
@@ -763,7 +824,7 @@ __device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc,
         double sd_op = 0.0, dic = 0.0;
         bool has = false;
         for (int i = 0; i < n; ++i) {
-            const osmt_dash_seg* __restrict__ s = &t->segs[i];
+            const osmt_dash_seg* __restrict__ s = &segs[i];
             if (dist_rem < s->start_from || dist_rem > s->end_to) continue; /* :145-157 */
             double base;
             if (dist_rem <= s->start_to) {
@@ -835,10 +896,55 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
                 walk_plain<false>(st, kc, initial_opacity, skip_first, sh.plane);
         } else {
 #pragma unroll 1
-            for (uint32_t t = main_plain ? 1u : 0u; t < 2u; ++t) /* t = 0: dashed edges (calculator `main`), 1: cap stubs (`caps`, line.rs:22) */
-                if (is_cap == (t == 1u)) walk_dashed(st, kc, t ? &sa->caps : &sa->main, sa->half_width, r.traveled, initial_opacity, sh.plane);
+            for (uint32_t t = main_plain ? 1u : 0u; t < 2u; ++t) { /* t = 0: dashed edges (calculator `main`), 1: cap stubs (line.rs:22) */
+                if (is_cap != (t == 1u)) continue;
+                const bool cp = t == 1u; /* wave-uniform: the table of a round is read with scalar loads */
+                const osmt_raster_args* la = late_args();
+                const osmt_dash_seg* sgs = cp ? &sa->caps_seg : la->dseg + (size_t)(sa - la->aux) * OSMT_MAX_DASH_SEGS;
+                walk_dashed(st, kc, cp ? 1 : sa->main_n_segs, (cp ? sa->caps_has_orig : sa->main_has_orig) != 0, cp ? 0.0 : sa->main_total_len,
+                            cp ? 0.0 : sa->main_r_total, sgs, sa->half_width, fabs(r.traveled) /* a stub's is -0.0 */, initial_opacity, sh.plane);
+            }
         }
     }
+}
+
+/* A stroke record as four 16-byte words — how it travels from the arena into LDS (a struct with 16-bit members that is
+ * zero-initialised and conditionally loaded ends up in scratch memory: the raw words stay in registers):
+ * q0 = p1x p1y p2x p2y · q1 = traveled, denom · q2 = rdenom, k_lo0, k_lo1 · q3 = m_lo0, m_lo1, k_n0 | k_n1 << 16, n_x0 | n_x1 << 16 */
+struct RawRec {
+    uint4 q0, q1, q2, q3;
+};
+static_assert(offsetof(osmt_srec, traveled) == 16 && offsetof(osmt_srec, rdenom) == 32 && offsetof(osmt_srec, m_lo0) == 48 &&
+              offsetof(osmt_srec, k_n0) == 56 && offsetof(osmt_srec, n_x0) == 60, "RawRec names the words of osmt_srec");
+__device__ __forceinline__ RawRec raw_rec_load(const osmt_srec* __restrict__ p) {
+    const uint4* __restrict__ s = reinterpret_cast<const uint4*>(p);
+    RawRec r;
+    r.q0 = s[0];
+    r.q1 = s[1];
+    r.q2 = s[2];
+    r.q3 = s[3];
+    return r;
+}
+__device__ __forceinline__ uint32_t raw_rec_items(const RawRec& r) { /* k_n0 + k_n1 + n_x0 + n_x1: every item is one perpendicular run */
+    return (r.q3.z & 0xFFFFu) + (r.q3.z >> 16) + (r.q3.w & 0xFFFFu) + (r.q3.w >> 16);
+}
+__device__ __forceinline__ bool raw_rec_is_cap(const RawRec& r) { return (int32_t)r.q1.y < 0; } /* traveled == -0.0: a cap stub (osmt_internal.h) */
+__device__ __forceinline__ void raw_rec_store(osmt_srec* dst, const RawRec& r) {
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = r.q0;
+    d[1] = r.q1;
+    d[2] = r.q2;
+    d[3] = r.q3;
+}
+__device__ __forceinline__ SegDer seg_derive_raw(const RawRec& r) {
+    osmt_srec t;
+    t.p1x = (int32_t)r.q0.x;
+    t.p1y = (int32_t)r.q0.y;
+    t.p2x = (int32_t)r.q0.z;
+    t.p2y = (int32_t)r.q0.w;
+    t.k_n0 = (uint16_t)(r.q3.z & 0xFFFFu);
+    t.k_n1 = (uint16_t)(r.q3.z >> 16);
+    return seg_derive(t, raw_rec_is_cap(r));
 }
 
 /* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
@@ -1286,10 +1392,12 @@ struct StrokeBinSeg {
     double ft;          /* feather_to of the op: max(|half_width| + 0.5, 1.0) */
     int32_t sx0, sy0;   /* first sub-tile of the window */
     uint32_t ncols;     /* window width in sub-tiles */
-    uint32_t slot0;     /* absolute arena slot of the window's first sub-tile */
+    uint32_t slot0;     /* legacy layout: absolute arena slot of the window's first sub-tile; sorted: first record of the op's first region */
     uint32_t op, job;
     uint32_t is_cap;
-    uint32_t _pad;
+    uint32_t swin;      /* the op's window (osmt_opinfo::swin), 0: legacy slots + keys */
+    uint32_t cell_base; /* sorted layout: the op's first cell counter */
+    uint32_t stride;    /* sorted layout: records per region */
 };
 struct StrokeBinShared {
     uint32_t incl[64]; /* inclusive pair count over the block's segments */
@@ -1302,7 +1410,7 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
                                                 const double* __restrict__ g_den, const double* __restrict__ g_rden, uint32_t n_vsegs,
                                                 uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
                                                 osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                                uint32_t* __restrict__ g_cnt) {
+                                                uint32_t* __restrict__ g_cnt, uint32_t* __restrict__ g_cellcnt) {
     /* ---- step A, lane = virtual segment: its op, end points, sub-tile window — everything k_opinfo left per segment
      * comes in with ONE level of loads, the op's record with a second ---- */
     const uint32_t g = blk * 64u + lane;
@@ -1324,16 +1432,21 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
             const osmt_opinfo* __restrict__ oi = &g_info[o];
             sg.ft = oi->stroke_ft;
             const uint32_t rec_cap = oi->rec_cap, arena_off = oi->arena_off;
+            const uint32_t swin = oi->swin;
             const SubWindow w = vseg_window(sg.rec.p1x, sg.rec.p1y, sg.rec.p2x, sg.rec.p2y, sg.rec.denom, sg.ft, n_sub_x, n_sub_y);
             const uint32_t wc = window_count(w);
-            if (wc && (unsigned long long)cand_off + wc <= rec_cap) { /* always: k_opinfo reserved this very window */
+            /* always: k_opinfo reserved this very window (legacy), or the regions of the union of the op's windows (sorted) */
+            if (wc && (swin ? rec_cap != 0u : (unsigned long long)cand_off + wc <= rec_cap)) {
                 sg.sx0 = w.sx0;
                 sg.sy0 = w.sy0;
                 sg.ncols = (uint32_t)(w.sx1 - w.sx0 + 1);
-                sg.slot0 = arena_off + cand_off;
+                sg.slot0 = swin ? arena_off : arena_off + cand_off;
                 sg.op = o;
                 sg.job = g_op_job[o];
-                sg._pad = 0u;
+                sg.swin = swin;
+                sg.cell_base = oi->cell_off;
+                sg.stride = oi->stride;
+                if (sg.is_cap) sg.rec.traveled = -0.0; /* the record says what it is (osmt_internal.h) */
                 sg.rec.k_lo0 = sg.rec.k_lo1 = sg.rec.m_lo0 = sg.rec.m_lo1 = 0;
                 sg.rec.k_n0 = sg.rec.k_n1 = sg.rec.n_x0 = sg.rec.n_x1 = 0;
                 sh.seg[lane] = sg;
@@ -1365,15 +1478,24 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
         osmt_srec rec = sg.rec;
         osmt_item_ranges ir;
         const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, sg.ft, x0, y0, x0 + SUB - 1, y0 + SUBH - 1, &ir);
-        const size_t slot = (size_t)sg.slot0 + j;
+        const uint32_t swin = sg.swin;
+        size_t slot = (size_t)sg.slot0 + j;
         if (cnt == 0u) {
-            g_skey[slot] = make_uint2(0xFFFFFFFFu, 0u);
+            if (!swin) g_skey[slot] = make_uint2(0xFFFFFFFFu, 0u); /* legacy: a hole; sorted: nothing is written at all */
             continue;
         }
         rec.k_lo0 = ir.k_lo0; rec.k_n0 = (uint16_t)ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = (uint16_t)ir.k_n1;
         rec.m_lo0 = ir.m_lo0; rec.n_x0 = (uint16_t)ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = (uint16_t)ir.n_x1;
+        if (swin) {
+            /* the next free record of this sub-tile's region (any order: one op = one generation, max-alpha) */
+            const uint32_t cell = ((uint32_t)sy - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + ((uint32_t)sx - (swin & 255u));
+            const uint32_t rank = atomicAdd(&g_cellcnt[sg.cell_base + cell], 1u);
+            if (rank >= sg.stride) continue; /* never: a segment leaves one record per sub-tile, the region has room for all of them */
+            slot = (size_t)sg.slot0 + (size_t)cell * sg.stride + rank;
+        } else {
+            g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
+        }
         g_srec[slot] = rec;
-        g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
         /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
         const uint32_t bit = 1u << sx;
         if (!(atomicOr(&g_submask[(size_t)sg.op * sub_rows + (uint32_t)sy], bit) & bit))
@@ -1393,7 +1515,7 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                               uint32_t* __restrict__ g_cnt) {
+                                               uint32_t* __restrict__ g_cnt, uint32_t* __restrict__ g_cellcnt) {
     __shared__ union {
         FillShared fill;
         StrokeBinShared bin;
@@ -1407,7 +1529,7 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
 #endif
     if (b < n_vblk)
         stroke_bin_body(shu.bin, b, threadIdx.x, g_info, g_vpts, g_vop, g_trav, g_den, g_rden, n_vsegs, scale, sub_rows, g_submask, g_cand_off,
-                        g_srec, g_skey, g_op_job, g_cnt);
+                        g_srec, g_skey, g_op_job, g_cnt, g_cellcnt);
     else
         fill_rows_body(shu.fill, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
                        g_op_job, g_cnt);
@@ -1431,7 +1553,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
                                                              unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
                                                              osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err,
-                                                             uint32_t g_fold_max_ops) {
+                                                             uint32_t g_fold_max_ops, const uint32_t* __restrict__ g_cellcnt) {
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1493,6 +1615,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
             if (__ballot(w != 0u) == 0ull) continue;
             osmt_ent e = {};
             uint32_t geom = 0u, arena0 = 0u;
+            uint32_t swin = 0u, cell_base = 0u, stride = 0u; /* sorted stroke layout: the op's window, first cell counter, region size */
             bool is_stroke = false;
             if (w != 0u) {
                 const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + b0 + lane];
@@ -1504,6 +1627,12 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                 e.opacity = hi->opacity;
                 e.aux = is_stroke ? hi->aux : hi->image_id;
                 e.nv = is_stroke ? hi->rec_cap : 0u;
+                if (is_stroke) {
+                    swin = hi->swin;
+                    cell_base = hi->cell_off;
+                    stride = hi->stride;
+                    e.flags = swin ? 0u : OSMT_ENT_LEGACY;
+                }
             }
             const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
             for (uint32_t sx = 0; sx < nsx; ++sx) {
@@ -1514,8 +1643,14 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                 const uint32_t col_left = (uint32_t)__builtin_amdgcn_readlane((int)row_n, (int)sx);
                 const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
                 if (hit && pos < col_left) {
-                    /* FILL: word index of this sub-tile's 16 rows; STROKE: the op's first slot */
+                    /* FILL: word index of this sub-tile's 16 rows; STROKE: the region of this sub-tile's records and how many
+                     * the binning left there (legacy layout: the op's first slot, e.nv = all its slots) */
                     e.arena = is_stroke ? arena0 : (arena0 + (sy - sr0) * ncols + (sx - c0)) * SUBH;
+                    if (swin) {
+                        const uint32_t cell = (sy - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sx - (swin & 255u));
+                        e.arena = arena0 + cell * stride;
+                        e.nv = min(g_cellcnt[cell_base + cell], stride);
+                    }
                     g_ent[(size_t)col_cur + pos] = e;
                 }
                 const uint32_t took = min((uint32_t)__popcll(bal), col_left);
@@ -1534,30 +1669,6 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
  * of perpendicular-run ranges per (segment, sub-tile) (k_stroke_bin).  What is left here is the part that needs the
  * pixels: walking the runs of a generation into the LDS alpha plane (set_pixel keeps the larger alpha,
  * tile_pixels.rs:114-118) and blending generation after generation in order (tile_pixels.rs:205-223). */
-/* The lane id as a value the compiler cannot connect to its earlier uses: addresses derived from it (output pixel,
- * staging slots, plane cells) are then computed WHERE they are used instead of once in the prologue and carried — or,
- * at 128 registers, spilled: nine such values cost 300 MB of scratch stores per launch. */
-__device__ __forceinline__ uint32_t fresh_lane() {
-    uint32_t t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-
-/* The kernel's own argument block, re-read from the kernel-argument segment at the point of use: the empty asm makes
- * the pointer opaque, so the compiler can neither hoist the (invariant) loads to the top of the kernel nor keep their
- * results alive across the loops in between. */
-/* a (uniform) index the compiler cannot connect to the loads it already made with it */
-__device__ __forceinline__ uint32_t late_index(uint32_t i) {
-    asm volatile("" : "+s"(i));
-    return i;
-}
-
-__device__ __forceinline__ const osmt_raster_args* late_args() {
-    const osmt_raster_args* p = (const osmt_raster_args*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
 /* blend_pixel (tile_pixels.rs:209-219) of one wave-uniform source colour into the pixels whose bit is set in `m`
  * (bit = lane): new = s + k * old, k = 1 - alpha, mul then add (no FMA).  The coverage of a fill arrives as whole
  * words, so the set of lanes IS the execution mask: six instructions for the covered lanes instead of six plus six
@@ -1708,11 +1819,23 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     t.opacity = hi->opacity;
                     t.aux = strk ? hi->aux : hi->image_id;
                     t.nv = strk ? hi->rec_cap : 0u;
-                    /* FILL: word index of this sub-tile's 16 rows (sr0 | c0 << 8 | ncols << 16); STROKE: the op's first slot */
+                    /* FILL: word index of this sub-tile's 16 rows (sr0 | c0 << 8 | ncols << 16); STROKE: this sub-tile's region
+                     * of the op's records and their number (legacy layout: the op's first slot, all its slots) */
                     t.arena = strk ? arena0
                                    : (arena0 + (sub / subs_per_row - (geom & 255u)) * ((geom >> 16) & 255u) + (sub % subs_per_row - ((geom >> 8) & 255u))) * SUBH;
                     t.stage = 0u;
-                    t._pad = 0u;
+                    t.flags = 0u;
+                    if (strk) {
+                        const uint32_t swin = hi->swin;
+                        if (swin) {
+                            const uint32_t stride = hi->stride;
+                            const uint32_t cell = (sub / subs_per_row - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sub % subs_per_row - (swin & 255u));
+                            t.arena = arena0 + cell * stride;
+                            t.nv = min(late_args()->cellcnt[hi->cell_off + cell], stride);
+                        } else {
+                            t.flags = OSMT_ENT_LEGACY;
+                        }
+                    }
                     tmp[r - base] = t;
                 }
             }
@@ -1727,7 +1850,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & ((1ull << fresh_lane()) - 1ull));
         /* slots of the stroke entries, prefix-summed over the chunk's lanes: the groups of the filter passes are cut out
          * of this scan with a ballot instead of a scalar loop over the entries (clamped: only "more than a pass" matters) */
-        const uint32_t nv_incl = wave_incl_scan(is_stroke ? min(e.nv, 1u << 20) : 0u);
+        /* (an entry of the legacy slot layout, or one with more records than the LDS holds, counts as "more than a group":
+         * it is cut out alone and walked SEGCAP slots / records at a time) */
+        const bool e_legacy = is_stroke && (e.flags & OSMT_ENT_LEGACY) != 0u;
+        const uint32_t nv_incl = wave_incl_scan(is_stroke ? ((e_legacy || e.nv > (uint32_t)SEGCAP) ? (uint32_t)SEGCAP + 1u : e.nv) : 0u);
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
             StagedEnt se;
@@ -1739,7 +1865,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             se.c2 = fc ? e.opacity * cb : cb;
             se.op = fc ? 1.0 - e.opacity : e.opacity;
             se.arena = e.arena;
-            se.kind_stage = e_kind | ((my_stage < (uint32_t)STAGECAP ? my_stage : 255u) << 8);
+            se.kind_stage = e_kind | ((my_stage < (uint32_t)STAGECAP ? my_stage : 255u) << 8) | (e_legacy ? 1u << 16 : 0u);
             se.aux = e.aux;
             se.nv = e.nv;
             sh.ent[lane] = se;
@@ -1783,16 +1909,17 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         if (total < 1000u) g0 = total; /* ablation: the chunk is staged, no group is filtered or drawn */
 #endif
         while (g0 < total) {
-        /* ---- group = consecutive list entries whose stroke slots fit in the SEGCAP lanes of ONE filter pass; an op with
-         * more slots forms a group of its own and is filtered SEGCAP slots at a time ---- */
+        /* ---- group = consecutive list entries whose stroke RECORDS — the entry says where this sub-tile's are and how many
+         * (sorted layout, osmt_internal.h) — fit the SEGCAP records the LDS holds; an entry with more, or one of the legacy
+         * slot layout, forms a group of its own and is walked SEGCAP records / slots at a time ---- */
         uint32_t gend = total, V = 0;
         bool big = false;
-        uint32_t s_before = 0u;           /* slots of the chunk's entries in front of the group */
+        uint32_t s_before = 0u;           /* records of the chunk's entries in front of the group */
         if (any_stroke) {
             s_before = g0 ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)g0 - 1) : 0u;
-            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)FILTCAP);
+            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)SEGCAP);
             if (over) gend = (uint32_t)__builtin_ctzll(over);
-            if (gend == g0) { /* the first entry alone has more slots than one filter pass looks at */
+            if (gend == g0) { /* the first entry alone is more than a group */
                 OSMT_DBG(if (lane == 0) sh.dbg[7] += 1u;)
                 big = true;
                 gend = g0 + 1u;
@@ -1802,123 +1929,40 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         if (V) {
             OSMT_DBG(if (lane == 0) sh.dbg[3] += 1u;)
-            /* ---- filter pass of the GROUP: every slot of every stroke entry of the group is looked at once, FILTCAP slots
-             * (four rounds of 64 lanes, all key loads in flight together); the records of THIS sub-tile are compacted in
-             * slot order (= op order, segment order).  Round 3 looked at SEGCAP slots per pass: an op of 90 slots — five
-             * edges and two stubs with windows of a dozen sub-tiles — took three passes (key -> record -> barrier each)
-             * and walked the two or three records it kept in up to three under-filled walks. ---- */
-            uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.seg);   /* mark[s]: list entry whose slots start at virtual slot s */
-            uint32_t* const tmp = reinterpret_cast<uint32_t*>(sh.der);  /* [c]: arena slot of kept record c, [SEGCAP + c]: its item count | cap flag */
+            /* ---- the group's records, ONE level of loads: lane c takes record c of the group = record (c - start of its
+             * entry) of that entry's region.  (Until round 4 the entries named all slots of their ops and the wave read the
+             * keys of up to 256 of them to find its own: key -> record, two dependent round trips and ~330 instructions.) ---- */
+            uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.der); /* mark[c]: the entry whose records start at record c of the group */
+            static_assert(sizeof(sh.der) >= 64 && SEGCAP <= 64, "one mark byte per lane");
             const uint32_t t_ = fresh_lane();
-#pragma unroll
-            for (uint32_t i = 0; i < FILTCAP; i += 256u) reinterpret_cast<uint32_t*>(mark + i)[t_] = 0xFFFFFFFFu;
+            if (t_ < 16u) reinterpret_cast<uint32_t*>(mark)[t_] = 0xFFFFFFFFu;
             __syncthreads();
             /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
             const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
             const bool mine = t_ >= g0 && t_ < gend && nv_incl != excl;
             if (mine) mark[excl - s_before] = (uint8_t)t_;
             __syncthreads();
-            constexpr uint32_t NR = FILTCAP / 64u;
-            uint32_t ridx[NR];
-            uint2 key[NR];
-            unsigned long long bal[NR];
-            uint32_t carry_pos = 0u, carry_ent = g0; /* the last entry start in the rounds so far */
-#pragma unroll
-            for (uint32_t r = 0; r < NR; ++r) {
-                ridx[r] = 0xFFFFFFFFu;
-                key[r] = make_uint2(0xFFFFFFFFu, 0u);
-                if (r * 64u < V) { /* uniform */
-                    const uint32_t vs = r * 64u + t_;
-                    const unsigned long long st = __ballot(mark[vs] != 0xFFu);
-                    const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
-                    const unsigned long long m = st & upto;
-                    uint32_t s0 = carry_pos, en = carry_ent;
-                    if (m) {
-                        s0 = r * 64u + 63u - (uint32_t)__builtin_clzll(m);
-                        en = mark[s0];
-                    }
-                    if (vs < V) {
-                        ridx[r] = sh.ent[en].arena + (vs - s0);
-                        key[r] = g_skey[ridx[r]]; /* (sub-tile, item count | cap flag << 31); hole: sub-tile 0xFFFFFFFF */
-                    }
-                    if (st) {
-                        carry_pos = r * 64u + 63u - (uint32_t)__builtin_clzll(st);
-                        carry_ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)mark[carry_pos]);
-                    }
-                }
+            const unsigned long long st = __ballot(mark[t_] != 0xFFu);
+            const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
+            const unsigned long long m = st & upto;
+            RawRec r = {};
+            const bool have = t_ < V; /* (then m != 0: record 0 of the group starts an entry) */
+            if (have) {
+                const uint32_t s0 = 63u - (uint32_t)__builtin_clzll(m);
+                const uint32_t en = mark[s0];
+                r = raw_rec_load(&g_srec[sh.ent[en].arena + (t_ - s0)]);
             }
-            uint32_t kept = 0u;
-#pragma unroll
-            for (uint32_t r = 0; r < NR; ++r) {
-                bal[r] = 0ull;
-                if (r * 64u >= V) continue; /* uniform */
-                const bool keep = key[r].x == sub && (key[r].y & 0x7FFFFFFFu) != 0u;
-                bal[r] = __ballot(keep);
-                const uint32_t c = kept + (uint32_t)__popcll(bal[r] & ((1ull << fresh_lane()) - 1ull));
-                if (keep && c < (uint32_t)SEGCAP) {
-                    tmp[c] = ridx[r];
-                    tmp[(uint32_t)SEGCAP + c] = key[r].y;
-                }
-                kept += (uint32_t)__popcll(bal[r]);
+            const uint32_t items = raw_rec_items(r);
+            const uint32_t incl = wave_incl_scan(items); /* inclusive prefix of the item counts */
+            __syncthreads(); /* the marks and the entries' regions are read: der takes the records' derived values, the entries their place among them */
+            if (mine) {
+                sh.ent[t_].arena = excl - s_before;
+                sh.ent[t_].nv = nv_incl - excl;
             }
-            /* lane e: kept records in front of entry e's slots, and among them.  A bound lies in one round: that round's
-             * ballot and the count of the rounds before it are selected per lane (a popcount per bound, not one per round) */
-            uint32_t slot0_v, nslot_v;
-            {
-                auto kept_below = [&](uint32_t x) { /* kept records among virtual slots [0, x), x <= V */
-                    const uint32_t rr = x >> 6;
-                    unsigned long long bsel = 0ull;
-                    uint32_t csel = kept, cum = 0u;
-#pragma unroll
-                    for (uint32_t r = 0; r < NR; ++r) {
-                        if (rr == r) {
-                            bsel = bal[r];
-                            csel = cum;
-                        }
-                        cum += (uint32_t)__popcll(bal[r]);
-                    }
-                    return csel + (uint32_t)__popcll(bsel & ((1ull << (x & 63u)) - 1ull));
-                };
-                const uint32_t na = kept_below(mine ? excl - s_before : 0u);
-                const uint32_t nb = kept_below(mine ? nv_incl - s_before : 0u);
-                slot0_v = na;
-                nslot_v = nb - na;
-            }
-            if (kept > (uint32_t)SEGCAP) { /* more records than the LDS holds: the group ends in front of the entry that does not fit */
-                const unsigned long long ov = __ballot(slot0_v + nslot_v > (uint32_t)SEGCAP);
-                const uint32_t e_ov = (uint32_t)__builtin_ctzll(ov);
-                if (e_ov == g0) { /* an op with more than SEGCAP records in ONE sub-tile: filtered and walked SEGCAP slots at a time */
-                    OSMT_DBG(if (lane == 0) sh.dbg[6] += 1u;)
-                    big = true;
-                    gend = g0 + 1u;
-                    kept = 0u;
-                } else {
-                    OSMT_DBG(if (lane == 0) sh.dbg[4] += 1u;)
-                    gend = e_ov;
-                    kept = (uint32_t)__builtin_amdgcn_readlane((int)slot0_v, (int)e_ov);
-                }
-            }
-            /* where an entry's records sit among the compacted ones replaces its arena position, which nothing needs any more */
-            if (mine && t_ < gend && !big) {
-                sh.ent[t_].arena = slot0_v;
-                sh.ent[t_].nv = nslot_v;
-            }
-            __syncthreads();
-            {
-                const uint32_t c = fresh_lane();
-                uint32_t ky = 0u, at = 0u;
-                if (c < kept) {
-                    ky = tmp[(uint32_t)SEGCAP + c];
-                    at = tmp[c];
-                }
-                const uint32_t incl = wave_incl_scan(ky & 0x7FFFFFFFu); /* inclusive prefix of the item counts */
-                __syncthreads(); /* tmp and mark are read: their memory takes the records now */
-                if (c < kept) {
-                    sh.pre[c] = incl;
-                    const osmt_srec r = g_srec[at];
-                    sh.seg[c] = r;
-                    sh.der[c] = seg_derive(r, (ky >> 31) != 0u);
-                }
+            if (have) {
+                sh.pre[t_] = incl;
+                raw_rec_store(&sh.seg[t_], r);
+                sh.der[t_] = seg_derive_raw(r);
             }
             __syncthreads();
         }
@@ -1927,7 +1971,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         for (uint32_t li = g0; li < gend; ++li) {
             const StagedEnt& en = sh.ent[li];
             const uint32_t ks = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.kind_stage);
-            const uint32_t kind = ks & 255u, stage = ks >> 8;
+            const uint32_t kind = ks & 255u, stage = (ks >> 8) & 255u;
             const double cop = en.op; /* a uniform value in a vector register */
 #if defined(OSMT_ABL) && OSMT_ABL == 6
             if (kind != 77u) continue; /* ablation: lists are staged, nothing is drawn */
@@ -1957,6 +2001,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 const uint32_t sflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.flags);
                 uint32_t n_rounds = 1u, big_cap = 0u, arena = 0u;
+                const bool big_legacy = ((ks >> 16) & 1u) != 0u;
                 if (big) {
                     big_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
                     arena = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
@@ -1965,26 +2010,26 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 for (uint32_t round = 0; round < n_rounds; ++round) {
                     uint32_t slot0 = 0u, nslot = 0u;
                     if (big) {
-                        /* ---- filter pass of ONE big op, SEGCAP of its slots per round ---- */
+                        /* ---- ONE big entry, SEGCAP per round: the records of this sub-tile's region (sorted layout: all of
+                         * them are its own), or slots of a long way (legacy layout: the key says whose a slot is) ---- */
                         __syncthreads(); /* previous round's records are consumed */
                         uint32_t ridx = 0xFFFFFFFFu;
                         const uint32_t v = round * (uint32_t)SEGCAP + lane;
                         if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
-                        uint32_t cnt = 0, is_cap = 0;
-                        if (ridx != 0xFFFFFFFFu) {
+                        bool keep = ridx != 0xFFFFFFFFu;
+                        if (keep && big_legacy) {
                             const uint2 key = g_skey[ridx];
-                            if (key.x == sub) {
-                                cnt = key.y & 0x7FFFFFFFu;
-                                is_cap = key.y >> 31;
-                            }
+                            keep = key.x == sub && (key.y & 0x7FFFFFFFu) != 0u;
                         }
+                        RawRec r = {};
+                        if (keep) r = raw_rec_load(&g_srec[ridx]);
+                        const uint32_t cnt = raw_rec_items(r);
                         gbal = __ballot(cnt > 0u);
                         const uint32_t incl = wave_incl_scan(cnt);
                         if (cnt > 0u) {
                             const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << fresh_lane()) - 1ull));
-                            const osmt_srec r = g_srec[ridx];
-                            sh.seg[slot] = r;
-                            sh.der[slot] = seg_derive(r, is_cap != 0u);
+                            raw_rec_store(&sh.seg[slot], r);
+                            sh.der[slot] = seg_derive_raw(r);
                             sh.pre[slot] = incl;
                         }
                         __syncthreads();
@@ -2379,11 +2424,11 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
     if (a.n_ops)
         hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
                            a.trav, a.den, a.rden, a.vpts, a.vop, a.op_blk, a.blk, a.n_vsegs, n_vblk,
-                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
+                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt, a.cellcnt);
     /* lists only for tiles with more than OSMT_FOLD_MAX_OPS ops (k_raster's waves put the others' together themselves) */
     if (a.n_jobs && (a.fold_max_ops == 0u || a.max_job_ops > a.fold_max_ops))
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
-                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops);
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops, a.cellcnt);
     return hipGetLastError();
 }
 
