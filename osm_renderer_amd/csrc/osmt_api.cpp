@@ -146,6 +146,7 @@ struct osmt_scene {
     double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     osmt_dash_seg* d_dseg = nullptr;
+    osmt_ent* d_entfix = nullptr;     /* [n_jobs][nsub][OSMT_LIST_FIXK] */
     uint32_t* d_submask = nullptr;
     uint32_t* d_op_blk = nullptr;
     uint32_t* d_op_vseg = nullptr; /* op -> its first virtual segment (stroke ops with segments) */
@@ -719,6 +720,7 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.cnt = sc->d_cnt;
     a.hdr = sc->d_hdr;
     a.ent = sc->d_ent;
+    a.entfix = sc->d_entfix;
     a.ent_cap = sizing ? 0ull : sc->ent_cap;
     a.fmask = sc->d_fmask;
     a.srec = sc->d_srec;
@@ -800,6 +802,7 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
             a.hdr = sc->d_hdr + (size_t)first_job * (Wt / OSMT_SUB_W) * (Wt / OSMT_SUB_H);
         }
         a.ent = sc->d_ent;
+        a.entfix = sc->d_entfix + (size_t)first_job * (OSMT_TILE_SIZE * sc->scale / OSMT_SUB_W) * (OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H) * OSMT_LIST_FIXK;
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
@@ -1142,6 +1145,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
+    const size_t o_entfix = carve(b->n_jobs * n_sub * (size_t)OSMT_LIST_FIXK * sizeof(osmt_ent) + 64); /* the first entries of every list, at a fixed place */
     s->bytes = off + 256;
     mark(1);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
@@ -1165,6 +1169,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_dseg = (osmt_dash_seg*)(s->d_base + o_dseg);
+    s->d_entfix = (osmt_ent*)(s->d_base + o_entfix);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
     s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
     s->d_op_vseg = (uint32_t*)(s->d_base + o_opvseg);

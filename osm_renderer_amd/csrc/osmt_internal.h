@@ -152,6 +152,14 @@ struct alignas(16) osmt_ent {
 };
 static_assert(sizeof(osmt_ent) == 32, "osmt_ent is two 16-byte loads");
 #define OSMT_ENT_LEGACY 1u /* STROKE: slots + keys instead of per-sub-tile regions */
+/* The first OSMT_LIST_FIXK entries of every (tile, sub-tile) list live at a FIXED place — entfix[(tile * nsub + sub) * FIXK + i]
+ * — only the rest goes to the list arena behind the header's offset.  A sub-tile wave of k_raster knows that address from its
+ * block index alone: it asks for the entries in the same breath as for the job record and the list header instead of one
+ * dependent round trip later (config 2 has ~5 entries per sub-tile: the whole list).  0: every entry in the arena (round 4). */
+#ifndef OSMT_V_FIXK
+#define OSMT_V_FIXK 8
+#endif
+#define OSMT_LIST_FIXK OSMT_V_FIXK
 
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
@@ -258,7 +266,8 @@ struct osmt_raster_args {
     const osmt_stroke_aux* aux;
     const osmt_dash_seg* dseg; /* [stroke][OSMT_MAX_DASH_SEGS]: DashSegments of the `main` calculators (dashed ops only) */
     const uint2* hdr;        /* [n_jobs][nsub]: (first entry, entry count) of the sub-tile's list (k_sublist) */
-    const osmt_ent* ent;     /* the lists */
+    const osmt_ent* ent;     /* the lists (entries behind the first OSMT_LIST_FIXK of each) */
+    const osmt_ent* entfix;  /* [n_jobs][nsub][OSMT_LIST_FIXK]: the first entries of every list */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
     /* tiles of at most fold_max_ops ops have no lists: their sub-tile waves read the op bits and the op records themselves */
@@ -314,6 +323,7 @@ struct osmt_prepass_args {
     uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
     uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */
     osmt_ent* ent;      /* list arena */
+    osmt_ent* entfix;   /* [n_jobs][nsub][OSMT_LIST_FIXK] */
     unsigned long long ent_cap;
     uint32_t* fmask;
     osmt_srec* srec;

@@ -460,10 +460,11 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                 if (a.err) *(volatile uint32_t*)a.err = OSMT_PREPASS_ERR_STROKE_ARENA;
             } else if (want_c) {
                 oi.cell_off = (uint32_t)c_off;
-                if (a.srec_cap) /* (not in the sizing pass) every cell starts empty */
-                    for (uint32_t i = 0; i < want_c; ++i) a.cellcnt[c_off + i] = 0u;
             }
         }
+        /* every cell starts empty (not in the sizing pass): the counters of the wave's ops are one contiguous piece */
+        if (a.srec_cap && c_base + c_tot <= a.srec_cap)
+            for (uint32_t i = lane; i < c_tot; i += OPINFO_THREADS) a.cellcnt[c_base + i] = 0u;
         if (want_f) {
             const unsigned long long off = f_base + (f_incl - f);
             oi.arena_off = (uint32_t)off;
@@ -1045,7 +1046,10 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 #endif
 constexpr uint32_t FILL_GROUP = OSMT_V_FILL_GROUP;
 constexpr uint32_t FILL_EMAX = 128;
-constexpr uint32_t FILL_RMAX = 512;
+#ifndef OSMT_V_FILL_RMAX
+#define OSMT_V_FILL_RMAX 512
+#endif
+constexpr uint32_t FILL_RMAX = OSMT_V_FILL_RMAX; /* crossing records of one pass (LDS: 12 bytes each) */
 struct FillShared {
     int32_t r_xmin[FILL_RMAX];
     int32_t r_xmax[FILL_RMAX];
@@ -1492,9 +1496,14 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
             const uint32_t rank = atomicAdd(&g_cellcnt[sg.cell_base + cell], 1u);
             if (rank >= sg.stride) continue; /* never: a segment leaves one record per sub-tile, the region has room for all of them */
             slot = (size_t)sg.slot0 + (size_t)cell * sg.stride + rank;
-        } else {
-            g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
+            g_srec[slot] = rec;
+            /* the op's bit for k_sublist (nobody waits for the old value), and whoever took the region's first record counts
+             * the op into that sub-tile's list */
+            atomicOr(&g_submask[(size_t)sg.op * sub_rows + (uint32_t)sy], 1u << sx);
+            if (rank == 0u) atomicAdd(g_cnt + ((size_t)sg.job * sub_rows + (uint32_t)sy) * (uint32_t)n_sub_x + (uint32_t)sx, 1u);
+            continue;
         }
+        g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
         g_srec[slot] = rec;
         /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
         const uint32_t bit = 1u << sx;
@@ -1506,7 +1515,12 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
 /* Both binning jobs in ONE launch: blocks [0, n_vblk) bin 64 stroke segments each (latency-bound: a bisection, a chain
  * of dependent loads, scattered 72-byte stores), the rest build the coverage rows of FILL_GROUP ops each (issue-bound) —
  * the two kinds overlap on the machine instead of running back to back. */
-__global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
+#ifdef OSMT_V_PREBIN_WAVES
+#define OSMT_PREBIN_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSMT_V_PREBIN_WAVES, OSMT_V_PREBIN_WAVES)))
+#else
+#define OSMT_PREBIN_BOUNDS __launch_bounds__(64)
+#endif
+__global__ OSMT_PREBIN_BOUNDS void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
                                                const double* __restrict__ g_rden, const int4* __restrict__ g_vpts,
@@ -1553,7 +1567,8 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
                                                              unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
                                                              osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err,
-                                                             uint32_t g_fold_max_ops, const uint32_t* __restrict__ g_cellcnt) {
+                                                             uint32_t g_fold_max_ops, osmt_ent* __restrict__ g_entfix) {
+    constexpr uint32_t FIXK = OSMT_LIST_FIXK; /* entries of a list that live at a fixed place (osmt_internal.h) */
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1565,7 +1580,10 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
     const uint32_t nsx = W / SUB;
     const uint32_t nsub = nsx * g_sub_rows;
     const uint32_t* __restrict__ cnt = g_cnt + (size_t)tile * nsub;
-    for (uint32_t i = tid; i < nsub; i += SUBLIST_THREADS) s_off[i] = cnt[i];
+    for (uint32_t i = tid; i < nsub; i += SUBLIST_THREADS) {
+        const uint32_t c = cnt[i];
+        s_off[i] = c > FIXK ? c - FIXK : 0u; /* the arena takes what does not fit the list's fixed slots */
+    }
     __syncthreads();
     if (wave == 0u) {
         /* lane l owns the contiguous piece [l*per, (l+1)*per): serial inside, wave scan across */
@@ -1596,7 +1614,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     for (uint32_t sy = wave; sy < g_sub_rows; sy += SUBLIST_THREADS / 64u) {
         /* lane sx keeps the write cursor of column sx */
-        uint32_t cur = 0u, row_n = 0u;
+        uint32_t cur = 0u, row_n = 0u, filled = 0u; /* arena position of the list's entry FIXK; entries still to come; entries written */
         if (lane < nsx) {
             const uint32_t c = cnt[sy * nsx + lane];
             cur = base + s_off[sy * nsx + lane];
@@ -1641,21 +1659,26 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                 if (bal == 0ull) continue;
                 const uint32_t col_cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)sx);
                 const uint32_t col_left = (uint32_t)__builtin_amdgcn_readlane((int)row_n, (int)sx);
+                const uint32_t col_filled = (uint32_t)__builtin_amdgcn_readlane((int)filled, (int)sx);
                 const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
                 if (hit && pos < col_left) {
                     /* FILL: word index of this sub-tile's 16 rows; STROKE: the region of this sub-tile's records and how many
                      * the binning left there (legacy layout: the op's first slot, e.nv = all its slots) */
                     e.arena = is_stroke ? arena0 : (arena0 + (sy - sr0) * ncols + (sx - c0)) * SUBH;
-                    if (swin) {
+                    if (swin) { /* (the count is read by k_raster's staging lane, beside the op's constants: here it would be a dependent load per column) */
                         const uint32_t cell = (sy - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sx - (swin & 255u));
                         e.arena = arena0 + cell * stride;
-                        e.nv = min(g_cellcnt[cell_base + cell], stride);
+                        e.nv = cell_base + cell;
                     }
-                    g_ent[(size_t)col_cur + pos] = e;
+                    const uint32_t idx = col_filled + pos; /* place in the sub-tile's list */
+                    if (idx < FIXK)
+                        g_entfix[((size_t)tile * nsub + sy * nsx + sx) * FIXK + idx] = e;
+                    else
+                        g_ent[(size_t)col_cur + (idx - FIXK)] = e;
                 }
                 const uint32_t took = min((uint32_t)__popcll(bal), col_left);
                 if (lane == sx) {
-                    cur += took;
+                    filled += took;
                     row_n -= took;
                 }
             }
@@ -1721,6 +1744,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint32_t sub = rest % nsub;
     if (tile >= a.n_jobs) return;
 
+    /* the first entries of this sub-tile's list sit at a fixed place (osmt_internal.h): asked for NOW, beside the job record
+     * and the list header, not one round trip behind the header (lanes beyond the list read slots nobody looks at) */
+    constexpr uint32_t FIXK = OSMT_LIST_FIXK;
+    /* (the small-batch instantiation builds most lists itself and reads the fixed entries of a long-list tile where it needs them) */
+    osmt_ent e_first;
+    if (!FOLD) e_first = a.entfix[((size_t)tile * nsub + sub) * FIXK + (FIXK != 0u ? lane & (FIXK - 1u) : 0u)];
+    static_assert((OSMT_LIST_FIXK & (OSMT_LIST_FIXK - 1)) == 0, "FIXK is a power of two (or 0)");
     const osmt_tile_job job = a.jobs[tile];
     SubRect rc;
     const uint32_t sub_x = sub % subs_per_row, sub_y = sub / subs_per_row;
@@ -1782,17 +1812,24 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         unsigned long long b0, b1;
         op_bits(&b0, &b1);
         hdr.y = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-    } else if (job.n_ops != 0u) {
-        /* a tile without ops is plain canvas (drawer.rs:60-131 with no areas): its headers are never looked at — a scene
-         * without any op has no list kernel launch at all */
+    } else {
+        /* (requested beside the job record, not behind it) a tile without ops is plain canvas (drawer.rs:60-131 with no
+         * areas): what its headers hold is never looked at — a scene without any op has no list kernel launch at all */
         hdr = a.hdr[(size_t)tile * nsub + sub];
+        if (job.n_ops == 0u) hdr = make_uint2(0u, 0u);
     }
 #if defined(OSMT_ABL) && OSMT_ABL == 8
     const uint32_t n_ent = hdr.y > 0xFFFFFFF0u ? 1u : 0u; /* ablation: the list is not even staged */
 #else
     const uint32_t n_ent = hdr.y;
 #endif
-    const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
+    const osmt_ent* OSMT_R my_ent = g_ent + hdr.x; /* entry FIXK of the list */
+    if (FIXK != 0u && !FOLD) {
+        /* parked in LDS until the first chunk takes them (held in registers they would stay alive through the whole chunk loop) */
+        static_assert(sizeof(osmt_ent) * OSMT_LIST_FIXK <= sizeof(sh.seg), "the fixed entries fit the record array");
+        if (lane < FIXK) reinterpret_cast<osmt_ent*>(sh.seg)[lane] = e_first;
+        __syncthreads();
+    }
 
     for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
         const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
@@ -1831,7 +1868,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                             const uint32_t stride = hi->stride;
                             const uint32_t cell = (sub / subs_per_row - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sub % subs_per_row - (swin & 255u));
                             t.arena = arena0 + cell * stride;
-                            t.nv = min(late_args()->cellcnt[hi->cell_off + cell], stride);
+                            t.nv = hi->cell_off + cell;
                         } else {
                             t.flags = OSMT_ENT_LEGACY;
                         }
@@ -1842,7 +1879,15 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             __syncthreads();
             if (hit) e = tmp[fresh_lane()];
         } else if (hit) {
-            e = my_ent[base + lane];
+            if (FIXK != 0u) {
+                const uint32_t t_ = fresh_lane();
+                if (base == 0u && t_ < FIXK)
+                    e = FOLD ? late_args()->entfix[((size_t)tile * nsub + sub) * FIXK + t_] : reinterpret_cast<const osmt_ent*>(sh.seg)[t_];
+                else
+                    e = my_ent[base + t_ - FIXK];
+            } else {
+                e = my_ent[base + lane];
+            }
         }
         const uint32_t e_kind = e.kind_color & 255u;
         const bool is_stroke = hit && e_kind == OSMT_OP_STROKE;
@@ -1853,7 +1898,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         /* (an entry of the legacy slot layout, or one with more records than the LDS holds, counts as "more than a group":
          * it is cut out alone and walked SEGCAP slots / records at a time) */
         const bool e_legacy = is_stroke && (e.flags & OSMT_ENT_LEGACY) != 0u;
-        const uint32_t nv_incl = wave_incl_scan(is_stroke ? ((e_legacy || e.nv > (uint32_t)SEGCAP) ? (uint32_t)SEGCAP + 1u : e.nv) : 0u);
+        /* how many records the binning left in this sub-tile's region of the op: the entry names the counter (k_sublist would
+         * have to wait for it column by column); asked for here, it arrives with the coverage words and stroke constants the
+         * staging lanes request below — no round trip of its own */
+        uint32_t rec_cnt = e.nv;
+        if (is_stroke && !e_legacy) rec_cnt = late_args()->cellcnt[e.nv];
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
             StagedEnt se;
@@ -1894,6 +1943,8 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 sh.sconst[my_stage] = kc;
             }
         }
+        if (is_stroke) sh.ent[fresh_lane()].nv = rec_cnt;
+        const uint32_t nv_incl = wave_incl_scan(is_stroke ? ((e_legacy || rec_cnt > (uint32_t)SEGCAP) ? (uint32_t)SEGCAP + 1u : rec_cnt) : 0u);
         const bool any_stroke = sbal != 0ull;
         if (any_stroke && !plane_clean) {
             static_assert((PLANE_STRIDE * SUBH) % NTHREADS == 0, "the plane is cleared in whole wave strides");
@@ -2146,6 +2197,23 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
     }
 
+    /* The block's place — tile, sub-tile origin, tile width — derived AGAIN from the block index for the epilogue: carried from
+     * the prologue these values sat in scalar registers across every loop of the kernel (or rather in the lanes of a spill
+     * register: 22 SGPR spills in round 4's kernel, all of them written in the prologue and read back here). */
+    uint32_t tile_e, W_e;
+    SubRect rce;
+    {
+        uint32_t b_ = blockIdx.x;
+        asm volatile("" : "+s"(b_));
+        W_e = OSMT_TILE_SIZE * late_args()->scale;
+        const uint32_t spr_ = W_e / SUB, nsub_ = spr_ * (W_e / SUBH);
+        const uint32_t rest_ = b_ >> 3, sub_ = rest_ % nsub_;
+        tile_e = (rest_ / nsub_) * 8u + (b_ & 7u);
+        rce.x0 = (int32_t)((sub_ % spr_) * SUB);
+        rce.y0 = (int32_t)((sub_ / spr_) * SUBH);
+        rce.x1 = rce.x0 + SUB - 1;
+        rce.y1 = rce.y0 + SUBH - 1;
+    }
     /* ---- label pass, blend_unfinished_pixels(true) (tile_pixels.rs:154-158,205-223) ----------
      * k_label_resolve has decided which labels succeeded; succeeded labels never share a pixel
      * (set_label_pixel refuses the second one), so every pixel is blended at most once and the
@@ -2156,25 +2224,25 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const osmt_labelinfo* OSMT_R g_lab = la->labels.info;
         const double* OSMT_R g_lab_plane = la->labels.plane;
         const double4* OSMT_R g_image_pool = la->image_pool;
-        const osmt_tile_label* OSMT_R tl = la->labels.tile_labels + la->labels.job_label_off[tile];
-        const uint32_t n_tl = la->labels.tile_label_cnt[tile];
+        const osmt_tile_label* OSMT_R tl = la->labels.tile_labels + la->labels.job_label_off[tile_e];
+        const uint32_t n_tl = la->labels.tile_label_cnt[tile_e];
         /* the tile's survivors are tested against the sub-tile 64 at a time (one load, one ballot): only the few
          * that reach into it are walked */
         for (uint32_t kb = 0; kb < n_tl; kb += 64u) {
           const uint32_t kk = kb + lane;
           osmt_tile_label e = {};
           if (kk < n_tl) e = tl[kk];
-          unsigned long long hm = __ballot(kk < n_tl && !(e.x0 > rc.x1 || e.x1 < rc.x0 || e.y0 > rc.y1 || e.y1 < rc.y0));
+          unsigned long long hm = __ballot(kk < n_tl && !(e.x0 > rce.x1 || e.x1 < rce.x0 || e.y0 > rce.y1 || e.y1 < rce.y0));
           while (hm) {
             const uint32_t hj = (uint32_t)__builtin_ctzll(hm);
             hm &= hm - 1ull;
             const osmt_labelinfo* OSMT_R li = g_lab + (uint32_t)__builtin_amdgcn_readlane((int)e.label, (int)hj);
             const int32_t ry0 = li->ry0, ry1 = li->ry1, cx0 = li->cx0;
             const int32_t cx1 = cx0 + (int32_t)li->cols - 1;
-            const bool text_hit = li->has_text && ry0 <= rc.y1 && ry1 >= rc.y0 && cx0 <= rc.x1 && cx1 >= rc.x0;
+            const bool text_hit = li->has_text && ry0 <= rce.y1 && ry1 >= rce.y0 && cx0 <= rce.x1 && cx1 >= rce.x0;
             const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
             const int32_t iw = (int32_t)li->icon_w, ih = (int32_t)li->icon_h;
-            const bool icon_hit = iw > 0 && ix0 <= rc.x1 && ix0 + iw - 1 >= rc.x0 && iy0 <= rc.y1 && iy0 + ih - 1 >= rc.y0;
+            const bool icon_hit = iw > 0 && ix0 <= rce.x1 && ix0 + iw - 1 >= rce.x0 && iy0 <= rce.y1 && iy0 + ih - 1 >= rce.y0;
             if (!text_hit && !icon_hit) continue;
             const double cr = (double)li->color[0] / 255.0, cg = (double)li->color[1] / 255.0,
                          cb = (double)li->color[2] / 255.0;
@@ -2182,10 +2250,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const uint32_t cols = li->cols;
             const double4* OSMT_R ipx = g_image_pool + li->icon_off;
             const uint32_t lx = fresh_lane() & (SUB - 1), ly0 = fresh_lane() / SUB;
-            const int32_t x = rc.x0 + (int32_t)lx;
+            const int32_t x = rce.x0 + (int32_t)lx;
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                const int32_t y = rc.y0 + (int32_t)(ly0 + (uint32_t)j * ROWSTEP);
+                const int32_t y = rce.y0 + (int32_t)(ly0 + (uint32_t)j * ROWSTEP);
                 double t = 0.0;
                 if (text_hit && y >= ry0 && y <= ry1 && x >= cx0 && x <= cx1)
                     t = plane[(size_t)(y - ry0) * cols + (uint32_t)(x - cx0)];
@@ -2222,29 +2290,29 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         __syncthreads();
         constexpr uint32_t ROW_DW = SUB * 3 / 4; /* 24 dwords per row */
-        uint8_t* const tile_out = reinterpret_cast<uint8_t*>(g_out) + (size_t)tile * g_out_tile_stride;
+        uint8_t* const tile_out = reinterpret_cast<uint8_t*>(g_out) + (size_t)tile_e * g_out_tile_stride;
 #pragma unroll
         for (uint32_t q = 0; q < ROW_DW * SUBH / NTHREADS; ++q) {
             const uint32_t d = q * NTHREADS + t_out;
             const uint32_t row = d / ROW_DW, k = d % ROW_DW;
             const uint32_t v = reinterpret_cast<const uint32_t*>(stg)[d];
-            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(tile_out + ((size_t)(rc.y0 + (int32_t)row) * W + (size_t)rc.x0) * 3u + 4u * k));
+            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(tile_out + ((size_t)(rce.y0 + (int32_t)row) * W_e + (size_t)rce.x0) * 3u + 4u * k));
         }
         return;
     }
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;
-        const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx_o);
+        const size_t px = (size_t)(rce.y0 + (int32_t)row) * W_e + (size_t)(rce.x0 + (int32_t)lx_o);
         if (OUT_F64) {
-            double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
+            double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile_e * W_e * W_e + px;
             *out = make_double4(acc[j][0], acc[j][1], acc[j][2], 1.0);
         } else {
             /* postdivide (tile_pixels.rs:171-175) with p.a == 1.0: val / 1.0 == val */
             const uint32_t v = f64_as_u8(255.0 * acc[j][0]) | (f64_as_u8(255.0 * acc[j][1]) << 8) |
                                (f64_as_u8(255.0 * acc[j][2]) << 16) | 0xFF000000u;
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
-                                                        (size_t)tile * g_out_tile_stride) + px;
+                                                        (size_t)tile_e * g_out_tile_stride) + px;
             /* written once, read by nobody on the device: a non-temporal store keeps the 268 MB of a launch's pixels from
              * pushing the lists, keys and records of the tiles still being drawn out of the L2s (0.644 -> 0.614 ms on config 2;
              * the same hint on the LOADS of the read-once list entries and coverage words costs 0.01 ms instead) */
@@ -2428,7 +2496,7 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
     /* lists only for tiles with more than OSMT_FOLD_MAX_OPS ops (k_raster's waves put the others' together themselves) */
     if (a.n_jobs && (a.fold_max_ops == 0u || a.max_job_ops > a.fold_max_ops))
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
-                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops, a.cellcnt);
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops, a.entfix);
     return hipGetLastError();
 }
 
