@@ -146,7 +146,6 @@ struct osmt_scene {
     double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     osmt_dash_seg* d_dseg = nullptr;
-    osmt_ent* d_entfix = nullptr;     /* [n_jobs][nsub][OSMT_LIST_FIXK] */
     uint32_t* d_submask = nullptr;
     uint32_t* d_op_blk = nullptr;
     uint32_t* d_op_vseg = nullptr; /* op -> its first virtual segment (stroke ops with segments) */
@@ -168,7 +167,6 @@ struct osmt_scene {
     uint32_t* d_fmask = nullptr;
     osmt_srec* d_srec = nullptr;
     uint2* d_skey = nullptr;
-    uint32_t* d_cellcnt = nullptr;    /* per (stroke op, cell of its window): records in that sub-tile's region (sorted layout) */
     unsigned long long fmask_cap = 0, srec_cap = 0; /* 64-byte groups / records */
     /* host-side tables whose upload may still be in flight on the call's stream */
     std::vector<uint32_t> h_pt_job, h_op_aux, h_op_blk, h_op_vseg, h_op_job, h_lab_wide;
@@ -720,12 +718,10 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.cnt = sc->d_cnt;
     a.hdr = sc->d_hdr;
     a.ent = sc->d_ent;
-    a.entfix = sc->d_entfix;
     a.ent_cap = sizing ? 0ull : sc->ent_cap;
     a.fmask = sc->d_fmask;
     a.srec = sc->d_srec;
     a.skey = sc->d_skey;
-    a.cellcnt = sc->d_cellcnt;
     a.fmask_cap = sizing ? 0ull : sc->fmask_cap;
     a.srec_cap = sizing ? 0ull : sc->srec_cap;
     a.err = sizing ? nullptr : sc->h_err; /* hipHostMallocMapped memory: one address on both sides (unified addressing) */
@@ -802,11 +798,9 @@ int render_impl(osmt_ctx* ctx, osmt_scene* sc, uint32_t stages, void* d_out, siz
             a.hdr = sc->d_hdr + (size_t)first_job * (Wt / OSMT_SUB_W) * (Wt / OSMT_SUB_H);
         }
         a.ent = sc->d_ent;
-        a.entfix = sc->d_entfix + (size_t)first_job * (OSMT_TILE_SIZE * sc->scale / OSMT_SUB_W) * (OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H) * OSMT_LIST_FIXK;
         a.fmask = sc->d_fmask;
         a.srec = sc->d_srec;
         a.skey = sc->d_skey;
-        a.cellcnt = sc->d_cellcnt;
         a.info = sc->d_info;
         a.submask = sc->d_submask;
         a.fold_max_ops = sc->n_jobs <= OSMT_FOLD_MAX_JOBS ? OSMT_FOLD_MAX_OPS : 0u; /* the same rule as the pre-pass (prepass_args) */
@@ -959,7 +953,6 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool 
     const size_t o_f = carve((size_t)(groups + 1) * 64);
     const size_t o_r = carve((size_t)(recs + 1) * sizeof(osmt_srec));
     const size_t o_k = carve((size_t)(recs + 1) * 8);
-    const size_t o_c = carve((size_t)(recs + 1) * 4); /* cell counters of the sorted stroke layout: an op has at most as many cells as records */
     const size_t o_e = carve((size_t)(ents + 1) * sizeof(osmt_ent));
     hipError_t e = dev_alloc(ctx, (void**)&s->d_arena, off + 256);
     if (e != hipSuccess) {
@@ -969,7 +962,6 @@ static int scene_size_arenas(osmt_ctx* ctx, osmt_scene* s, size_t n_fills, bool 
     s->d_fmask = (uint32_t*)(s->d_arena + o_f);
     s->d_srec = (osmt_srec*)(s->d_arena + o_r);
     s->d_skey = (uint2*)(s->d_arena + o_k);
-    s->d_cellcnt = (uint32_t*)(s->d_arena + o_c);
     s->d_ent = (osmt_ent*)(s->d_arena + o_e);
     s->ent_cap = ents + 1;
     s->fmask_cap = groups + 1; /* never 0: 0 means "sizing pass" to the kernels */
@@ -1145,7 +1137,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
-    const size_t o_entfix = carve(b->n_jobs * n_sub * (size_t)OSMT_LIST_FIXK * sizeof(osmt_ent) + 64); /* the first entries of every list, at a fixed place */
     s->bytes = off + 256;
     mark(1);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
@@ -1169,7 +1160,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_den = (double*)(s->d_base + o_den);
     s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
     s->d_dseg = (osmt_dash_seg*)(s->d_base + o_dseg);
-    s->d_entfix = (osmt_ent*)(s->d_base + o_entfix);
     s->d_submask = (uint32_t*)(s->d_base + o_submask);
     s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
     s->d_op_vseg = (uint32_t*)(s->d_base + o_opvseg);

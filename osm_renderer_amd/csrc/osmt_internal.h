@@ -31,7 +31,7 @@ struct osmt_dash_seg {
 struct osmt_cap_seg {
     int32_t p1x, p1y, p2x, p2y;
     int32_t valid; /* the edge is not degenerate and the cap is Round/Square */
-    uint32_t cand_off; /* first slot of the stub's sub-tile window in the op's slice of the stroke arena (legacy layout) */
+    uint32_t cand_off; /* first slot of the stub's sub-tile window in the op's slice of the stroke arena */
     double denom;  /* center_dist_denom of the stub */
 };
 
@@ -62,18 +62,7 @@ static_assert(sizeof(osmt_stroke_aux) == 192, "three 64-byte lines");
 /* Everything k_raster needs to start on an op, in ONE 64-byte record (one s_load_dwordx16): the op header fields it
  * uses and the results of the pre-pass — k_raster never touches ops, rings or points. */
 struct osmt_opinfo {
-    union {
-        struct {
-            int32_t x0, y0, x1, y1; /* FILL: inclusive extent of the op's points (empty: x0 > x1) */
-        };
-        struct {
-            /* STROKE with the SORTED record layout (swin != 0): the op's sub-tile window — the union of its segments'
-             * windows — wx0 | wy0 << 8 | wcols << 16 | wrows << 24, the first of its wcols * wrows cell counters
-             * (osmt_prepass_args::cellcnt) and the records every cell's region has room for (= the op's virtual segments:
-             * a segment leaves at most one record per sub-tile).  swin == 0: the legacy slot layout (see osmt_srec). */
-            uint32_t swin, cell_off, stride, _spare;
-        };
-    };
+    int32_t x0, y0, x1, y1; /* inclusive extent of the op's points (empty: x0 > x1) */
     uint32_t aux;           /* STROKE: index into the stroke_aux table */
     uint32_t n_edges;       /* total edges over all rings */
     uint32_t first_pt;      /* first point of the op's FIRST ring: a one-ring polygon is binned without touching osmt_op / osmt_ring */
@@ -102,23 +91,11 @@ static_assert(sizeof(osmt_opinfo) == 64, "osmt_opinfo must be one 64-byte record
  * fill.rs:23-45).  Group index = arena_off + (sr - sr0) * ncols + (c - c0).  Written by k_fill_rows once per op — the
  * rows of an op are evaluated ONCE per tile, not once per sub-tile column.
  *
- * Stroke arena, SORTED layout (round 5; every op whose window cells x virtual segments fit OSMT_SORT_MAX_SLOTS): the
- * op owns one REGION of `stride` records per sub-tile (cell) of its window, region of cell c = arena_off + c * stride.
- * The lane of k_prebin that finds that a segment draws into a sub-tile takes the next free record of that cell's region
- * (atomicAdd on the cell's counter: inside one op — one generation, set_pixel keeps the larger alpha — the order of
- * the records is irrelevant) and writes it there; nothing is written for a sub-tile the segment cannot reach.  k_sublist
- * puts (region, count) into the op's list entry for that sub-tile, so k_raster fetches exactly the records of its own
- * sub-tile with ONE level of loads — until round 4 it read the 8-byte keys of ALL slots of the op (a polyline of five
- * edges and two stubs: ~90, two or three of them its own) and then the records: two dependent round trips and ~330
- * instructions per group of ops, a quarter of the kernel.  A cap stub's record carries traveled = -0.0 (an edge's is
- * >= +0.0; -0.0 + sd == +0.0 + sd for every sd >= 0, so the arithmetic of the walk cannot tell).
- *
- * LEGACY layout (long ways: an op of 60 segments across a whole tile would reserve 128 regions of 62 records): one SLOT
- * per (virtual segment, sub-tile of its window): the step ranges of the segment's perpendicular runs for that sub-tile
- * when it can draw there, a hole otherwise.  The slots of one op are contiguous (arena_off .. + rec_cap) and in segment
- * order; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
- * one coalesced load (k_raster: SEGCAP slots per round). */
-#define OSMT_SORT_MAX_SLOTS 4096u
+ * Stroke arena: one SLOT per (virtual segment, sub-tile of its window), written by k_stroke_bin: the step ranges of
+ * the segment's perpendicular runs for that sub-tile when it can draw there, a hole otherwise.  The slots of one op
+ * are contiguous (arena_off .. + rec_cap) and in segment order — no atomics, the layout is a pure function of the
+ * scene; `key` = the sub-tile of a slot (0xFFFFFFFF: hole), kept in its own array so that a wave filters 64 slots with
+ * one coalesced load. */
 struct alignas(16) osmt_srec {
     int32_t p1x, p1y, p2x, p2y;
     double traveled;      /* line.rs:31, before this edge (0 for a cap stub) */
@@ -142,24 +119,15 @@ struct osmt_blk_bbox {
  * k_raster needs to start on it resolved for THAT sub-tile.  k_raster then streams its own short list instead of
  * scanning the op bits of the whole tile (config 5: 9000 bits for ~100 drawing ops) and never touches osmt_opinfo. */
 struct alignas(16) osmt_ent {
-    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first record of THIS sub-tile's region (legacy layout: first slot of the op) */
+    uint32_t arena;      /* FILL: first word of the 16 coverage words of THIS sub-tile; STROKE: first slot of the op */
     uint32_t kind_color; /* kind | r << 8 | g << 16 | b << 24 */
     double opacity;
     uint32_t aux;        /* STROKE: index into the stroke_aux table; FILL_IMAGE: image id */
-    uint32_t nv;         /* STROKE: records of the op in THIS sub-tile (legacy layout: slots of the op in the stroke arena, rec_cap) */
+    uint32_t nv;         /* STROKE: slots of the op in the stroke arena (rec_cap) */
     uint32_t stage;      /* k_raster's own use while the entry sits in LDS */
-    uint32_t flags;      /* OSMT_ENT_LEGACY */
+    uint32_t _pad;
 };
 static_assert(sizeof(osmt_ent) == 32, "osmt_ent is two 16-byte loads");
-#define OSMT_ENT_LEGACY 1u /* STROKE: slots + keys instead of per-sub-tile regions */
-/* The first OSMT_LIST_FIXK entries of every (tile, sub-tile) list live at a FIXED place — entfix[(tile * nsub + sub) * FIXK + i]
- * — only the rest goes to the list arena behind the header's offset.  A sub-tile wave of k_raster knows that address from its
- * block index alone: it asks for the entries in the same breath as for the job record and the list header instead of one
- * dependent round trip later (config 2 has ~5 entries per sub-tile: the whole list).  0: every entry in the arena (round 4). */
-#ifndef OSMT_V_FIXK
-#define OSMT_V_FIXK 8
-#endif
-#define OSMT_LIST_FIXK OSMT_V_FIXK
 
 struct osmt_image_desc {
     uint64_t offset; /* first pixel in the image pool (double4 units) */
@@ -266,8 +234,7 @@ struct osmt_raster_args {
     const osmt_stroke_aux* aux;
     const osmt_dash_seg* dseg; /* [stroke][OSMT_MAX_DASH_SEGS]: DashSegments of the `main` calculators (dashed ops only) */
     const uint2* hdr;        /* [n_jobs][nsub]: (first entry, entry count) of the sub-tile's list (k_sublist) */
-    const osmt_ent* ent;     /* the lists (entries behind the first OSMT_LIST_FIXK of each) */
-    const osmt_ent* entfix;  /* [n_jobs][nsub][OSMT_LIST_FIXK]: the first entries of every list */
+    const osmt_ent* ent;     /* the lists */
     const uint32_t* fmask;   /* fill arena (words) */
     const osmt_srec* srec;   /* stroke arena */
     /* tiles of at most fold_max_ops ops have no lists: their sub-tile waves read the op bits and the op records themselves */
@@ -275,8 +242,7 @@ struct osmt_raster_args {
     uint32_t _pad1;
     const osmt_opinfo* info;
     const uint32_t* submask; /* [op][sub-tile row]: bit sx = the op draws into sub-tile (sx, row) */
-    const uint2* skey;       /* legacy stroke slots: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
-    const uint32_t* cellcnt; /* sorted stroke layout: records per (op, cell of its window) */
+    const uint2* skey;       /* per stroke slot: (its sub-tile sy * subs_per_row + sx, or 0xFFFFFFFF for a hole; item count | cap flag << 31) */
     const osmt_image_desc* images;
     const double4* image_pool;
     uint32_t n_images;
@@ -319,16 +285,14 @@ struct osmt_prepass_args {
      * the edge / cap stub (p1 == p2: draws nothing) and its op, bit 31 = the segment is a cap stub */
     int4* vpts;
     uint32_t* vop;
-    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries, [3] cell counters; zeroed by the launcher */
+    unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries; zeroed by the launcher */
     uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
     uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */
     osmt_ent* ent;      /* list arena */
-    osmt_ent* entfix;   /* [n_jobs][nsub][OSMT_LIST_FIXK] */
     unsigned long long ent_cap;
     uint32_t* fmask;
     osmt_srec* srec;
     uint2* skey;
-    uint32_t* cellcnt;  /* [srec_cap]: per (stroke op, cell of its sub-tile window) the records written so far (sorted layout); zeroed by k_opinfo */
     unsigned long long fmask_cap, srec_cap; /* arena capacities (groups / records); 0 = sizing pass: only the cursors are produced */
     /* host-mapped (pinned, coherent) word of the scene, or NULL: a kernel whose arena reservation does not fit — it cannot,
      * the arenas are sized by the same code; a future change to the binning that breaks the invariant must not show as

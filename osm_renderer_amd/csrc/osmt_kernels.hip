@@ -128,8 +128,8 @@ __device__ __forceinline__ int2 push_away_from(int2 self, int2 other, double by)
 
 /* opacity_calculator.rs:98-143 compute_segments, for one calculator: the first `max_out` segments go to `segs`, the number
  * of segments the reference pushes is returned. */
-__device__ __forceinline__ int compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap, osmt_dash_seg* segs, int max_out,
-                                double* total_len) {
+__device__ __forceinline__ int compute_segments(double hlw, const double* __restrict__ dashes, int n_dashes, int cap, osmt_dash_seg* segs,
+                                                int max_out, double* total_len) {
     double len_before = 0.0;
     int n = 0;
     for (int it = 0; it <= n_dashes; ++it) {
@@ -252,17 +252,6 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     const bool caps = is_stroke && (op.cap == OSMT_CAP_ROUND || op.cap == OSMT_CAP_SQUARE);
     osmt_cap_seg c0 = {0, 0, 0, 0, 0, 0u, 1.0}, c1 = {0, 0, 0, 0, 0, 0u, 1.0};
     unsigned long long cand = 0ull; /* slots reserved so far: one per (virtual segment, sub-tile of its window) */
-    int32_t ux0 = INT32_MAX, uy0 = INT32_MAX, ux1 = INT32_MIN, uy1 = INT32_MIN; /* union of the segments' sub-tile windows */
-    auto add_window = [&](const SubWindow& w) -> uint32_t {
-        const uint32_t wc = window_count(w);
-        if (wc) {
-            ux0 = min(ux0, w.sx0);
-            ux1 = max(ux1, w.sx1);
-            uy0 = min(uy0, w.sy0);
-            uy1 = max(uy1, w.sy1);
-        }
-        return wc;
-    };
     double traveled = 0.0;
     uint32_t seen = 0; /* running edge index + 1 over all rings (point_pairs.rs:36-40) */
     /* bounding boxes of the 64-edge blocks (ops with more than 64 edges only) */
@@ -316,7 +305,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
                     a.vpts[e] = make_int4(prev.x, prev.y, p.x, p.y);
                     a.vop[e] = o;
                     if (!(prev.x == p.x && prev.y == p.y)) { /* a degenerate edge draws nothing (line.rs:73-75) */
-                        cand += add_window(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
+                        cand += window_count(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
                         /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
                          * degenerate (`first` is consumed by a degenerate first edge) */
                         if (caps && seen == 1u) {
@@ -338,17 +327,16 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
      * offsets from a prefix scan): 2.3 M single-lane atomics on two addresses were what bounded this kernel on the
      * dense config (~1 atomic per clock at the L2) ---- */
     unsigned long long want_f = 0ull, want_s = 0ull; /* fill groups / stroke slots this op reserves */
-    uint32_t want_c = 0u;                             /* cell counters (sorted stroke layout) */
     uint32_t fill_geom_ok = 0u;
     if (is_stroke) {
         /* a stub that push_away_from rounds back onto its own start draws nothing (line.rs:73-75) */
         if (c0.valid && (c0.p1x != c0.p2x || c0.p1y != c0.p2y)) {
             c0.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-            cand += add_window(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
+            cand += window_count(vseg_window(c0.p1x, c0.p1y, c0.p2x, c0.p2y, c0.denom, ft, n_sub_x, n_sub_y));
         }
         if (c1.valid && (c1.p1x != c1.p2x || c1.p1y != c1.p2y)) {
             c1.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
-            cand += add_window(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
+            cand += window_count(vseg_window(c1.p1x, c1.p1y, c1.p2x, c1.p2y, c1.denom, ft, n_sub_x, n_sub_y));
         }
         if (caps) { /* the two stubs are the op's last two virtual segments; an invalid one is stored degenerate (p1 == p2) */
             const osmt_cap_seg* cs[2] = {&c0, &c1};
@@ -396,25 +384,6 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         oi.rec_cap = (uint32_t)cand;
         oi.stroke_ft = ft;
         want_s = cand;
-        /* Record layout (osmt_internal.h): SORTED — one region of `stride` records per sub-tile of the op's window, so that
-         * k_raster finds the records of its sub-tile without looking at the others' — whenever the regions stay small;
-         * long ways keep the slot + key layout.  The extent fields of the record are a fill's: a stroke keeps its window there. */
-        oi.swin = 0u;
-        oi.cell_off = 0u;
-        oi.stride = 0u;
-        oi._spare = 0u;
-        if (cand != 0ull && ux0 <= ux1) {
-            const uint32_t wcols = (uint32_t)(ux1 - ux0 + 1), wrows = (uint32_t)(uy1 - uy0 + 1);
-            const uint32_t n_vs = n_edges + (caps ? 2u : 0u);
-            const unsigned long long slots = (unsigned long long)wcols * wrows * n_vs;
-            if (slots <= (unsigned long long)OSMT_SORT_MAX_SLOTS) {
-                oi.swin = (uint32_t)ux0 | ((uint32_t)uy0 << 8) | (wcols << 16) | (wrows << 24);
-                oi.stride = n_vs;
-                oi.rec_cap = (uint32_t)slots;
-                want_s = slots;
-                want_c = wcols * wrows;
-            }
-        }
     } else if (!none) {
         /* fills: rows ytop+1 .. ybot carry records (fill.rs:66-72), spans lie inside the points' x range */
         const int32_t ylo = max(oi.y0 + 1, 0), yhi = min(oi.y1, W - 1);
@@ -433,19 +402,14 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         const uint32_t s_lo = (uint32_t)want_s & 0xFFFFu, s_hi = (uint32_t)(want_s >> 16);
         const uint32_t f_incl = wave_incl_scan(f);
         const unsigned long long s_incl = ((unsigned long long)wave_incl_scan(s_hi) << 16) + wave_incl_scan(s_lo);
-        const uint32_t c_incl = wave_incl_scan(want_c); /* at most 2048 cells per op */
-        const uint32_t c_tot = (uint32_t)__builtin_amdgcn_readlane((int)c_incl, OPINFO_THREADS - 1);
         const uint32_t f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_incl, OPINFO_THREADS - 1);
         const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), OPINFO_THREADS - 1) << 32) |
                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, OPINFO_THREADS - 1);
-        unsigned long long f_base = 0ull, s_base = 0ull, c_base = 0ull;
+        unsigned long long f_base = 0ull, s_base = 0ull;
         if (lane == 0u) {
             if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
             if (s_tot) s_base = atomicAdd(&a.cursors[1], s_tot);
-            if (c_tot) c_base = atomicAdd(&a.cursors[3], (unsigned long long)c_tot);
         }
-        c_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c_base >> 32)) << 32) |
-                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c_base);
         f_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f_base >> 32)) << 32) |
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f_base);
         s_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_base >> 32)) << 32) |
@@ -453,18 +417,11 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         if (want_s) {
             const unsigned long long off = s_base + (s_incl - want_s);
             oi.arena_off = (uint32_t)off;
-            /* the cell counters share the arena's capacity: an op has at most as many cells as records */
-            const unsigned long long c_off = c_base + (c_incl - want_c);
-            if (a.srec_cap && (off + want_s > a.srec_cap || c_off + want_c > a.srec_cap)) { /* never: the arena was sized by this same code */
+            if (a.srec_cap && off + want_s > a.srec_cap) { /* never: the arena was sized by this same code */
                 oi.rec_cap = 0;
                 if (a.err) *(volatile uint32_t*)a.err = OSMT_PREPASS_ERR_STROKE_ARENA;
-            } else if (want_c) {
-                oi.cell_off = (uint32_t)c_off;
             }
         }
-        /* every cell starts empty (not in the sizing pass): the counters of the wave's ops are one contiguous piece */
-        if (a.srec_cap && c_base + c_tot <= a.srec_cap)
-            for (uint32_t i = lane; i < c_tot; i += OPINFO_THREADS) a.cellcnt[c_base + i] = 0u;
         if (want_f) {
             const unsigned long long off = f_base + (f_incl - f);
             oi.arena_off = (uint32_t)off;
@@ -576,9 +533,13 @@ struct alignas(8) SegDer {
 static_assert(sizeof(SegDer) == 40, "five 8-byte LDS words");
 constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_CAP = 8u, SEGW_SLOW = 16u;
 
+#ifndef OSMT_V_FILTCAP
+#define OSMT_V_FILTCAP 256
+#endif
+constexpr uint32_t FILTCAP = OSMT_V_FILTCAP; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
 struct RasterShared {
-    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] record fetches of groups [5] fill visits
-                                * [7] entries walked alone (legacy layout, or more than SEGCAP records in the sub-tile) */
+    OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] filter passes of groups [4] groups ended by the
+                                * 33rd kept record [5] fill visits [6] ops with more than SEGCAP records in the sub-tile [7] ops with more than FILTCAP slots */
     osmt_srec seg[SEGCAP];          /* records of the current group that belong to this sub-tile, compacted */
     SegDer der[SEGCAP];
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
@@ -591,6 +552,8 @@ struct RasterShared {
 #endif
 };
 static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
+static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP % 256u == 0u,
+              "the filter pass borrows seg[] for its entry marks (one 4-byte store per lane) and der[] for the kept slots");
 
 struct SubRect {
     int32_t x0, y0, x1, y1; /* inclusive */
@@ -903,49 +866,10 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
                 const osmt_raster_args* la = late_args();
                 const osmt_dash_seg* sgs = cp ? &sa->caps_seg : la->dseg + (size_t)(sa - la->aux) * OSMT_MAX_DASH_SEGS;
                 walk_dashed(st, kc, cp ? 1 : sa->main_n_segs, (cp ? sa->caps_has_orig : sa->main_has_orig) != 0, cp ? 0.0 : sa->main_total_len,
-                            cp ? 0.0 : sa->main_r_total, sgs, sa->half_width, fabs(r.traveled) /* a stub's is -0.0 */, initial_opacity, sh.plane);
+                            cp ? 0.0 : sa->main_r_total, sgs, sa->half_width, r.traveled, initial_opacity, sh.plane);
             }
         }
     }
-}
-
-/* A stroke record as four 16-byte words — how it travels from the arena into LDS (a struct with 16-bit members that is
- * zero-initialised and conditionally loaded ends up in scratch memory: the raw words stay in registers):
- * q0 = p1x p1y p2x p2y · q1 = traveled, denom · q2 = rdenom, k_lo0, k_lo1 · q3 = m_lo0, m_lo1, k_n0 | k_n1 << 16, n_x0 | n_x1 << 16 */
-struct RawRec {
-    uint4 q0, q1, q2, q3;
-};
-static_assert(offsetof(osmt_srec, traveled) == 16 && offsetof(osmt_srec, rdenom) == 32 && offsetof(osmt_srec, m_lo0) == 48 &&
-              offsetof(osmt_srec, k_n0) == 56 && offsetof(osmt_srec, n_x0) == 60, "RawRec names the words of osmt_srec");
-__device__ __forceinline__ RawRec raw_rec_load(const osmt_srec* __restrict__ p) {
-    const uint4* __restrict__ s = reinterpret_cast<const uint4*>(p);
-    RawRec r;
-    r.q0 = s[0];
-    r.q1 = s[1];
-    r.q2 = s[2];
-    r.q3 = s[3];
-    return r;
-}
-__device__ __forceinline__ uint32_t raw_rec_items(const RawRec& r) { /* k_n0 + k_n1 + n_x0 + n_x1: every item is one perpendicular run */
-    return (r.q3.z & 0xFFFFu) + (r.q3.z >> 16) + (r.q3.w & 0xFFFFu) + (r.q3.w >> 16);
-}
-__device__ __forceinline__ bool raw_rec_is_cap(const RawRec& r) { return (int32_t)r.q1.y < 0; } /* traveled == -0.0: a cap stub (osmt_internal.h) */
-__device__ __forceinline__ void raw_rec_store(osmt_srec* dst, const RawRec& r) {
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    d[0] = r.q0;
-    d[1] = r.q1;
-    d[2] = r.q2;
-    d[3] = r.q3;
-}
-__device__ __forceinline__ SegDer seg_derive_raw(const RawRec& r) {
-    osmt_srec t;
-    t.p1x = (int32_t)r.q0.x;
-    t.p1y = (int32_t)r.q0.y;
-    t.p2x = (int32_t)r.q0.z;
-    t.p2y = (int32_t)r.q0.w;
-    t.k_n0 = (uint16_t)(r.q3.z & 0xFFFFu);
-    t.k_n1 = (uint16_t)(r.q3.z >> 16);
-    return seg_derive(t, raw_rec_is_cap(r));
 }
 
 /* fill.rs:23-45 for ONE row without storing its records: stream them in (x_min, edge) order by
@@ -1047,9 +971,11 @@ __device__ __noinline__ uint32_t fill_row_streaming(const osmt_ring* __restrict_
 constexpr uint32_t FILL_GROUP = OSMT_V_FILL_GROUP;
 constexpr uint32_t FILL_EMAX = 128;
 #ifndef OSMT_V_FILL_RMAX
-#define OSMT_V_FILL_RMAX 512
+#define OSMT_V_FILL_RMAX 384
 #endif
-constexpr uint32_t FILL_RMAX = OSMT_V_FILL_RMAX; /* crossing records of one pass (LDS: 12 bytes each) */
+/* crossing records of one pass (LDS: 12 bytes each).  384: the workgroup's LDS is 9.5 KB and 16 single-wave workgroups fit a CU
+ * (512: 11 KB, 14 — measured in round 5: pre-pass 0.252 -> 0.241 ms on config 2, 3.28 -> 3.15 on 256 config-5 tiles) */
+constexpr uint32_t FILL_RMAX = OSMT_V_FILL_RMAX;
 struct FillShared {
     int32_t r_xmin[FILL_RMAX];
     int32_t r_xmax[FILL_RMAX];
@@ -1396,12 +1322,10 @@ struct StrokeBinSeg {
     double ft;          /* feather_to of the op: max(|half_width| + 0.5, 1.0) */
     int32_t sx0, sy0;   /* first sub-tile of the window */
     uint32_t ncols;     /* window width in sub-tiles */
-    uint32_t slot0;     /* legacy layout: absolute arena slot of the window's first sub-tile; sorted: first record of the op's first region */
+    uint32_t slot0;     /* absolute arena slot of the window's first sub-tile */
     uint32_t op, job;
     uint32_t is_cap;
-    uint32_t swin;      /* the op's window (osmt_opinfo::swin), 0: legacy slots + keys */
-    uint32_t cell_base; /* sorted layout: the op's first cell counter */
-    uint32_t stride;    /* sorted layout: records per region */
+    uint32_t _pad;
 };
 struct StrokeBinShared {
     uint32_t incl[64]; /* inclusive pair count over the block's segments */
@@ -1414,7 +1338,7 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
                                                 const double* __restrict__ g_den, const double* __restrict__ g_rden, uint32_t n_vsegs,
                                                 uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
                                                 osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                                uint32_t* __restrict__ g_cnt, uint32_t* __restrict__ g_cellcnt) {
+                                                uint32_t* __restrict__ g_cnt) {
     /* ---- step A, lane = virtual segment: its op, end points, sub-tile window — everything k_opinfo left per segment
      * comes in with ONE level of loads, the op's record with a second ---- */
     const uint32_t g = blk * 64u + lane;
@@ -1436,21 +1360,16 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
             const osmt_opinfo* __restrict__ oi = &g_info[o];
             sg.ft = oi->stroke_ft;
             const uint32_t rec_cap = oi->rec_cap, arena_off = oi->arena_off;
-            const uint32_t swin = oi->swin;
             const SubWindow w = vseg_window(sg.rec.p1x, sg.rec.p1y, sg.rec.p2x, sg.rec.p2y, sg.rec.denom, sg.ft, n_sub_x, n_sub_y);
             const uint32_t wc = window_count(w);
-            /* always: k_opinfo reserved this very window (legacy), or the regions of the union of the op's windows (sorted) */
-            if (wc && (swin ? rec_cap != 0u : (unsigned long long)cand_off + wc <= rec_cap)) {
+            if (wc && (unsigned long long)cand_off + wc <= rec_cap) { /* always: k_opinfo reserved this very window */
                 sg.sx0 = w.sx0;
                 sg.sy0 = w.sy0;
                 sg.ncols = (uint32_t)(w.sx1 - w.sx0 + 1);
-                sg.slot0 = swin ? arena_off : arena_off + cand_off;
+                sg.slot0 = arena_off + cand_off;
                 sg.op = o;
                 sg.job = g_op_job[o];
-                sg.swin = swin;
-                sg.cell_base = oi->cell_off;
-                sg.stride = oi->stride;
-                if (sg.is_cap) sg.rec.traveled = -0.0; /* the record says what it is (osmt_internal.h) */
+                sg._pad = 0u;
                 sg.rec.k_lo0 = sg.rec.k_lo1 = sg.rec.m_lo0 = sg.rec.m_lo1 = 0;
                 sg.rec.k_n0 = sg.rec.k_n1 = sg.rec.n_x0 = sg.rec.n_x1 = 0;
                 sh.seg[lane] = sg;
@@ -1482,29 +1401,15 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
         osmt_srec rec = sg.rec;
         osmt_item_ranges ir;
         const uint32_t cnt = osmt_seg_ranges(rec.p1x, rec.p1y, rec.p2x, rec.p2y, rec.denom, sg.ft, x0, y0, x0 + SUB - 1, y0 + SUBH - 1, &ir);
-        const uint32_t swin = sg.swin;
-        size_t slot = (size_t)sg.slot0 + j;
+        const size_t slot = (size_t)sg.slot0 + j;
         if (cnt == 0u) {
-            if (!swin) g_skey[slot] = make_uint2(0xFFFFFFFFu, 0u); /* legacy: a hole; sorted: nothing is written at all */
+            g_skey[slot] = make_uint2(0xFFFFFFFFu, 0u);
             continue;
         }
         rec.k_lo0 = ir.k_lo0; rec.k_n0 = (uint16_t)ir.k_n0; rec.k_lo1 = ir.k_lo1; rec.k_n1 = (uint16_t)ir.k_n1;
         rec.m_lo0 = ir.m_lo0; rec.n_x0 = (uint16_t)ir.n_x0; rec.m_lo1 = ir.m_lo1; rec.n_x1 = (uint16_t)ir.n_x1;
-        if (swin) {
-            /* the next free record of this sub-tile's region (any order: one op = one generation, max-alpha) */
-            const uint32_t cell = ((uint32_t)sy - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + ((uint32_t)sx - (swin & 255u));
-            const uint32_t rank = atomicAdd(&g_cellcnt[sg.cell_base + cell], 1u);
-            if (rank >= sg.stride) continue; /* never: a segment leaves one record per sub-tile, the region has room for all of them */
-            slot = (size_t)sg.slot0 + (size_t)cell * sg.stride + rank;
-            g_srec[slot] = rec;
-            /* the op's bit for k_sublist (nobody waits for the old value), and whoever took the region's first record counts
-             * the op into that sub-tile's list */
-            atomicOr(&g_submask[(size_t)sg.op * sub_rows + (uint32_t)sy], 1u << sx);
-            if (rank == 0u) atomicAdd(g_cnt + ((size_t)sg.job * sub_rows + (uint32_t)sy) * (uint32_t)n_sub_x + (uint32_t)sx, 1u);
-            continue;
-        }
-        g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
         g_srec[slot] = rec;
+        g_skey[slot] = make_uint2((uint32_t)(sy * n_sub_x + sx), cnt | (sg.is_cap << 31));
         /* the thread that sets an op's bit first also counts the op into that sub-tile's list (k_sublist) */
         const uint32_t bit = 1u << sx;
         if (!(atomicOr(&g_submask[(size_t)sg.op * sub_rows + (uint32_t)sy], bit) & bit))
@@ -1515,12 +1420,7 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
 /* Both binning jobs in ONE launch: blocks [0, n_vblk) bin 64 stroke segments each (latency-bound: a bisection, a chain
  * of dependent loads, scattered 72-byte stores), the rest build the coverage rows of FILL_GROUP ops each (issue-bound) —
  * the two kinds overlap on the machine instead of running back to back. */
-#ifdef OSMT_V_PREBIN_WAVES
-#define OSMT_PREBIN_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSMT_V_PREBIN_WAVES, OSMT_V_PREBIN_WAVES)))
-#else
-#define OSMT_PREBIN_BOUNDS __launch_bounds__(64)
-#endif
-__global__ OSMT_PREBIN_BOUNDS void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
+__global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
                                                const double* __restrict__ g_trav, const double* __restrict__ g_den,
                                                const double* __restrict__ g_rden, const int4* __restrict__ g_vpts,
@@ -1529,7 +1429,7 @@ __global__ OSMT_PREBIN_BOUNDS void k_prebin(const osmt_op* __restrict__ g_ops, u
                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
                                                const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                               uint32_t* __restrict__ g_cnt, uint32_t* __restrict__ g_cellcnt) {
+                                               uint32_t* __restrict__ g_cnt) {
     __shared__ union {
         FillShared fill;
         StrokeBinShared bin;
@@ -1543,7 +1443,7 @@ __global__ OSMT_PREBIN_BOUNDS void k_prebin(const osmt_op* __restrict__ g_ops, u
 #endif
     if (b < n_vblk)
         stroke_bin_body(shu.bin, b, threadIdx.x, g_info, g_vpts, g_vop, g_trav, g_den, g_rden, n_vsegs, scale, sub_rows, g_submask, g_cand_off,
-                        g_srec, g_skey, g_op_job, g_cnt, g_cellcnt);
+                        g_srec, g_skey, g_op_job, g_cnt);
     else
         fill_rows_body(shu.fill, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
                        g_op_job, g_cnt);
@@ -1567,8 +1467,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              uint32_t g_sub_rows, const uint32_t* __restrict__ g_cnt,
                                                              unsigned long long* __restrict__ g_cursor, uint2* __restrict__ g_hdr,
                                                              osmt_ent* __restrict__ g_ent, unsigned long long ent_cap, uint32_t* g_err,
-                                                             uint32_t g_fold_max_ops, osmt_ent* __restrict__ g_entfix) {
-    constexpr uint32_t FIXK = OSMT_LIST_FIXK; /* entries of a list that live at a fixed place (osmt_internal.h) */
+                                                             uint32_t g_fold_max_ops) {
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1580,10 +1479,43 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
     const uint32_t nsx = W / SUB;
     const uint32_t nsub = nsx * g_sub_rows;
     const uint32_t* __restrict__ cnt = g_cnt + (size_t)tile * nsub;
-    for (uint32_t i = tid; i < nsub; i += SUBLIST_THREADS) {
-        const uint32_t c = cnt[i];
-        s_off[i] = c > FIXK ? c - FIXK : 0u; /* the arena takes what does not fit the list's fixed slots */
-    }
+    /* The kernel is a chain of dependent round trips — counts -> (scan) -> the tile's reservation -> job -> op bits -> op
+     * records -> entries — with one workgroup per tile and nothing else to do meanwhile.  Round 5: what does not depend on the
+     * reservation is asked for BEFORE it: the job record with the counts, every wave's first 64 op words while wave 0 scans,
+     * their op records while its atomicAdd is on its way. */
+    const osmt_tile_job job = g_jobs[tile];
+    const uint32_t n_ops = job.n_ops;
+    for (uint32_t i = tid; i < nsub; i += SUBLIST_THREADS) s_off[i] = cnt[i];
+    auto load_bits = [&](uint32_t sy, uint32_t b0) -> uint32_t {
+        const uint32_t i = b0 + lane;
+        return (i < n_ops && sy < g_sub_rows) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sy] : 0u;
+    };
+    /* what an entry takes from its op's record (the arena position is resolved per sub-tile below) */
+    struct OpRec {
+        osmt_ent e;
+        uint32_t geom, arena0;
+        bool is_stroke;
+    };
+    auto fetch = [&](uint32_t w, uint32_t b0) -> OpRec {
+        OpRec r;
+        r.e = {};
+        r.geom = 0u;
+        r.arena0 = 0u;
+        r.is_stroke = false;
+        if (w != 0u) {
+            const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + b0 + lane];
+            const uint32_t kind = hi->kind;
+            r.is_stroke = kind == OSMT_OP_STROKE;
+            r.arena0 = hi->arena_off;
+            r.geom = hi->fill_geom;
+            r.e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
+            r.e.opacity = hi->opacity;
+            r.e.aux = r.is_stroke ? hi->aux : hi->image_id;
+            r.e.nv = r.is_stroke ? hi->rec_cap : 0u;
+        }
+        return r;
+    };
+    const uint32_t pre_w = load_bits(wave, 0u); /* the wave's first row is row `wave` */
     __syncthreads();
     if (wave == 0u) {
         /* lane l owns the contiguous piece [l*per, (l+1)*per): serial inside, wave scan across */
@@ -1606,15 +1538,14 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
             if (!s_base[1] && g_err) *(volatile uint32_t*)g_err = OSMT_PREPASS_ERR_LIST_ARENA; /* the tile would be blank: tell the host */
         }
     }
+    const OpRec pre = fetch(pre_w, 0u);
     __syncthreads();
     const uint32_t base = s_base[0];
     const bool fits = s_base[1] != 0u;
-    const osmt_tile_job job = g_jobs[tile];
-    const uint32_t n_ops = job.n_ops;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     for (uint32_t sy = wave; sy < g_sub_rows; sy += SUBLIST_THREADS / 64u) {
         /* lane sx keeps the write cursor of column sx */
-        uint32_t cur = 0u, row_n = 0u, filled = 0u; /* arena position of the list's entry FIXK; entries still to come; entries written */
+        uint32_t cur = 0u, row_n = 0u;
         if (lane < nsx) {
             const uint32_t c = cnt[sy * nsx + lane];
             cur = base + s_off[sy * nsx + lane];
@@ -1622,36 +1553,16 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
             g_hdr[(size_t)tile * nsub + sy * nsx + lane] = make_uint2(cur, row_n);
         }
         if (__ballot(row_n != 0u) == 0ull) continue; /* nothing draws into this row (or the reservation failed) */
-        auto load_bits = [&](uint32_t b0) -> uint32_t {
-            const uint32_t i = b0 + lane;
-            return (i < n_ops) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sy] : 0u;
-        };
-        uint32_t bits_next = load_bits(0);
+        const bool first_row = sy == wave;
+        uint32_t bits_next = first_row ? pre_w : load_bits(sy, 0u);
         for (uint32_t b0 = 0; b0 < n_ops; b0 += 64u) {
             const uint32_t w = bits_next;
-            if (b0 + 64u < n_ops) bits_next = load_bits(b0 + 64u);
+            if (b0 + 64u < n_ops) bits_next = load_bits(sy, b0 + 64u);
             if (__ballot(w != 0u) == 0ull) continue;
-            osmt_ent e = {};
-            uint32_t geom = 0u, arena0 = 0u;
-            uint32_t swin = 0u, cell_base = 0u, stride = 0u; /* sorted stroke layout: the op's window, first cell counter, region size */
-            bool is_stroke = false;
-            if (w != 0u) {
-                const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + b0 + lane];
-                const uint32_t kind = hi->kind;
-                is_stroke = kind == OSMT_OP_STROKE;
-                arena0 = hi->arena_off;
-                geom = hi->fill_geom;
-                e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
-                e.opacity = hi->opacity;
-                e.aux = is_stroke ? hi->aux : hi->image_id;
-                e.nv = is_stroke ? hi->rec_cap : 0u;
-                if (is_stroke) {
-                    swin = hi->swin;
-                    cell_base = hi->cell_off;
-                    stride = hi->stride;
-                    e.flags = swin ? 0u : OSMT_ENT_LEGACY;
-                }
-            }
+            const OpRec rec = (first_row && b0 == 0u) ? pre : fetch(w, b0);
+            osmt_ent e = rec.e;
+            const uint32_t geom = rec.geom, arena0 = rec.arena0;
+            const bool is_stroke = rec.is_stroke;
             const uint32_t sr0 = geom & 255u, c0 = (geom >> 8) & 255u, ncols = (geom >> 16) & 255u;
             for (uint32_t sx = 0; sx < nsx; ++sx) {
                 const bool hit = (w >> sx) & 1u;
@@ -1659,26 +1570,15 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                 if (bal == 0ull) continue;
                 const uint32_t col_cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)sx);
                 const uint32_t col_left = (uint32_t)__builtin_amdgcn_readlane((int)row_n, (int)sx);
-                const uint32_t col_filled = (uint32_t)__builtin_amdgcn_readlane((int)filled, (int)sx);
                 const uint32_t pos = (uint32_t)__popcll(bal & lanes_below);
                 if (hit && pos < col_left) {
-                    /* FILL: word index of this sub-tile's 16 rows; STROKE: the region of this sub-tile's records and how many
-                     * the binning left there (legacy layout: the op's first slot, e.nv = all its slots) */
+                    /* FILL: word index of this sub-tile's 16 rows; STROKE: the op's first slot */
                     e.arena = is_stroke ? arena0 : (arena0 + (sy - sr0) * ncols + (sx - c0)) * SUBH;
-                    if (swin) { /* (the count is read by k_raster's staging lane, beside the op's constants: here it would be a dependent load per column) */
-                        const uint32_t cell = (sy - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sx - (swin & 255u));
-                        e.arena = arena0 + cell * stride;
-                        e.nv = cell_base + cell;
-                    }
-                    const uint32_t idx = col_filled + pos; /* place in the sub-tile's list */
-                    if (idx < FIXK)
-                        g_entfix[((size_t)tile * nsub + sy * nsx + sx) * FIXK + idx] = e;
-                    else
-                        g_ent[(size_t)col_cur + (idx - FIXK)] = e;
+                    g_ent[(size_t)col_cur + pos] = e;
                 }
                 const uint32_t took = min((uint32_t)__popcll(bal), col_left);
                 if (lane == sx) {
-                    filled += took;
+                    cur += took;
                     row_n -= took;
                 }
             }
@@ -1744,13 +1644,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
     const uint32_t sub = rest % nsub;
     if (tile >= a.n_jobs) return;
 
-    /* the first entries of this sub-tile's list sit at a fixed place (osmt_internal.h): asked for NOW, beside the job record
-     * and the list header, not one round trip behind the header (lanes beyond the list read slots nobody looks at) */
-    constexpr uint32_t FIXK = OSMT_LIST_FIXK;
-    /* (the small-batch instantiation builds most lists itself and reads the fixed entries of a long-list tile where it needs them) */
-    osmt_ent e_first;
-    if (!FOLD) e_first = a.entfix[((size_t)tile * nsub + sub) * FIXK + (FIXK != 0u ? lane & (FIXK - 1u) : 0u)];
-    static_assert((OSMT_LIST_FIXK & (OSMT_LIST_FIXK - 1)) == 0, "FIXK is a power of two (or 0)");
     const osmt_tile_job job = a.jobs[tile];
     SubRect rc;
     const uint32_t sub_x = sub % subs_per_row, sub_y = sub / subs_per_row;
@@ -1823,13 +1716,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
 #else
     const uint32_t n_ent = hdr.y;
 #endif
-    const osmt_ent* OSMT_R my_ent = g_ent + hdr.x; /* entry FIXK of the list */
-    if (FIXK != 0u && !FOLD) {
-        /* parked in LDS until the first chunk takes them (held in registers they would stay alive through the whole chunk loop) */
-        static_assert(sizeof(osmt_ent) * OSMT_LIST_FIXK <= sizeof(sh.seg), "the fixed entries fit the record array");
-        if (lane < FIXK) reinterpret_cast<osmt_ent*>(sh.seg)[lane] = e_first;
-        __syncthreads();
-    }
+    const osmt_ent* OSMT_R my_ent = g_ent + hdr.x;
 
     for (uint32_t base = 0; base < n_ent; base += OPCHUNK) {
         const uint32_t total = min((uint32_t)OPCHUNK, n_ent - base);
@@ -1856,38 +1743,18 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     t.opacity = hi->opacity;
                     t.aux = strk ? hi->aux : hi->image_id;
                     t.nv = strk ? hi->rec_cap : 0u;
-                    /* FILL: word index of this sub-tile's 16 rows (sr0 | c0 << 8 | ncols << 16); STROKE: this sub-tile's region
-                     * of the op's records and their number (legacy layout: the op's first slot, all its slots) */
+                    /* FILL: word index of this sub-tile's 16 rows (sr0 | c0 << 8 | ncols << 16); STROKE: the op's first slot */
                     t.arena = strk ? arena0
                                    : (arena0 + (sub / subs_per_row - (geom & 255u)) * ((geom >> 16) & 255u) + (sub % subs_per_row - ((geom >> 8) & 255u))) * SUBH;
                     t.stage = 0u;
-                    t.flags = 0u;
-                    if (strk) {
-                        const uint32_t swin = hi->swin;
-                        if (swin) {
-                            const uint32_t stride = hi->stride;
-                            const uint32_t cell = (sub / subs_per_row - ((swin >> 8) & 255u)) * ((swin >> 16) & 255u) + (sub % subs_per_row - (swin & 255u));
-                            t.arena = arena0 + cell * stride;
-                            t.nv = hi->cell_off + cell;
-                        } else {
-                            t.flags = OSMT_ENT_LEGACY;
-                        }
-                    }
+                    t._pad = 0u;
                     tmp[r - base] = t;
                 }
             }
             __syncthreads();
             if (hit) e = tmp[fresh_lane()];
         } else if (hit) {
-            if (FIXK != 0u) {
-                const uint32_t t_ = fresh_lane();
-                if (base == 0u && t_ < FIXK)
-                    e = FOLD ? late_args()->entfix[((size_t)tile * nsub + sub) * FIXK + t_] : reinterpret_cast<const osmt_ent*>(sh.seg)[t_];
-                else
-                    e = my_ent[base + t_ - FIXK];
-            } else {
-                e = my_ent[base + lane];
-            }
+            e = my_ent[base + lane];
         }
         const uint32_t e_kind = e.kind_color & 255u;
         const bool is_stroke = hit && e_kind == OSMT_OP_STROKE;
@@ -1895,14 +1762,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & ((1ull << fresh_lane()) - 1ull));
         /* slots of the stroke entries, prefix-summed over the chunk's lanes: the groups of the filter passes are cut out
          * of this scan with a ballot instead of a scalar loop over the entries (clamped: only "more than a pass" matters) */
-        /* (an entry of the legacy slot layout, or one with more records than the LDS holds, counts as "more than a group":
-         * it is cut out alone and walked SEGCAP slots / records at a time) */
-        const bool e_legacy = is_stroke && (e.flags & OSMT_ENT_LEGACY) != 0u;
-        /* how many records the binning left in this sub-tile's region of the op: the entry names the counter (k_sublist would
-         * have to wait for it column by column); asked for here, it arrives with the coverage words and stroke constants the
-         * staging lanes request below — no round trip of its own */
-        uint32_t rec_cnt = e.nv;
-        if (is_stroke && !e_legacy) rec_cnt = late_args()->cellcnt[e.nv];
+        const uint32_t nv_incl = wave_incl_scan(is_stroke ? min(e.nv, 1u << 20) : 0u);
         __syncthreads(); /* the previous chunk's list is consumed */
         if (hit) {
             StagedEnt se;
@@ -1914,7 +1774,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             se.c2 = fc ? e.opacity * cb : cb;
             se.op = fc ? 1.0 - e.opacity : e.opacity;
             se.arena = e.arena;
-            se.kind_stage = e_kind | ((my_stage < (uint32_t)STAGECAP ? my_stage : 255u) << 8) | (e_legacy ? 1u << 16 : 0u);
+            se.kind_stage = e_kind | ((my_stage < (uint32_t)STAGECAP ? my_stage : 255u) << 8);
             se.aux = e.aux;
             se.nv = e.nv;
             sh.ent[lane] = se;
@@ -1943,8 +1803,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 sh.sconst[my_stage] = kc;
             }
         }
-        if (is_stroke) sh.ent[fresh_lane()].nv = rec_cnt;
-        const uint32_t nv_incl = wave_incl_scan(is_stroke ? ((e_legacy || rec_cnt > (uint32_t)SEGCAP) ? (uint32_t)SEGCAP + 1u : rec_cnt) : 0u);
         const bool any_stroke = sbal != 0ull;
         if (any_stroke && !plane_clean) {
             static_assert((PLANE_STRIDE * SUBH) % NTHREADS == 0, "the plane is cleared in whole wave strides");
@@ -1960,17 +1818,16 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         if (total < 1000u) g0 = total; /* ablation: the chunk is staged, no group is filtered or drawn */
 #endif
         while (g0 < total) {
-        /* ---- group = consecutive list entries whose stroke RECORDS — the entry says where this sub-tile's are and how many
-         * (sorted layout, osmt_internal.h) — fit the SEGCAP records the LDS holds; an entry with more, or one of the legacy
-         * slot layout, forms a group of its own and is walked SEGCAP records / slots at a time ---- */
+        /* ---- group = consecutive list entries whose stroke slots fit in the SEGCAP lanes of ONE filter pass; an op with
+         * more slots forms a group of its own and is filtered SEGCAP slots at a time ---- */
         uint32_t gend = total, V = 0;
         bool big = false;
-        uint32_t s_before = 0u;           /* records of the chunk's entries in front of the group */
+        uint32_t s_before = 0u;           /* slots of the chunk's entries in front of the group */
         if (any_stroke) {
             s_before = g0 ? (uint32_t)__builtin_amdgcn_readlane((int)nv_incl, (int)g0 - 1) : 0u;
-            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)SEGCAP);
+            const unsigned long long over = __ballot(lane >= g0 && lane < total && nv_incl - s_before > (uint32_t)FILTCAP);
             if (over) gend = (uint32_t)__builtin_ctzll(over);
-            if (gend == g0) { /* the first entry alone is more than a group */
+            if (gend == g0) { /* the first entry alone has more slots than one filter pass looks at */
                 OSMT_DBG(if (lane == 0) sh.dbg[7] += 1u;)
                 big = true;
                 gend = g0 + 1u;
@@ -1980,40 +1837,123 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         if (V) {
             OSMT_DBG(if (lane == 0) sh.dbg[3] += 1u;)
-            /* ---- the group's records, ONE level of loads: lane c takes record c of the group = record (c - start of its
-             * entry) of that entry's region.  (Until round 4 the entries named all slots of their ops and the wave read the
-             * keys of up to 256 of them to find its own: key -> record, two dependent round trips and ~330 instructions.) ---- */
-            uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.der); /* mark[c]: the entry whose records start at record c of the group */
-            static_assert(sizeof(sh.der) >= 64 && SEGCAP <= 64, "one mark byte per lane");
+            /* ---- filter pass of the GROUP: every slot of every stroke entry of the group is looked at once, FILTCAP slots
+             * (four rounds of 64 lanes, all key loads in flight together); the records of THIS sub-tile are compacted in
+             * slot order (= op order, segment order).  Round 3 looked at SEGCAP slots per pass: an op of 90 slots — five
+             * edges and two stubs with windows of a dozen sub-tiles — took three passes (key -> record -> barrier each)
+             * and walked the two or three records it kept in up to three under-filled walks. ---- */
+            uint8_t* const mark = reinterpret_cast<uint8_t*>(sh.seg);   /* mark[s]: list entry whose slots start at virtual slot s */
+            uint32_t* const tmp = reinterpret_cast<uint32_t*>(sh.der);  /* [c]: arena slot of kept record c, [SEGCAP + c]: its item count | cap flag */
             const uint32_t t_ = fresh_lane();
-            if (t_ < 16u) reinterpret_cast<uint32_t*>(mark)[t_] = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t i = 0; i < FILTCAP; i += 256u) reinterpret_cast<uint32_t*>(mark + i)[t_] = 0xFFFFFFFFu;
             __syncthreads();
             /* exclusive prefix = the inclusive one of the lane below (wave_shr:1; lane 0 keeps the 0) */
             const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nv_incl, 0x138, 0xF, 0xF, false);
             const bool mine = t_ >= g0 && t_ < gend && nv_incl != excl;
             if (mine) mark[excl - s_before] = (uint8_t)t_;
             __syncthreads();
-            const unsigned long long st = __ballot(mark[t_] != 0xFFu);
-            const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
-            const unsigned long long m = st & upto;
-            RawRec r = {};
-            const bool have = t_ < V; /* (then m != 0: record 0 of the group starts an entry) */
-            if (have) {
-                const uint32_t s0 = 63u - (uint32_t)__builtin_clzll(m);
-                const uint32_t en = mark[s0];
-                r = raw_rec_load(&g_srec[sh.ent[en].arena + (t_ - s0)]);
+            constexpr uint32_t NR = FILTCAP / 64u;
+            uint32_t ridx[NR];
+            uint2 key[NR];
+            unsigned long long bal[NR];
+            uint32_t carry_pos = 0u, carry_ent = g0; /* the last entry start in the rounds so far */
+#pragma unroll
+            for (uint32_t r = 0; r < NR; ++r) {
+                ridx[r] = 0xFFFFFFFFu;
+                key[r] = make_uint2(0xFFFFFFFFu, 0u);
+                if (r * 64u < V) { /* uniform */
+                    const uint32_t vs = r * 64u + t_;
+                    const unsigned long long st = __ballot(mark[vs] != 0xFFu);
+                    const unsigned long long upto = (t_ == 63u) ? ~0ull : ((2ull << t_) - 1ull);
+                    const unsigned long long m = st & upto;
+                    uint32_t s0 = carry_pos, en = carry_ent;
+                    if (m) {
+                        s0 = r * 64u + 63u - (uint32_t)__builtin_clzll(m);
+                        en = mark[s0];
+                    }
+                    if (vs < V) {
+                        ridx[r] = sh.ent[en].arena + (vs - s0);
+                        key[r] = g_skey[ridx[r]]; /* (sub-tile, item count | cap flag << 31); hole: sub-tile 0xFFFFFFFF */
+                    }
+                    if (st) {
+                        carry_pos = r * 64u + 63u - (uint32_t)__builtin_clzll(st);
+                        carry_ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)mark[carry_pos]);
+                    }
+                }
             }
-            const uint32_t items = raw_rec_items(r);
-            const uint32_t incl = wave_incl_scan(items); /* inclusive prefix of the item counts */
-            __syncthreads(); /* the marks and the entries' regions are read: der takes the records' derived values, the entries their place among them */
-            if (mine) {
-                sh.ent[t_].arena = excl - s_before;
-                sh.ent[t_].nv = nv_incl - excl;
+            uint32_t kept = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < NR; ++r) {
+                bal[r] = 0ull;
+                if (r * 64u >= V) continue; /* uniform */
+                const bool keep = key[r].x == sub && (key[r].y & 0x7FFFFFFFu) != 0u;
+                bal[r] = __ballot(keep);
+                const uint32_t c = kept + (uint32_t)__popcll(bal[r] & ((1ull << fresh_lane()) - 1ull));
+                if (keep && c < (uint32_t)SEGCAP) {
+                    tmp[c] = ridx[r];
+                    tmp[(uint32_t)SEGCAP + c] = key[r].y;
+                }
+                kept += (uint32_t)__popcll(bal[r]);
             }
-            if (have) {
-                sh.pre[t_] = incl;
-                raw_rec_store(&sh.seg[t_], r);
-                sh.der[t_] = seg_derive_raw(r);
+            /* lane e: kept records in front of entry e's slots, and among them.  A bound lies in one round: that round's
+             * ballot and the count of the rounds before it are selected per lane (a popcount per bound, not one per round) */
+            uint32_t slot0_v, nslot_v;
+            {
+                auto kept_below = [&](uint32_t x) { /* kept records among virtual slots [0, x), x <= V */
+                    const uint32_t rr = x >> 6;
+                    unsigned long long bsel = 0ull;
+                    uint32_t csel = kept, cum = 0u;
+#pragma unroll
+                    for (uint32_t r = 0; r < NR; ++r) {
+                        if (rr == r) {
+                            bsel = bal[r];
+                            csel = cum;
+                        }
+                        cum += (uint32_t)__popcll(bal[r]);
+                    }
+                    return csel + (uint32_t)__popcll(bsel & ((1ull << (x & 63u)) - 1ull));
+                };
+                const uint32_t na = kept_below(mine ? excl - s_before : 0u);
+                const uint32_t nb = kept_below(mine ? nv_incl - s_before : 0u);
+                slot0_v = na;
+                nslot_v = nb - na;
+            }
+            if (kept > (uint32_t)SEGCAP) { /* more records than the LDS holds: the group ends in front of the entry that does not fit */
+                const unsigned long long ov = __ballot(slot0_v + nslot_v > (uint32_t)SEGCAP);
+                const uint32_t e_ov = (uint32_t)__builtin_ctzll(ov);
+                if (e_ov == g0) { /* an op with more than SEGCAP records in ONE sub-tile: filtered and walked SEGCAP slots at a time */
+                    OSMT_DBG(if (lane == 0) sh.dbg[6] += 1u;)
+                    big = true;
+                    gend = g0 + 1u;
+                    kept = 0u;
+                } else {
+                    OSMT_DBG(if (lane == 0) sh.dbg[4] += 1u;)
+                    gend = e_ov;
+                    kept = (uint32_t)__builtin_amdgcn_readlane((int)slot0_v, (int)e_ov);
+                }
+            }
+            /* where an entry's records sit among the compacted ones replaces its arena position, which nothing needs any more */
+            if (mine && t_ < gend && !big) {
+                sh.ent[t_].arena = slot0_v;
+                sh.ent[t_].nv = nslot_v;
+            }
+            __syncthreads();
+            {
+                const uint32_t c = fresh_lane();
+                uint32_t ky = 0u, at = 0u;
+                if (c < kept) {
+                    ky = tmp[(uint32_t)SEGCAP + c];
+                    at = tmp[c];
+                }
+                const uint32_t incl = wave_incl_scan(ky & 0x7FFFFFFFu); /* inclusive prefix of the item counts */
+                __syncthreads(); /* tmp and mark are read: their memory takes the records now */
+                if (c < kept) {
+                    sh.pre[c] = incl;
+                    const osmt_srec r = g_srec[at];
+                    sh.seg[c] = r;
+                    sh.der[c] = seg_derive(r, (ky >> 31) != 0u);
+                }
             }
             __syncthreads();
         }
@@ -2022,7 +1962,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         for (uint32_t li = g0; li < gend; ++li) {
             const StagedEnt& en = sh.ent[li];
             const uint32_t ks = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.kind_stage);
-            const uint32_t kind = ks & 255u, stage = (ks >> 8) & 255u;
+            const uint32_t kind = ks & 255u, stage = ks >> 8;
             const double cop = en.op; /* a uniform value in a vector register */
 #if defined(OSMT_ABL) && OSMT_ABL == 6
             if (kind != 77u) continue; /* ablation: lists are staged, nothing is drawn */
@@ -2052,7 +1992,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 const uint32_t sflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.flags);
                 uint32_t n_rounds = 1u, big_cap = 0u, arena = 0u;
-                const bool big_legacy = ((ks >> 16) & 1u) != 0u;
                 if (big) {
                     big_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
                     arena = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.arena);
@@ -2061,26 +2000,26 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 for (uint32_t round = 0; round < n_rounds; ++round) {
                     uint32_t slot0 = 0u, nslot = 0u;
                     if (big) {
-                        /* ---- ONE big entry, SEGCAP per round: the records of this sub-tile's region (sorted layout: all of
-                         * them are its own), or slots of a long way (legacy layout: the key says whose a slot is) ---- */
+                        /* ---- filter pass of ONE big op, SEGCAP of its slots per round ---- */
                         __syncthreads(); /* previous round's records are consumed */
                         uint32_t ridx = 0xFFFFFFFFu;
                         const uint32_t v = round * (uint32_t)SEGCAP + lane;
                         if (lane < (uint32_t)SEGCAP && v < big_cap) ridx = arena + v;
-                        bool keep = ridx != 0xFFFFFFFFu;
-                        if (keep && big_legacy) {
+                        uint32_t cnt = 0, is_cap = 0;
+                        if (ridx != 0xFFFFFFFFu) {
                             const uint2 key = g_skey[ridx];
-                            keep = key.x == sub && (key.y & 0x7FFFFFFFu) != 0u;
+                            if (key.x == sub) {
+                                cnt = key.y & 0x7FFFFFFFu;
+                                is_cap = key.y >> 31;
+                            }
                         }
-                        RawRec r = {};
-                        if (keep) r = raw_rec_load(&g_srec[ridx]);
-                        const uint32_t cnt = raw_rec_items(r);
                         gbal = __ballot(cnt > 0u);
                         const uint32_t incl = wave_incl_scan(cnt);
                         if (cnt > 0u) {
                             const uint32_t slot = (uint32_t)__popcll(gbal & ((1ull << fresh_lane()) - 1ull));
-                            raw_rec_store(&sh.seg[slot], r);
-                            sh.der[slot] = seg_derive_raw(r);
+                            const osmt_srec r = g_srec[ridx];
+                            sh.seg[slot] = r;
+                            sh.der[slot] = seg_derive(r, is_cap != 0u);
                             sh.pre[slot] = incl;
                         }
                         __syncthreads();
@@ -2197,23 +2136,6 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
     }
 
-    /* The block's place — tile, sub-tile origin, tile width — derived AGAIN from the block index for the epilogue: carried from
-     * the prologue these values sat in scalar registers across every loop of the kernel (or rather in the lanes of a spill
-     * register: 22 SGPR spills in round 4's kernel, all of them written in the prologue and read back here). */
-    uint32_t tile_e, W_e;
-    SubRect rce;
-    {
-        uint32_t b_ = blockIdx.x;
-        asm volatile("" : "+s"(b_));
-        W_e = OSMT_TILE_SIZE * late_args()->scale;
-        const uint32_t spr_ = W_e / SUB, nsub_ = spr_ * (W_e / SUBH);
-        const uint32_t rest_ = b_ >> 3, sub_ = rest_ % nsub_;
-        tile_e = (rest_ / nsub_) * 8u + (b_ & 7u);
-        rce.x0 = (int32_t)((sub_ % spr_) * SUB);
-        rce.y0 = (int32_t)((sub_ / spr_) * SUBH);
-        rce.x1 = rce.x0 + SUB - 1;
-        rce.y1 = rce.y0 + SUBH - 1;
-    }
     /* ---- label pass, blend_unfinished_pixels(true) (tile_pixels.rs:154-158,205-223) ----------
      * k_label_resolve has decided which labels succeeded; succeeded labels never share a pixel
      * (set_label_pixel refuses the second one), so every pixel is blended at most once and the
@@ -2224,25 +2146,25 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const osmt_labelinfo* OSMT_R g_lab = la->labels.info;
         const double* OSMT_R g_lab_plane = la->labels.plane;
         const double4* OSMT_R g_image_pool = la->image_pool;
-        const osmt_tile_label* OSMT_R tl = la->labels.tile_labels + la->labels.job_label_off[tile_e];
-        const uint32_t n_tl = la->labels.tile_label_cnt[tile_e];
+        const osmt_tile_label* OSMT_R tl = la->labels.tile_labels + la->labels.job_label_off[tile];
+        const uint32_t n_tl = la->labels.tile_label_cnt[tile];
         /* the tile's survivors are tested against the sub-tile 64 at a time (one load, one ballot): only the few
          * that reach into it are walked */
         for (uint32_t kb = 0; kb < n_tl; kb += 64u) {
           const uint32_t kk = kb + lane;
           osmt_tile_label e = {};
           if (kk < n_tl) e = tl[kk];
-          unsigned long long hm = __ballot(kk < n_tl && !(e.x0 > rce.x1 || e.x1 < rce.x0 || e.y0 > rce.y1 || e.y1 < rce.y0));
+          unsigned long long hm = __ballot(kk < n_tl && !(e.x0 > rc.x1 || e.x1 < rc.x0 || e.y0 > rc.y1 || e.y1 < rc.y0));
           while (hm) {
             const uint32_t hj = (uint32_t)__builtin_ctzll(hm);
             hm &= hm - 1ull;
             const osmt_labelinfo* OSMT_R li = g_lab + (uint32_t)__builtin_amdgcn_readlane((int)e.label, (int)hj);
             const int32_t ry0 = li->ry0, ry1 = li->ry1, cx0 = li->cx0;
             const int32_t cx1 = cx0 + (int32_t)li->cols - 1;
-            const bool text_hit = li->has_text && ry0 <= rce.y1 && ry1 >= rce.y0 && cx0 <= rce.x1 && cx1 >= rce.x0;
+            const bool text_hit = li->has_text && ry0 <= rc.y1 && ry1 >= rc.y0 && cx0 <= rc.x1 && cx1 >= rc.x0;
             const int32_t ix0 = li->icon_x, iy0 = li->icon_y;
             const int32_t iw = (int32_t)li->icon_w, ih = (int32_t)li->icon_h;
-            const bool icon_hit = iw > 0 && ix0 <= rce.x1 && ix0 + iw - 1 >= rce.x0 && iy0 <= rce.y1 && iy0 + ih - 1 >= rce.y0;
+            const bool icon_hit = iw > 0 && ix0 <= rc.x1 && ix0 + iw - 1 >= rc.x0 && iy0 <= rc.y1 && iy0 + ih - 1 >= rc.y0;
             if (!text_hit && !icon_hit) continue;
             const double cr = (double)li->color[0] / 255.0, cg = (double)li->color[1] / 255.0,
                          cb = (double)li->color[2] / 255.0;
@@ -2250,10 +2172,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
             const uint32_t cols = li->cols;
             const double4* OSMT_R ipx = g_image_pool + li->icon_off;
             const uint32_t lx = fresh_lane() & (SUB - 1), ly0 = fresh_lane() / SUB;
-            const int32_t x = rce.x0 + (int32_t)lx;
+            const int32_t x = rc.x0 + (int32_t)lx;
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                const int32_t y = rce.y0 + (int32_t)(ly0 + (uint32_t)j * ROWSTEP);
+                const int32_t y = rc.y0 + (int32_t)(ly0 + (uint32_t)j * ROWSTEP);
                 double t = 0.0;
                 if (text_hit && y >= ry0 && y <= ry1 && x >= cx0 && x <= cx1)
                     t = plane[(size_t)(y - ry0) * cols + (uint32_t)(x - cx0)];
@@ -2290,29 +2212,29 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         __syncthreads();
         constexpr uint32_t ROW_DW = SUB * 3 / 4; /* 24 dwords per row */
-        uint8_t* const tile_out = reinterpret_cast<uint8_t*>(g_out) + (size_t)tile_e * g_out_tile_stride;
+        uint8_t* const tile_out = reinterpret_cast<uint8_t*>(g_out) + (size_t)tile * g_out_tile_stride;
 #pragma unroll
         for (uint32_t q = 0; q < ROW_DW * SUBH / NTHREADS; ++q) {
             const uint32_t d = q * NTHREADS + t_out;
             const uint32_t row = d / ROW_DW, k = d % ROW_DW;
             const uint32_t v = reinterpret_cast<const uint32_t*>(stg)[d];
-            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(tile_out + ((size_t)(rce.y0 + (int32_t)row) * W_e + (size_t)rce.x0) * 3u + 4u * k));
+            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(tile_out + ((size_t)(rc.y0 + (int32_t)row) * W + (size_t)rc.x0) * 3u + 4u * k));
         }
         return;
     }
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;
-        const size_t px = (size_t)(rce.y0 + (int32_t)row) * W_e + (size_t)(rce.x0 + (int32_t)lx_o);
+        const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx_o);
         if (OUT_F64) {
-            double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile_e * W_e * W_e + px;
+            double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
             *out = make_double4(acc[j][0], acc[j][1], acc[j][2], 1.0);
         } else {
             /* postdivide (tile_pixels.rs:171-175) with p.a == 1.0: val / 1.0 == val */
             const uint32_t v = f64_as_u8(255.0 * acc[j][0]) | (f64_as_u8(255.0 * acc[j][1]) << 8) |
                                (f64_as_u8(255.0 * acc[j][2]) << 16) | 0xFF000000u;
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
-                                                        (size_t)tile_e * g_out_tile_stride) + px;
+                                                        (size_t)tile * g_out_tile_stride) + px;
             /* written once, read by nobody on the device: a non-temporal store keeps the 268 MB of a launch's pixels from
              * pushing the lists, keys and records of the tiles still being drawn out of the L2s (0.644 -> 0.614 ms on config 2;
              * the same hint on the LOADS of the read-once list entries and coverage words costs 0.01 ms instead) */
@@ -2492,11 +2414,11 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
     if (a.n_ops)
         hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
                            a.trav, a.den, a.rden, a.vpts, a.vop, a.op_blk, a.blk, a.n_vsegs, n_vblk,
-                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt, a.cellcnt);
+                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
     /* lists only for tiles with more than OSMT_FOLD_MAX_OPS ops (k_raster's waves put the others' together themselves) */
     if (a.n_jobs && (a.fold_max_ops == 0u || a.max_job_ops > a.fold_max_ops))
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
-                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops, a.entfix);
+                           a.cursors + 2, a.hdr, a.ent, a.ent_cap, a.err, a.fold_max_ops);
     return hipGetLastError();
 }
 
