@@ -27,7 +27,7 @@ else:
 NT = dl.n_jobs
 out = ctx.render(ctx.upload(dl)).cpu().numpy().view(np.uint32).reshape(NT, 256, 256)
 c = out[:, ::16, :].reshape(NT, 16, 8, 32)[:, :, :, :8].reshape(-1, 8).astype(np.int64)
-names = ["stroke_visits", "passes", "items", "group_record_fetches", "(unused)", "fill_visits", "(unused)", "entries_walked_alone"]
+names = ["stroke_visits", "passes", "items", "group_filter_passes", "groups_cut_by_kept", "fill_visits", "ops_over_segcap_kept", "ops_over_filtcap_slots"]
 print("waves", len(c))
 for i, n in enumerate(names):
     print(f"{n:16s} per wave {c[:, i].mean():10.2f}   per tile {c[:, i].sum() / NT:12.1f}")
