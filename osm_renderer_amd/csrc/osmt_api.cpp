@@ -88,6 +88,7 @@ struct osmt_ctx {
     /* idle non-blocking streams: every host-buffer call runs on its own stream, so calls from the reference's N
      * worker threads (http_server.rs:50-83) overlap on the GPU instead of queueing behind the NULL stream */
     std::vector<hipStream_t> idle_streams;
+    hipStream_t poison_stream = nullptr; /* OSMT_POISON_ALLOC: the fills run on a stream of the highest priority (dev_poison) */
     std::vector<cached_buf> host_cache; /* pinned staging buffers (one packed H2D copy per small call) */
     std::vector<osmt_image_desc> images;
     std::vector<double> image_pool_host; /* premultiplied f64 RGBA */
@@ -235,12 +236,28 @@ hipError_t stream_acquire(osmt_ctx* ctx, hipStream_t* out);
 void stream_release(osmt_ctx* ctx, hipStream_t st);
 
 hipError_t dev_poison(osmt_ctx* ctx, void* p, size_t bytes) {
+    /* The fill is a kernel: on a pooled stream it can share a hardware queue with a caller's long queue of renders and wait
+     * for all of them (tests/test_gpu_fullsize_and_errors.py::test_worker_threads_..., once in four runs).  A stream of the
+     * highest priority has a queue of its own and its workgroups are dispatched first. */
     hipStream_t st = nullptr;
-    hipError_t e = stream_acquire(ctx, &st);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        if (!ctx->poison_stream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi); /* hi = the numerically lowest = greatest priority */
+            if (hipStreamCreateWithPriority(&ctx->poison_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->poison_stream = nullptr;
+            }
+        }
+        st = ctx->poison_stream;
+    }
+    const bool pooled = st == nullptr;
+    hipError_t e = pooled ? stream_acquire(ctx, &st) : hipSuccess;
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p, 0xA5, bytes, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    stream_release(ctx, st);
+    if (pooled) stream_release(ctx, st);
     return e;
 }
 
@@ -438,6 +455,7 @@ void ctx_teardown(osmt_ctx* ctx) {
     for (void* p : ctx->image_graveyard) (void)hipFree(p);
     for (auto& c : ctx->cache) (void)hipFree(c.p);
     for (hipStream_t st : ctx->idle_streams) (void)hipStreamDestroy(st);
+    if (ctx->poison_stream) (void)hipStreamDestroy(ctx->poison_stream);
     for (auto& c : ctx->host_cache) (void)hipHostFree(c.p);
     if (ctx->err_page) (void)hipHostFree(ctx->err_page);
     delete ctx;
@@ -1681,7 +1699,31 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
         return rc;
     }
     void* d_out = nullptr;
-    if (batch->n_jobs) {
+    /* A FEW tiles into PINNED caller memory (osmt_host_alloc / hipHostMalloc: mapped into the device's address space): k_raster
+     * writes the pixels straight there — no device framebuffer, no copy.  Round 5 measured why it matters: asynchronous
+     * device-to-host copies into pinned buffers from several threads at once queue up behind each other in the runtime (one-tile
+     * requests, 4 threads: 10.9 k tiles/s with pinned caller buffers against 35.5 k with pageable ones, which the runtime
+     * copies synchronously on the calling thread; profiles/r05_f_worker_pinned.txt).  The worker entry's gathered groups land
+     * in the library's own pinned staging, so they take this path too: 16 tiles = the groups that 32 request threads form
+     * (98 k tiles/s against 73 k with 8 tiles, the same with 32; profiles/r05_h_zero_copy_threshold.txt).
+     * OSMT_ZERO_COPY_TILES: most tiles of such a call (0: never). */
+    bool zero_copy = false;
+    static const uint32_t zc_max = [] {
+        const char* v = getenv("OSMT_ZERO_COPY_TILES");
+        return (uint32_t)(v ? std::min(std::max(atoi(v), 0), 64) : 16);
+    }();
+    if (batch->n_jobs && batch->n_jobs <= zc_max && ((uintptr_t)out_rgba & 3u) == 0u && (stride & 3u) == 0u) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, out_rgba) == hipSuccess) {
+            if (at.type == hipMemoryTypeHost && at.devicePointer) {
+                d_out = at.devicePointer;
+                zero_copy = true;
+            }
+        } else {
+            (void)hipGetLastError(); /* pageable memory: not an error */
+        }
+    }
+    if (batch->n_jobs && !zero_copy) {
         hipError_t e = dev_alloc(ctx, &d_out, batch->n_jobs * host_bytes); /* RGB8: written by k_raster as packed triples */
         if (e != hipSuccess) {
             osmt_scene_free(sc);
@@ -1689,11 +1731,11 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
             return fail(OSMT_OOM, "hipMalloc(output) failed: %s", hipGetErrorString(e));
         }
     }
-    rc = render_impl(ctx, sc, 7u | (rgb ? 32u : 0u), d_out ? d_out : (void*)4, host_bytes, false, st);
+    rc = render_impl(ctx, sc, 7u | (rgb ? 32u : 0u), d_out ? d_out : (void*)4, zero_copy ? stride : host_bytes, false, st);
     if (rc == OSMT_OK && batch->n_jobs) {
         hipError_t e = hipSuccess;
         const void* src = d_out;
-        if (rc == OSMT_OK && e == hipSuccess) {
+        if (rc == OSMT_OK && e == hipSuccess && !zero_copy) {
             if (stride == host_bytes)
                 e = hipMemcpyAsync(out_rgba, src, batch->n_jobs * host_bytes, hipMemcpyDeviceToHost, st);
             else
@@ -1704,7 +1746,7 @@ static int osmt_render_batch_labels_once(osmt_ctx* ctx, const osmt_batch* batch,
     }
     if (rc == OSMT_OK) rc = label_error_check(sc, st);
     osmt_scene_free(sc); /* waits for the call's stream */
-    dev_free(ctx, d_out);
+    if (!zero_copy) dev_free(ctx, d_out);
     stream_release(ctx, st);
     return rc;
 }

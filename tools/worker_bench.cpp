@@ -85,7 +85,12 @@ int main(int argc, char** argv) {
             auto body = [&](int t, int n_calls, bool record) {
                 osmt_worker* w = nullptr;
                 if (osmt_worker_create(ctx, &w) != OSMT_OK) { ++bad; return; }
-                std::vector<uint8_t> out(tile_rgb);
+                /* OSMT_BENCH_PINNED=1: the caller's output buffer is pinned (osmt_host_alloc), as in bench.py's latency legs */
+                std::vector<uint8_t> out_pageable(tile_rgb);
+                void* out_pinned = nullptr;
+                if (getenv("OSMT_BENCH_PINNED") && osmt_host_alloc(ctx, tile_rgb, &out_pinned) != OSMT_OK) { ++bad; return; }
+                uint8_t* const out_p = out_pinned ? (uint8_t*)out_pinned : out_pageable.data();
+                struct view { uint8_t* p; uint8_t* data() const { return p; } } out{out_p};
                 for (int c = 0; c < n_calls; ++c) {
                     const auto a = std::chrono::steady_clock::now();
                     const int rc = mode == 0 ? osmt_render_batch_rgb(ctx, &work[t].batch, nullptr, out.data(), tile_rgb)
@@ -96,6 +101,7 @@ int main(int argc, char** argv) {
                     if (c % 16 == 0 && memcmp(out.data(), want[t].data(), tile_rgb) != 0) ++differ;
                 }
                 osmt_worker_destroy(w);
+                if (out_pinned) osmt_host_free(ctx, out_pinned);
             };
             {
                 std::vector<std::thread> th;  // warm-up: streams, staging buffers, device buffers of every size
