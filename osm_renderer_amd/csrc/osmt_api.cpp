@@ -132,6 +132,7 @@ struct osmt_scene {
     uint32_t n_jobs = 0, n_ops = 0, n_rings = 0, n_pts = 0, n_dashes = 0, n_strokes = 0;
     uint32_t scale = 1, coord_kind = 0, n_blk = 0;
     char* d_base = nullptr; /* one allocation, carved below */
+    char* d_front = nullptr; /* big uploads: the arrays the host provides, in an allocation of their own (copied by a helper thread while the tables are built) */
     size_t bytes = 0;
     osmt_tile_job* d_jobs = nullptr;
     osmt_op* d_ops = nullptr;
@@ -997,7 +998,40 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     /* Big uploads: the O(n_pts) coordinate scan runs on helper threads while this one builds the index tables and feeds
      * the copies (they do not depend on it); the verdict is collected before the first kernel can be launched. */
     const bool big = b && coord_count(b) >= ((size_t)1 << 16);
-    int rc = trusted ? OSMT_OK : validate_batch(b, !big);
+    /* Where the host's own arrays go inside the scene's memory: known from the batch's sizes alone */
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const bool ll = b && b->coord_kind == OSMT_COORD_LATLON_F64;
+    const bool nr = b && b->coord_kind == OSMT_COORD_NODE_REF;
+    size_t o_jobs = 0, o_ops = 0, o_rings = 0, o_latlon = 0, o_refs = 0, o_pts = 0, o_dashes = 0, o_ptjob = 0, o_opaux = 0, o_opblk = 0, o_opvseg = 0,
+           o_opjob = 0, front_bytes = 0;
+    if (b) {
+        o_jobs = carve(b->n_jobs * sizeof(osmt_tile_job));
+        o_ops = carve(b->n_ops * sizeof(osmt_op));
+        o_rings = carve(b->n_rings * sizeof(osmt_ring));
+        o_latlon = carve(ll ? b->n_pts * 16 : nr ? b->n_nodes * 16 : 0);
+        o_refs = carve(nr ? b->n_pts * 4 : 0);
+        o_pts = carve(b->n_pts * 8);
+        o_dashes = carve((b->n_dashes + 1) * 8);
+        o_ptjob = carve(b->n_pts * 4);
+        o_opaux = carve(b->n_ops * 4);
+        o_opblk = carve(b->n_ops * 4);
+        o_opvseg = carve(b->n_ops * 4);
+        o_opjob = carve(b->n_ops * 4);
+        front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
+    }
+    /* SPLIT upload (round 5; big stream-ordered uploads): the caller's arrays — 27 MB for 1024 config-2 tiles, 0.44 ms of
+     * pageable copies — go to an allocation of their own and are copied by a helper thread WHILE this thread validates the jobs
+     * and builds the index tables (0.3 + 0.19 ms): the host half of a one-piece call was validation -> tables -> copies in a
+     * row in front of the GPU half.  Nothing on the device looks at the data before the verdicts are in (the first launch comes
+     * after the join below). */
+    const bool split = big && st != nullptr && front_bytes > STAGE_MAX_BYTES;
+    int rc = OSMT_OK;
+    if (!trusted) rc = split ? validate_batch_global(b) : validate_batch(b, !big);
     if (rc != OSMT_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     struct coord_check {
@@ -1011,16 +1045,18 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
                 if (rc[i] != OSMT_OK) return fail(rc[i], "%s", msg[i].c_str());
             return OSMT_OK;
         }
-        ~coord_check() {
+        void wait() {
             for (auto& t : th)
                 if (t.joinable()) t.join();
         }
+        ~coord_check() { wait(); }
     } cc;
+    const unsigned n_coord_thr = (big && !trusted) ? (coord_count(b) >= ((size_t)1 << 19) ? 2u : 1u) : 0u;
+    cc.rc.assign(n_coord_thr + (split ? 2u : 0u), OSMT_OK); /* sized before any helper runs: they write their own slots */
+    cc.msg.resize(n_coord_thr + (split ? 2u : 0u));
     if (big && !trusted) {
         const size_t n = coord_count(b);
-        const unsigned n_thr = n >= ((size_t)1 << 19) ? 2u : 1u;
-        cc.rc.assign(n_thr, OSMT_OK);
-        cc.msg.resize(n_thr);
+        const unsigned n_thr = n_coord_thr;
         for (unsigned t = 0; t < n_thr; ++t) {
             const size_t lo = n * t / n_thr, hi = n * (t + 1) / n_thr;
             try {
@@ -1031,6 +1067,53 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             } catch (...) { /* no thread to be had: scan here */
                 cc.rc[t] = validate_coords_range(b, lo, hi);
                 if (cc.rc[t] != OSMT_OK) cc.msg[t] = osmt_last_error();
+            }
+        }
+    }
+
+    char* d_front = nullptr;
+    if (split) {
+        hipError_t fe = dev_alloc(ctx, (void**)&d_front, front_bytes + 256);
+        if (fe != hipSuccess) {
+            cc.wait();
+            return fail(fe == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", front_bytes, hipGetErrorString(fe));
+        }
+        /* two helpers: the op side (jobs, ops, rings, dashes) and the coordinate side — 16 + 11 MB for 1024 config-2 tiles */
+        auto copy_user_arrays = [&cc, ctx, b, st, d_front, ll, nr, o_jobs, o_ops, o_rings, o_latlon, o_refs, o_pts, o_dashes](unsigned slot, bool coords) {
+            cc.rc[slot] = guarded([&] {
+                HIP_TRY(hipSetDevice(ctx->device));
+                auto put = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+                    return bytes ? hipMemcpyAsync(d_front + o, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+                };
+                if (!coords) {
+                    HIP_TRY(put(o_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job)));
+                    HIP_TRY(put(o_ops, b->ops, b->n_ops * sizeof(osmt_op)));
+                    HIP_TRY(put(o_rings, b->rings, b->n_rings * sizeof(osmt_ring)));
+                    HIP_TRY(put(o_dashes, b->dashes, b->n_dashes * 8));
+                } else {
+                    if (ll) HIP_TRY(put(o_latlon, b->latlon, b->n_pts * 16));
+                    if (nr) HIP_TRY(put(o_latlon, b->nodes, b->n_nodes * 16));
+                    if (nr) HIP_TRY(put(o_refs, b->node_refs, b->n_pts * 4));
+                    if (!ll && !nr) HIP_TRY(put(o_pts, b->points, b->n_pts * 8));
+                }
+                return (int)OSMT_OK;
+            });
+            if (cc.rc[slot] != OSMT_OK) cc.msg[slot] = osmt_last_error();
+        };
+        for (unsigned h = 0; h < 2u; ++h) {
+            try {
+                cc.th.emplace_back(copy_user_arrays, n_coord_thr + h, h == 1u);
+            } catch (...) { /* no thread to be had: copy here */
+                copy_user_arrays(n_coord_thr + h, h == 1u);
+            }
+        }
+        if (!trusted) { /* the per-job half of validate_batch, beside the copies (coordinates: the helpers above) */
+            for (size_t j = 0; rc == OSMT_OK && j < b->n_jobs; ++j) rc = validate_job(b, j, false);
+            if (rc != OSMT_OK) {
+                const std::string msg = osmt_last_error();
+                cc.wait();
+                dev_free(ctx, d_front);
+                return fail(rc, "%s", msg.c_str());
             }
         }
     }
@@ -1050,7 +1133,11 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     };
     mark(0);
     osmt_scene* s = new (std::nothrow) osmt_scene();
-    if (!s) return fail(OSMT_OOM, "out of host memory");
+    if (!s) {
+        cc.wait();
+        dev_free(ctx, d_front);
+        return fail(OSMT_OOM, "out of host memory");
+    }
     s->own_stream = st;
     /* host-side index tables: point -> job (for projection), op -> stroke slot */
     std::vector<uint32_t>& pt_job = s->h_pt_job;
@@ -1100,6 +1187,8 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     }
     if (n_vsegs >= 0xFFFFFFFFull) {
         delete s;
+        cc.wait();
+        dev_free(ctx, d_front);
         return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices (stroke segments)");
     }
 
@@ -1118,27 +1207,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->scale = b->scale;
     s->coord_kind = b->coord_kind;
 
-    size_t off = 0;
-    auto carve = [&](size_t bytes) {
-        const size_t o = off;
-        off = align_up(off + bytes, 256);
-        return o;
-    };
-    const bool ll = b->coord_kind == OSMT_COORD_LATLON_F64;
-    const bool nr = b->coord_kind == OSMT_COORD_NODE_REF;
-    const size_t o_jobs = carve(b->n_jobs * sizeof(osmt_tile_job));
-    const size_t o_ops = carve(b->n_ops * sizeof(osmt_op));
-    const size_t o_rings = carve(b->n_rings * sizeof(osmt_ring));
-    const size_t o_latlon = carve(ll ? b->n_pts * 16 : nr ? b->n_nodes * 16 : 0);
-    const size_t o_refs = carve(nr ? b->n_pts * 4 : 0);
-    const size_t o_pts = carve(b->n_pts * 8);
-    const size_t o_dashes = carve((b->n_dashes + 1) * 8);
-    const size_t o_ptjob = carve(b->n_pts * 4);
-    const size_t o_opaux = carve(b->n_ops * 4);
-    const size_t o_opblk = carve(b->n_ops * 4);
-    const size_t o_opvseg = carve(b->n_ops * 4);
-    const size_t o_opjob = carve(b->n_ops * 4);
-    const size_t front_bytes = off; /* everything the host provides sits in [0, front_bytes) */
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     /* per virtual segment (not per point: two stroke ops may share a ring, e.g. a casing and its stroke) */
     const size_t o_trav = carve((n_vsegs + 1) * 8);
@@ -1155,41 +1223,47 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
-    s->bytes = off + 256;
+    s->d_front = d_front;
+    s->bytes = off - (split ? front_bytes : 0) + 256;
     mark(1);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     mark(2);
     if (e != hipSuccess) {
+        cc.wait();
+        dev_free(ctx, d_front);
         scene_delete(s);
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
                     hipGetErrorString(e));
     }
-    s->d_jobs = (osmt_tile_job*)(s->d_base + o_jobs);
-    s->d_ops = (osmt_op*)(s->d_base + o_ops);
-    s->d_rings = (osmt_ring*)(s->d_base + o_rings);
-    s->d_latlon = (double*)(s->d_base + o_latlon);
-    s->d_node_refs = (uint32_t*)(s->d_base + o_refs);
-    s->d_pts = (int32_t*)(s->d_base + o_pts);
-    s->d_dashes = (double*)(s->d_base + o_dashes);
-    s->d_pt_job = (uint32_t*)(s->d_base + o_ptjob);
-    s->d_op_aux = (uint32_t*)(s->d_base + o_opaux);
-    s->d_info = (osmt_opinfo*)(s->d_base + o_info);
-    s->d_trav = (double*)(s->d_base + o_trav);
-    s->d_den = (double*)(s->d_base + o_den);
-    s->d_aux = (osmt_stroke_aux*)(s->d_base + o_aux);
-    s->d_dseg = (osmt_dash_seg*)(s->d_base + o_dseg);
-    s->d_submask = (uint32_t*)(s->d_base + o_submask);
-    s->d_op_blk = (uint32_t*)(s->d_base + o_opblk);
-    s->d_op_vseg = (uint32_t*)(s->d_base + o_opvseg);
-    s->d_blk = (osmt_blk_bbox*)(s->d_base + o_blk);
-    s->d_rden = (double*)(s->d_base + o_rden);
-    s->d_op_job = (uint32_t*)(s->d_base + o_opjob);
-    s->d_vpts = (int4*)(s->d_base + o_vpts);
-    s->d_vop = (uint32_t*)(s->d_base + o_vop);
-    s->d_cand_off = (uint32_t*)(s->d_base + o_candoff);
-    s->d_cursors = (unsigned long long*)(s->d_base + o_cursors);
-    s->d_cnt = (uint32_t*)(s->d_base + o_cursors + 32);
-    s->d_hdr = (uint2*)(s->d_base + o_hdr);
+    /* front offsets live in d_front when the upload is split, everything behind them in d_base */
+    char* const fbase = split ? d_front : s->d_base;
+    char* const rbase = split ? s->d_base - front_bytes : s->d_base;
+    s->d_jobs = (osmt_tile_job*)(fbase + o_jobs);
+    s->d_ops = (osmt_op*)(fbase + o_ops);
+    s->d_rings = (osmt_ring*)(fbase + o_rings);
+    s->d_latlon = (double*)(fbase + o_latlon);
+    s->d_node_refs = (uint32_t*)(fbase + o_refs);
+    s->d_pts = (int32_t*)(fbase + o_pts);
+    s->d_dashes = (double*)(fbase + o_dashes);
+    s->d_pt_job = (uint32_t*)(fbase + o_ptjob);
+    s->d_op_aux = (uint32_t*)(fbase + o_opaux);
+    s->d_info = (osmt_opinfo*)(rbase + o_info);
+    s->d_trav = (double*)(rbase + o_trav);
+    s->d_den = (double*)(rbase + o_den);
+    s->d_aux = (osmt_stroke_aux*)(rbase + o_aux);
+    s->d_dseg = (osmt_dash_seg*)(rbase + o_dseg);
+    s->d_submask = (uint32_t*)(rbase + o_submask);
+    s->d_op_blk = (uint32_t*)(fbase + o_opblk);
+    s->d_op_vseg = (uint32_t*)(fbase + o_opvseg);
+    s->d_blk = (osmt_blk_bbox*)(rbase + o_blk);
+    s->d_rden = (double*)(rbase + o_rden);
+    s->d_op_job = (uint32_t*)(fbase + o_opjob);
+    s->d_vpts = (int4*)(rbase + o_vpts);
+    s->d_vop = (uint32_t*)(rbase + o_vop);
+    s->d_cand_off = (uint32_t*)(rbase + o_candoff);
+    s->d_cursors = (unsigned long long*)(rbase + o_cursors);
+    s->d_cnt = (uint32_t*)(rbase + o_cursors + 32);
+    s->d_hdr = (uint2*)(rbase + o_hdr);
 
     auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
@@ -1238,27 +1312,35 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
         *out_scene = s;
         return OSMT_OK;
     }
-    if (err == hipSuccess) err = up(s->d_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
-    if (err == hipSuccess) err = up(s->d_ops, b->ops, b->n_ops * sizeof(osmt_op));
-    if (err == hipSuccess) err = up(s->d_rings, b->rings, b->n_rings * sizeof(osmt_ring));
-    if (err == hipSuccess && ll) err = up(s->d_latlon, b->latlon, b->n_pts * 16);
-    if (err == hipSuccess && nr) err = up(s->d_latlon, b->nodes, b->n_nodes * 16);
-    if (err == hipSuccess && nr) err = up(s->d_node_refs, b->node_refs, b->n_pts * 4);
-    if (err == hipSuccess && !ll && !nr) err = up(s->d_pts, b->points, b->n_pts * 8);
-    if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
+    if (!split) { /* (split: the helper thread is copying these) */
+        if (err == hipSuccess) err = up(s->d_jobs, b->jobs, b->n_jobs * sizeof(osmt_tile_job));
+        if (err == hipSuccess) err = up(s->d_ops, b->ops, b->n_ops * sizeof(osmt_op));
+        if (err == hipSuccess) err = up(s->d_rings, b->rings, b->n_rings * sizeof(osmt_ring));
+        if (err == hipSuccess && ll) err = up(s->d_latlon, b->latlon, b->n_pts * 16);
+        if (err == hipSuccess && nr) err = up(s->d_latlon, b->nodes, b->n_nodes * 16);
+        if (err == hipSuccess && nr) err = up(s->d_node_refs, b->node_refs, b->n_pts * 4);
+        if (err == hipSuccess && !ll && !nr) err = up(s->d_pts, b->points, b->n_pts * 8);
+        if (err == hipSuccess) err = up(s->d_dashes, b->dashes, b->n_dashes * 8);
+    }
     if (err == hipSuccess && host_pt_job) err = up(s->d_pt_job, pt_job.data(), b->n_pts * 4);
-    if (err == hipSuccess && !host_pt_job) err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st ? st : nullptr);
+    if (err == hipSuccess && !host_pt_job && !split) err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st ? st : nullptr);
     if (err == hipSuccess) err = up(s->d_op_aux, op_aux.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_blk, op_blk.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_vseg, op_vseg.data(), b->n_ops * 4);
     if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
     if (err != hipSuccess) {
+        cc.wait();
         dev_free(ctx, s->d_base);
+        dev_free(ctx, s->d_front);
         scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
     mark(3);
-    rc = cc.join(); /* no kernel has seen the coordinates yet */
+    rc = cc.join(); /* no kernel has seen the coordinates yet; the helper's copies are on the stream */
+    if (rc == OSMT_OK && split && !host_pt_job) { /* the point -> job kernel reads the jobs the helper copied: behind the join */
+        err = osmt_launch_ptjob(s->d_jobs, s->n_jobs, s->d_pt_job, s->n_pts, st);
+        if (err != hipSuccess) rc = fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
+    }
     mark(4);
     if (rc == OSMT_OK) rc = scene_size_arenas(ctx, s, n_fills, allow_guess);
     mark(5);
@@ -1312,6 +1394,7 @@ void osmt_scene_free(osmt_scene* s) {
      * was rendered on (public scenes) — not for the device: other workers' streams keep running */
     (void)scene_wait_idle(s);
     dev_free(s->ctx, s->d_base);
+    dev_free(s->ctx, s->d_front);
     dev_free(s->ctx, s->d_arena);
     dev_free(s->ctx, s->d_lab_base);
     stage_release(s->ctx, s->h_stage);

@@ -330,3 +330,46 @@ def test_guessed_arenas_that_turn_out_too_small_are_rendered_again(oracle):
         assert np.array_equal(_decode(files[17]), got_small[17][..., :3])
     finally:
         ctx.close()
+
+
+def test_split_upload_refuses_bad_batches_and_renders_good_ones(gpu_ctx, oracle):
+    """Uploads of more than 4 MB of host arrays are SPLIT (round 5): a helper thread copies the caller's arrays while the calling
+    thread validates the jobs and builds the index tables.  A bad op, a bad ring, a bad coordinate anywhere must still be refused
+    before any kernel has seen the batch — with the helper joined and its buffer given back — and good batches render like the
+    oracle, through the host-buffer entry (stream-ordered upload) and as a scene."""
+    n = 420
+    dl = synth.config2(n)  # ~11 MB of host arrays
+    assert len(dl.coords) * 16 + len(dl.ops) * 64 > (4 << 20)
+    pick = [0, 1, 211, n - 1]
+    want = oracle.render_batch(dl.subset(pick), threads=4)
+    np.testing.assert_array_equal(gpu_ctx.render_batch_host(dl)[pick], want)
+    for kind in ("ring_off", "n_rings", "coord", "dashes", "kind"):
+        bad = synth.config2(n)
+        k = len(bad.ops) - 3
+        if kind == "ring_off":
+            bad.ops["ring_off"][k] = 10**8
+            code = abi.INVALID_ARG
+        elif kind == "n_rings":
+            bad.ops["n_rings"][5] = 10**6
+            code = abi.INVALID_ARG
+        elif kind == "coord":
+            bad.coords[len(bad.coords) - 7, 0] = 89.9
+            code = abi.UNSUPPORTED
+        elif kind == "dashes":
+            strokes = np.nonzero(bad.ops["kind"] == abi.OP_STROKE)[0]
+            bad.ops["has_dashes"][strokes[-1]] = 1
+            bad.ops["n_dashes"][strokes[-1]] = 0
+            code = abi.INVALID_ARG
+        else:
+            bad.ops["kind"][k] = 77
+            code = abi.INVALID_ARG
+        for call in (gpu_ctx.render_batch_host, gpu_ctx.upload):
+            with pytest.raises(OsmtError) as e:
+                call(bad)
+            assert e.value.code == code, (kind, e.value)
+    # nothing leaked or hung: the same good batch again, as a scene and through the RGB entry
+    scene = gpu_ctx.upload(dl)
+    got = gpu_ctx.render(scene).cpu().numpy()
+    scene.free()
+    np.testing.assert_array_equal(got[pick], want)
+    np.testing.assert_array_equal(gpu_ctx.render_batch_rgb(dl).reshape(n, 256, 256, 3)[pick], want[..., :3])
