@@ -547,31 +547,26 @@ def main():
 
         # ---- end to end through the host-buffer ABI (upload + kernels + readback per call) -----------
         try:
+            # every one-call leg: two untimed calls (the context's buffer cache, the runtime's staging for the pageable display
+            # lists and the helper threads of the split upload settle over the first two), then the best of five
+            def best_call(fn, warm=2, reps=5):
+                for _ in range(warm):
+                    fn()
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts)
+
             pin = ctx.host_alloc((dl.n_jobs, dl.dim, dl.dim, 4))
-            ctx.render_batch_host(dl, out=pin)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                ctx.render_batch_host(dl, out=pin)
-                ts.append(time.perf_counter() - t0)
-            raw_s = min(ts)
+            raw_s = best_call(lambda: ctx.render_batch_host(dl, out=pin))
             pin3 = ctx.host_alloc((dl.n_jobs, dl.dim * dl.dim * 3))
-            ctx.render_batch_rgb(dl, out=pin3)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                ctx.render_batch_rgb(dl, out=pin3)
-                ts.append(time.perf_counter() - t0)
-            rgb_s = min(ts)
+            rgb_s = best_call(lambda: ctx.render_batch_rgb(dl, out=pin3))
             ctx.host_free(pin3)
             pbuf = ctx.host_alloc((dl.n_jobs * 96 * 1024,))
             _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                _, off = ctx.render_batch_png(dl, out=pbuf, as_bytes=False)
-                ts.append(time.perf_counter() - t0)
-            png_s = min(ts)
+            png_s = best_call(lambda: ctx.render_batch_png(dl, out=pbuf, as_bytes=False), warm=1)
             # the same call from the reference's server shape (http_server.rs:50-83: a pool of workers, one request each):
             # W host threads issue PNG batches back to back; one thread's validation / upload overlaps another's kernels
             import threading
@@ -616,7 +611,7 @@ def main():
                 ctx.host_free(b_)
             result["end_to_end"] = {
                 "what": "wall clock around one osmt_render_batch / osmt_render_batch_png call (validation + H2D of the display lists + all "
-                        "kernels + D2H into pinned host memory), best of 3; never `value`",
+                        "kernels + D2H into pinned host memory), best of 5 after two untimed calls; never `value`",
                 "tiles": dl.n_jobs,
                 "raw_rgba8_pinned_tiles_per_s": dl.n_jobs / raw_s, "raw_rgba8_ms": raw_s * 1e3,
                 "raw_rgb8_pinned_tiles_per_s": dl.n_jobs / rgb_s, "raw_rgb8_ms": rgb_s * 1e3,
