@@ -31,6 +31,12 @@ def test_rgb_into_pinned_memory_with_tight_and_padded_strides(gpu_ctx, oracle, n
             if stride > tight:
                 assert (got[:, tight:] == 0x5A).all(), "the padding between tiles is the caller's"
             assert (buf[n * stride :] == 0x5A).all()
+            # a pointer INTO a pinned allocation (a 4-byte aligned offset): still zero copy, the device address follows the offset
+            if n * stride + 12 <= buf.size:
+                inner = buf[12 : 12 + n * stride]
+                buf[:] = 0x33
+                got3 = gpu_ctx.render_batch_rgb(dl, out=inner.reshape(n, stride), stride=stride)
+                assert np.array_equal(got3[:, :tight], want) and (buf[:12] == 0x33).all() and (buf[12 + n * stride :] == 0x33).all()
             # an odd pointer cannot take the zero-copy path (dword stores): the copy path must give the same bytes
             odd = buf[1 : 1 + n * stride]
             if stride == tight and n <= 3:
