@@ -200,8 +200,20 @@ __device__ __forceinline__ uint32_t window_count(const SubWindow& w) {
 constexpr uint32_t OPINFO_THREADS = OSMT_V_OPINFO_THREADS; /* ops per wave.  Half-empty waves, more of them (measured: config-2 pre-pass 257 us with
                                                            * 64, 274 with 32, 309 with 16) do not help: a wave runs as long as its longest op anyway */
 static_assert(OPINFO_THREADS == 64 || OPINFO_THREADS == 32 || OPINFO_THREADS == 16, "the wave scans read their totals from the last active lane");
-__global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
-    const uint32_t o_raw = blockIdx.x * OPINFO_THREADS + threadIdx.x;
+/* Waves per workgroup.  A wave's two arena reservations are one atomicAdd per cursor — and a same-address atomic costs ~12 ns:
+ * 1440 waves (config 2) queue up for 17 us behind each cursor at the end of a 45 us kernel, the 36 000 waves of 256 config-5 tiles
+ * for 0.4 ms of its 0.50.  The waves of a workgroup share ONE atomicAdd per cursor (totals and bases handed over through LDS):
+ * pre-pass of config 2 0.232 -> 0.209 ms with four waves, 0.205 with eight; 2.80 -> 2.69 ms on 256 config-5 tiles
+ * (profiles/r05_o_opinfo_waves_stage_times.txt). */
+#ifndef OSMT_V_OPINFO_WAVES
+#define OSMT_V_OPINFO_WAVES 8
+#endif
+constexpr uint32_t OPINFO_WAVES = OSMT_V_OPINFO_WAVES;
+static_assert(OPINFO_WAVES == 1 || OPINFO_THREADS == 64, "several waves per workgroup: whole waves");
+__global__ __launch_bounds__(OPINFO_THREADS * OPINFO_WAVES) void k_opinfo(const osmt_prepass_args a) {
+    const uint32_t op_lane = threadIdx.x % OPINFO_THREADS, op_wave = threadIdx.x / OPINFO_THREADS;
+    const uint32_t wblk = blockIdx.x * OPINFO_WAVES + op_wave; /* the wave's 64 ops (waves behind the pool shadow its last op) */
+    const uint32_t o_raw = wblk * OPINFO_THREADS + op_lane;
     const bool live = o_raw < a.n_ops;
     const uint32_t o = live ? o_raw : a.n_ops - 1u; /* lanes past the pool shadow the last op and store nothing: the wave
                                                      * stays whole for the reservation at the end */
@@ -213,9 +225,9 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     {
         /* the sub-tile words of the wave's 64 ops are one contiguous piece: cleared with whole-line stores (a lane
          * clearing its own op's 16 words touched 64 lines per store) */
-        const size_t w_first = (size_t)blockIdx.x * OPINFO_THREADS * sub_rows;
-        const size_t w_end = min((size_t)a.n_ops, (size_t)(blockIdx.x + 1u) * OPINFO_THREADS) * sub_rows;
-        for (size_t i = w_first + threadIdx.x; i < w_end; i += OPINFO_THREADS) a.submask[i] = 0u;
+        const size_t w_first = min((size_t)a.n_ops, (size_t)wblk * OPINFO_THREADS) * sub_rows;
+        const size_t w_end = min((size_t)a.n_ops, (size_t)(wblk + 1u) * OPINFO_THREADS) * sub_rows;
+        for (size_t i = w_first + op_lane; i < w_end; i += OPINFO_THREADS) a.submask[i] = 0u;
     }
     osmt_opinfo oi;
     oi.x0 = oi.y0 = INT32_MAX;
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
     }
     {
         /* per-op counts are below 2^32 (clamped) and a fill window below 2^16: 16-bit halves scan without overflow */
-        const uint32_t lane = threadIdx.x;
+        const uint32_t lane = op_lane;
         const uint32_t f = (uint32_t)want_f;
         const uint32_t s_lo = (uint32_t)want_s & 0xFFFFu, s_hi = (uint32_t)(want_s >> 16);
         const uint32_t f_incl = wave_incl_scan(f);
@@ -406,9 +418,40 @@ __global__ __launch_bounds__(64) void k_opinfo(const osmt_prepass_args a) {
         const unsigned long long s_tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s_incl >> 32), OPINFO_THREADS - 1) << 32) |
                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s_incl, OPINFO_THREADS - 1);
         unsigned long long f_base = 0ull, s_base = 0ull;
-        if (lane == 0u) {
-            if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
-            if (s_tot) s_base = atomicAdd(&a.cursors[1], s_tot);
+        if (OPINFO_WAVES == 1u) {
+            if (lane == 0u) {
+                if (f_tot) f_base = atomicAdd(&a.cursors[0], (unsigned long long)f_tot);
+                if (s_tot) s_base = atomicAdd(&a.cursors[1], s_tot);
+            }
+        } else {
+            /* the workgroup's waves hand their totals to thread 0, which reserves for all of them and hands the bases back */
+            __shared__ unsigned long long s_tot_f[OPINFO_WAVES], s_tot_s[OPINFO_WAVES];
+            if (lane == 0u) {
+                s_tot_f[op_wave] = f_tot;
+                s_tot_s[op_wave] = s_tot;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0u) {
+                unsigned long long bf = 0ull, bs = 0ull;
+                for (uint32_t w = 0; w < OPINFO_WAVES; ++w) {
+                    bf += s_tot_f[w];
+                    bs += s_tot_s[w];
+                }
+                bf = bf ? atomicAdd(&a.cursors[0], bf) : 0ull;
+                bs = bs ? atomicAdd(&a.cursors[1], bs) : 0ull;
+                for (uint32_t w = 0; w < OPINFO_WAVES; ++w) { /* totals -> first group / record of every wave */
+                    const unsigned long long tf = s_tot_f[w], ts = s_tot_s[w];
+                    s_tot_f[w] = bf;
+                    s_tot_s[w] = bs;
+                    bf += tf;
+                    bs += ts;
+                }
+            }
+            __syncthreads();
+            if (lane == 0u) {
+                f_base = s_tot_f[op_wave];
+                s_base = s_tot_s[op_wave];
+            }
         }
         f_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f_base >> 32)) << 32) |
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f_base);
@@ -2408,7 +2451,9 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
         const hipError_t e = hipMemsetAsync(a.cursors, 0, osmt_prepass_zero_words(a) * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
     }
-    if (a.n_ops) hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + OPINFO_THREADS - 1u) / OPINFO_THREADS), dim3(OPINFO_THREADS), 0, st, a);
+    if (a.n_ops)
+        hipLaunchKernelGGL(k_opinfo, dim3((a.n_ops + OPINFO_THREADS * OPINFO_WAVES - 1u) / (OPINFO_THREADS * OPINFO_WAVES)),
+                           dim3(OPINFO_THREADS * OPINFO_WAVES), 0, st, a);
     if (a.fmask_cap == 0 && a.srec_cap == 0) return hipGetLastError(); /* sizing pass */
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
     if (a.n_ops)
