@@ -553,9 +553,16 @@ struct StrokeConst {
 constexpr uint32_t STROKE_PLAIN_MAIN = 1u; /* the main calculator has no dash segments */
 constexpr uint32_t STROKE_UNIT_FD = 2u;    /* feather_dist == 1.0 exactly */
 constexpr uint32_t STROKE_TINY_MUL = 4u;   /* opacity_mul below 1e-100 (or NaN): no shortcut may assume mul0 * v > 0 */
+constexpr uint32_t STROKE_DASH_FAST = 8u;  /* dashed, no original_endpoints, pattern length > 0, mul0 comfortably positive: walk_items_dashed */
 __device__ __forceinline__ uint32_t stroke_flags(const osmt_stroke_aux* __restrict__ sa) {
-    return (sa->main_n_segs == 0 ? STROKE_PLAIN_MAIN : 0u) | (sa->fd0 == 1.0 ? STROKE_UNIT_FD : 0u) |
-           (sa->mul0 >= 1e-100 ? 0u : STROKE_TINY_MUL);
+    const bool tiny = !(sa->mul0 >= 1e-100);
+    const int n = sa->main_n_segs;
+#ifdef OSMT_V_NO_DASH_FAST
+    const bool fast = false;
+#else
+    const bool fast = n > 0 && sa->main_has_orig == 0 && sa->main_total_len > 0.0 && !tiny;
+#endif
+    return (n == 0 ? STROKE_PLAIN_MAIN : 0u) | (sa->fd0 == 1.0 ? STROKE_UNIT_FD : 0u) | (tiny ? STROKE_TINY_MUL : 0u) | (fast ? STROKE_DASH_FAST : 0u);
 }
 #ifndef OSMT_V_STAGECAP
 #define OSMT_V_STAGECAP 16
@@ -580,6 +587,12 @@ constexpr uint32_t SEGW_INCX_NEG = 1u, SEGW_INCY_NEG = 2u, SEGW_SWAP = 4u, SEGW_
 #define OSMT_V_FILTCAP 256
 #endif
 constexpr uint32_t FILTCAP = OSMT_V_FILTCAP; /* slots of a group's stroke entries one filter pass looks at (four rounds of 64 lanes) */
+#if OSMT_V_OPCHUNK <= OSMT_V_STAGECAP
+#define OSMT_STAGE_UNION 1
+#else
+#define OSMT_STAGE_UNION 0
+#endif
+constexpr int DTAB_F = 7; /* start_from, start_to, end_from, end_to, opacity_mul, r_start, r_end */
 struct RasterShared {
     OSMT_DBG(uint32_t dbg[8];) /* diagnostic build: [0] stroke visits [1] passes [2] items [3] filter passes of groups [4] groups ended by the
                                 * 33rd kept record [5] fill visits [6] ops with more than SEGCAP records in the sub-tile [7] ops with more than FILTCAP slots */
@@ -588,13 +601,34 @@ struct RasterShared {
     uint32_t pre[SEGCAP];           /* inclusive item prefix of the compacted records */
     unsigned long long plane[PLANE_STRIDE * SUBH]; /* generation alpha plane (f64 bit patterns) */
     StagedEnt ent[OPCHUNK];         /* ops of the chunk that draw into this sub-tile, in order */
-    uint32_t fmask[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
-    StrokeConst sconst[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
+#if OSMT_STAGE_UNION
+    /* an entry is a fill OR a stroke: with a staging slot per ENTRY of the chunk (stage = the entry's place in it) the
+     * coverage words and the stroke constants share their 64 bytes — 768 bytes that the dash table and the queue of the
+     * dashed walk (below) take instead */
+    union {
+        uint32_t fmask[SUBH];
+        StrokeConst sconst;
+    } stg[STAGECAP];
+#else
+    uint32_t fmask_[STAGECAP][SUBH]; /* coverage words of the first STAGECAP fills of the chunk */
+    StrokeConst sconst_[STAGECAP];   /* constants of the first STAGECAP strokes of the chunk */
+#endif
+    /* walk_items_dashed: the DashSegments of the op being walked (seven of a record's nine doubles: no original_endpoints
+     * on that path), staged once per visit, and the queue of the pixels whose dash phase lies within a ramp */
+    double dtab[OSMT_MAX_DASH_SEGS][DTAB_F];
+    uint32_t queue[64];
 #ifdef OSMT_V_LDSPAD
     uint8_t occupancy_experiment_pad[OSMT_V_LDSPAD];
 #endif
 };
 static_assert(sizeof(RasterShared) <= 10240, "16 waves per CU (four per SIMD) share 160 KB of LDS");
+#if OSMT_STAGE_UNION
+#define SH_FMASK(sh, st) ((sh).stg[st].fmask)
+#define SH_SCONST(sh, st) ((sh).stg[st].sconst)
+#else
+#define SH_FMASK(sh, st) ((sh).fmask_[st])
+#define SH_SCONST(sh, st) ((sh).sconst_[st])
+#endif
 static_assert(FILTCAP <= sizeof(osmt_srec) * SEGCAP && 8u * SEGCAP <= sizeof(SegDer) * SEGCAP && FILTCAP % 256u == 0u,
               "the filter pass borrows seg[] for its entry marks (one 4-byte store per lane) and der[] for the kept slots");
 
@@ -868,6 +902,196 @@ __device__ __forceinline__ void walk_dashed(RunState& st, const StrokeConst& kc,
     }
 }
 
+/* ---- dashed edges without original_endpoints: the calculator only where the dash phase needs it (round 6) -----------
+ * A pixel of a dashed edge costs the full calculator — dist(pixel, p1), two square roots, the exact `%`, the loop over
+ * the DashSegments (opacity_calculator.rs:32-80): ~280 instructions against the 57 of an un-dashed one; a quarter of
+ * config 2's stroke ops cost as much as the other three quarters (profiles/r06_a_heavy_split.txt).  But WITHOUT
+ * original_endpoints (cap_dist == 0 for every pixel: the line cap is not Round, or use_caps_for_dashes is off)
+ *   (1) how far a run goes does not depend on the dashes: is_in_line <=> cdop > 0 <=> cd < feather_to, as for an
+ *       un-dashed edge (mul0 > 0; STROKE_TINY_MUL ops do not come here);
+ *   (2) a pixel whose phase dist_rem lies strictly inside (start_to, end_from) of a segment with opacity_mul == 1.0 has
+ *       sd_op == 1.0 (every segment's value is <= 1), so its opacity is min(1.0, cdop) = cdop — the un-dashed pixel;
+ *   (3) a pixel whose phase lies outside every [start_from, end_to] has sd_op == 0: opacity 0, set_pixel is a no-op
+ *       (max-alpha against a plane of +0.0; initial_opacity >= 0 is validated).
+ * Which of the three holds is decided from an APPROXIMATE phase — |dot(pixel - p1, p2 - p1)| / len instead of
+ * sqrt(dist(pixel, p1)^2 - cd^2), one multiply on a value that is updated by additions like center_dist_raw — with a
+ * margin `mu` that covers the distance between the two.  The reference evaluates, in f64 (S, CD, SD: the exact
+ * squared distance to p1, distance to the line, distance along it; S = SD^2 + CD^2),
+ *     ld^2 = S (1 + d3), |d3| <= 2^-50;   cd^2 = CD^2 (1 + d5), |d5| <= 2^-49;   diff = SD^2 + e,
+ *     |e| <= S 2^-50 + CD^2 2^-49 + 2^-53 |diff| <= SD^2 2^-49 + CD^2 2^-48,
+ *     |sqrt(max(diff, 0)) - SD| <= min(|e| / SD, sqrt(2 |e|)) <= SD 2^-49 + CD 2^-23  (CD < feather_to <= 2^15 + 1: <= 2^-7.9),
+ * then adds `traveled` (one rounding, <= 2^-53 of the sum) and takes an exact `%`; the approximation has relative error
+ * 2^-50.  mu = 2^-7 + 2^-40 (traveled + distance along the line + 64) is above all of it for every input the
+ * validation admits (|coordinates| <= 2^28, widths <= 65536).  Pixels within mu of a ramp, of 0 or of the pattern
+ * length — a few per cent for real dash patterns — are queued (sub-tile cell + record: four bytes) and evaluated by the
+ * EXACT calculator with lanes packed, once the queue holds a wave's worth or the op's runs are walked; everything
+ * a queued pixel needs is recomputed from its cell and its record, bit for bit what the run held
+ * (center_dist_raw is an exact integer either way).  tests/test_gpu_parity_ops.py::test_dash_phase_*, the fuzzer and the
+ * golden crops "dashed" / "subway" hold the two paths against the oracle. */
+__device__ __forceinline__ double dashed_exact_opacity(const double (*dtab)[DTAB_F], int n, double total, double r_total, double ddx,
+                                                       double ddy, double cd, double traveled) {
+    const double ld = sqrt(ddx * ddx + ddy * ddy);       /* dist(pixel, p1), line.rs:119 */
+    const double sd = sqrt(fmax(ld * ld - cd * cd, 0.0)); /* line.rs:120 */
+    double dist_rem = traveled + sd;
+    { /* total > 0, dist_rem >= 0: exact `%` (opacity_calculator.rs:57-60), quotient estimated with RN(1 / total) */
+        double nq = trunc(dist_rem * r_total);
+        double rr = fma(-nq, total, dist_rem);
+        if (rr < 0.0) {
+            nq -= 1.0;
+            rr = fma(-nq, total, dist_rem);
+        } else if (rr >= total) {
+            nq += 1.0;
+            rr = fma(-nq, total, dist_rem);
+        }
+        dist_rem = rr;
+    }
+    double sd_op = 0.0;
+    for (int i = 0; i < n; ++i) { /* opacity_calculator.rs:145-157 */
+        const double s_from = dtab[i][0], s_to = dtab[i][1], e_from = dtab[i][2], e_to = dtab[i][3];
+        if (dist_rem < s_from || dist_rem > e_to) continue;
+        double base;
+        if (dist_rem <= s_to) {
+            const double d = s_to - s_from, x = dist_rem - s_from;
+            base = d == 1.0 ? x : osmt_div_exact(x, d, dtab[i][5]);
+        } else if (dist_rem < e_from) {
+            base = 1.0;
+        } else {
+            const double d = e_to - e_from, x = e_to - dist_rem;
+            base = d == 1.0 ? x : osmt_div_exact(x, d, dtab[i][6]);
+        }
+        sd_op = fmax(sd_op, dtab[i][4] * base);
+    }
+    return sd_op;
+}
+
+template <class Shared>
+__device__ __forceinline__ void dashed_drain(Shared& sh, uint32_t qn, const StrokeConst& kc, int n, double total, double r_total, double initial_opacity,
+                                             const SubRect& rc) {
+    const uint32_t q = fresh_lane();
+    if (q < qn) {
+        const uint32_t e = sh.queue[q];
+        const uint32_t rx = e & (uint32_t)(SUB - 1), ry = (e >> 5) & (uint32_t)(SUBH - 1);
+        const osmt_srec& r = sh.seg[e >> 16];
+        const int32_t ddx = rc.x0 + (int32_t)rx - r.p1x, ddy = rc.y0 + (int32_t)ry - r.p1y;
+        const int32_t dxs = r.p2x - r.p1x, dys = r.p2y - r.p1y;
+        /* center_dist_raw (line.rs:116-117; the constant cancels at p1): the integer the run's additions held */
+        const double raw = (double)((int64_t)dys * (int64_t)ddx - (int64_t)dxs * (int64_t)ddy);
+        const double cd = osmt_div_exact(fabs(raw), r.denom, r.rdenom);
+        const double sd_op = dashed_exact_opacity(sh.dtab, n, total, r_total, (double)ddx, (double)ddy, cd, r.traveled);
+        const double num = kc.ft0 - cd; /* cd < feather_to: the run checked it */
+        const double qv = kc.fd0 == 1.0 ? num : osmt_div_exact(num, kc.fd0, kc.rfd0);
+        const double cdop = kc.mul0 * (cd < kc.ff0 ? 1.0 : qv);
+        atomicMax(&sh.plane[ry * PLANE_STRIDE + rx], (unsigned long long)__double_as_longlong(initial_opacity * fmin(sd_op, cdop)));
+    }
+}
+
+/* the EDGE items among [it_lo, it_hi) of a dashed op without original_endpoints (cap stubs are left to walk_items) */
+template <class Shared>
+__device__ __forceinline__ void walk_items_dashed(Shared& sh, uint32_t slot0, uint32_t nslot, uint32_t item_base, uint32_t it_lo, uint32_t it_hi,
+                                                  const StrokeConst& kc, int n, double total, double r_total, double initial_opacity, const SubRect& rc) {
+    const double ff0 = kc.ff0, ft0 = kc.ft0, fd0 = kc.fd0, rfd0 = kc.rfd0, mul0 = kc.mul0;
+    uint32_t qn = 0u; /* queued pixels (wave-uniform) */
+    for (uint32_t b0 = it_lo; b0 < it_hi; b0 += 64u) {
+        const uint32_t it = b0 + fresh_lane();
+        bool active = it < it_hi;
+        RunState st;
+        /* the run's WINDOW: the interval of distances along the polyline (traveled + distance along the edge, un-reduced)
+         * around the run's first pixel in which the verdict of that pixel holds — the inside of a dash (2), kind 1, or a gap
+         * between dashes (3), kind 2, shrunk by mu on both sides; kind 0: the run starts within a ramp, no window.  The
+         * phase changes by less than a pixel per step of a run, so most pixels of a run stay in its window: the per-pixel
+         * test is one multiply-add and two compares, the DashSegments are looked at once per RUN. */
+        double dotv = 0.0, dot_step = 0.0, dot_corr = 0.0, trav = 0.0, w_lo = 0.0, w_hi = -1.0;
+        uint32_t slot_tag = 0u, kind = 0u;
+        if (active) {
+            uint32_t lo_s = slot0, nn = nslot;
+            while (nn > 1u) {
+                const uint32_t half = nn >> 1;
+                const bool right = sh.pre[lo_s + half - 1u] <= it;
+                lo_s = right ? lo_s + half : lo_s;
+                nn = right ? nn - half : half;
+            }
+            const uint32_t base_items = (lo_s == slot0) ? item_base : sh.pre[lo_s - 1u];
+            const osmt_srec& r = sh.seg[lo_s];
+            const SegDer& d = sh.der[lo_s];
+            if (d.w & SEGW_CAP) {
+                active = false;
+            } else {
+                bool skip_first;
+                walk_setup(st, r, d, it - base_items, rc, &skip_first);
+                const double dxs = (double)(r.p2x - r.p1x), dys = (double)(r.p2y - r.p1y);
+                dotv = dxs * (double)st.d1x + dys * (double)st.d1y;
+                dot_step = dxs * (double)st.sx + dys * (double)st.sy;
+                dot_corr = dxs * (double)st.cx + dys * (double)st.cy;
+                trav = r.traveled;
+                slot_tag = lo_s << 16;
+                const double dt0 = trav + fabs(dotv) * st.rdenom;
+                const double mu = 0x1p-7 + 0x1p-40 * (dt0 + 64.0);
+                const double base = trunc(dt0 * r_total) * total;
+                const double p0 = dt0 - base;
+                bool in_any = false, interior = false;
+                double g_lo = 0.0, g_hi = total, i_lo = 0.0, i_hi = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const double s_from = sh.dtab[i][0], s_to = sh.dtab[i][1], e_from = sh.dtab[i][2], e_to = sh.dtab[i][3];
+                    in_any = in_any || (p0 >= s_from && p0 <= e_to);
+                    g_lo = e_to < p0 ? fmax(g_lo, e_to) : g_lo;
+                    g_hi = s_from > p0 ? fmin(g_hi, s_from) : g_hi;
+                    if (sh.dtab[i][4] == 1.0 && p0 > s_to && p0 < e_from) {
+                        interior = true;
+                        i_lo = fmax(s_to, 0.0);
+                        i_hi = fmin(e_from, total);
+                    }
+                }
+                if (interior) {
+                    kind = 1u;
+                    w_lo = base + i_lo + mu;
+                    w_hi = base + i_hi - mu;
+                } else if (!in_any) {
+                    kind = 2u;
+                    w_lo = base + g_lo + mu;
+                    w_hi = base + g_hi - mu;
+                }
+            }
+        }
+        while (__ballot(active)) {
+            bool slow = false;
+            if (active) {
+                const double cd = osmt_div_exact(fabs(st.raw), st.denom, st.rdenom); /* == fabs(raw) / denom (line.rs:116-118) */
+                if (!(cd < ft0)) {
+                    active = false; /* (1): the run ends where an un-dashed one would */
+                } else if ((((uint32_t)st.rx & ~(uint32_t)(SUB - 1)) | ((uint32_t)st.ry & ~(uint32_t)(SUBH - 1))) == 0u) {
+                    const double dt = trav + fabs(dotv) * st.rdenom;
+                    if (dt > w_lo && dt < w_hi) {
+                        if (kind == 1u) { /* (2) */
+                            const double num = ft0 - cd;
+                            const double qv = fd0 == 1.0 ? num : osmt_div_exact(num, fd0, rfd0);
+                            const double cdop = mul0 * (cd < ff0 ? 1.0 : qv);
+                            atomicMax(&sh.plane[st.ry * PLANE_STRIDE + st.rx], (unsigned long long)__double_as_longlong(initial_opacity * cdop));
+                        } /* else (3): opacity 0 */
+                    } else {
+                        slow = true;
+                    }
+                }
+            }
+            const unsigned long long sb = __ballot(slow);
+            if (sb) {
+                const uint32_t ns = (uint32_t)__popcll(sb);
+                if (qn + ns > 64u) {
+                    dashed_drain(sh, qn, kc, n, total, r_total, initial_opacity, rc);
+                    qn = 0u;
+                }
+                if (slow) sh.queue[qn + (uint32_t)__popcll(sb & ((1ull << fresh_lane()) - 1ull))] = slot_tag | ((uint32_t)st.ry << 5) | (uint32_t)st.rx;
+                qn += ns;
+            }
+            if (active) {
+                const bool corr = st.err + st.two_a > st.b;
+                dotv += corr ? dot_step + dot_corr : dot_step;
+                walk_advance(st);
+            }
+        }
+    }
+    if (qn) dashed_drain(sh, qn, kc, n, total, r_total, initial_opacity, rc);
+}
+
 /* Items [it_lo, it_hi) of the compacted records [slot0, slot0 + nslot) of ONE op — its edges' records and, behind them,
  * its cap stubs' — lanes packed: the record of item `it` is the first slot whose inclusive item prefix exceeds it
  * (bisection over the LDS prefix).  Edges and stubs share a pass (round 3 walked them in separate ones: a quarter of all
@@ -881,6 +1105,13 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
     OSMT_DBG(if (lane == 0u) { sh.dbg[1] += (it_hi - it_lo + 63u) / 64u; sh.dbg[2] += it_hi - it_lo; })
     const bool main_plain = (sflags & STROKE_PLAIN_MAIN) != 0u;
     const bool unit_fd = (sflags & (STROKE_UNIT_FD | STROKE_TINY_MUL)) == STROKE_UNIT_FD;
+    const bool dash_fast = (sflags & STROKE_DASH_FAST) != 0u;
+    if (dash_fast) {
+        walk_items_dashed(sh, slot0, nslot, item_base, it_lo, it_hi, kc, sa->main_n_segs, sa->main_total_len, sa->main_r_total, initial_opacity, rc);
+        /* the op's cap stubs (another calculator, line.rs:22), if it has any in this sub-tile, go through the loop below */
+        const uint32_t l_ = fresh_lane();
+        if (!__ballot(l_ < nslot && (sh.der[slot0 + l_].w & SEGW_CAP) != 0u)) return;
+    }
     for (uint32_t it = it_lo + lane; it < it_hi; it += 64u) {
         uint32_t lo_s = slot0, n = nslot;
         while (n > 1u) {
@@ -902,15 +1133,21 @@ __device__ __forceinline__ void walk_items(Shared& sh, uint32_t lane, uint32_t s
             else
                 walk_plain<false>(st, kc, initial_opacity, skip_first, sh.plane);
         } else {
+#ifndef OSMT_V_NODASH /* compile-time probe: the kernel without the full calculator */
 #pragma unroll 1
             for (uint32_t t = main_plain ? 1u : 0u; t < 2u; ++t) { /* t = 0: dashed edges (calculator `main`), 1: cap stubs (line.rs:22) */
                 if (is_cap != (t == 1u)) continue;
+                if (dash_fast && t == 0u) continue; /* walked above */
+#ifdef OSMT_V_SKIPHEAVY /* timing probe (wrong pixels): 1 = dashed edges not walked, 2 = cap stubs not walked */
+                if (t == (OSMT_V_SKIPHEAVY - 1)) continue;
+#endif
                 const bool cp = t == 1u; /* wave-uniform: the table of a round is read with scalar loads */
                 const osmt_raster_args* la = late_args();
                 const osmt_dash_seg* sgs = cp ? &sa->caps_seg : la->dseg + (size_t)(sa - la->aux) * OSMT_MAX_DASH_SEGS;
                 walk_dashed(st, kc, cp ? 1 : sa->main_n_segs, (cp ? sa->caps_has_orig : sa->main_has_orig) != 0, cp ? 0.0 : sa->main_total_len,
                             cp ? 0.0 : sa->main_r_total, sgs, sa->half_width, r.traveled, initial_opacity, sh.plane);
             }
+#endif
         }
     }
 }
@@ -1702,6 +1939,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
      * blend_pixel keeps it at exactly 1.0 — fl(a + fl(1-a)*1.0) == 1.0 for every alpha in
      * [0, 2^52] (1-a is exact for a >= 0.5; below, the rounding error of 1-a is <= 2^-54 and
      * 1 + e rounds to 1.0) — so it is a constant, checked bit-for-bit by the f64 parity tests. */
+#ifdef OSMT_V_ACCPROBE /* occupancy probe (wrong pixels): pixels share accumulators, the instruction stream is the same */
+#define AJ(j) ((j) % OSMT_V_ACCPROBE)
+#else
+#define AJ(j) (j)
+#endif
     double acc[PXT][3];
     {
         double r = 0.0, g = 0.0, bl = 0.0;
@@ -1712,9 +1954,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
-            acc[j][0] = r;
-            acc[j][1] = g;
-            acc[j][2] = bl;
+            acc[AJ(j)][0] = r;
+            acc[AJ(j)][1] = g;
+            acc[AJ(j)][2] = bl;
         }
     }
     bool plane_clean = false; /* the alpha plane is cleared when the first stroke op shows up */
@@ -1801,8 +2043,13 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         }
         const uint32_t e_kind = e.kind_color & 255u;
         const bool is_stroke = hit && e_kind == OSMT_OP_STROKE;
-        const unsigned long long sbal = __ballot(is_stroke), fbal = __ballot(hit && !is_stroke);
+        const unsigned long long sbal = __ballot(is_stroke);
+#if OSMT_STAGE_UNION
+        const uint32_t my_stage = fresh_lane(); /* one staging slot per entry of the chunk */
+#else
+        const unsigned long long fbal = __ballot(hit && !is_stroke);
         const uint32_t my_stage = (uint32_t)__popcll((is_stroke ? sbal : fbal) & ((1ull << fresh_lane()) - 1ull));
+#endif
         /* slots of the stroke entries, prefix-summed over the chunk's lanes: the groups of the filter passes are cut out
          * of this scan with a ballot instead of a scalar loop over the entries (clamped: only "more than a pass" matters) */
         const uint32_t nv_incl = wave_incl_scan(is_stroke ? min(e.nv, 1u << 20) : 0u);
@@ -1825,7 +2072,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 /* the fill's 16 coverage words (one 64-byte line), requested by the lane that staged the entry — beside the
                  * strokes' constants, not a round trip behind them */
                 const uint4* OSMT_R src = reinterpret_cast<const uint4*>(g_fmask + e.arena);
-                uint4* dst = reinterpret_cast<uint4*>(&sh.fmask[my_stage][0]);
+                uint4* dst = reinterpret_cast<uint4*>(&SH_FMASK(sh, my_stage)[0]);
                 const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
                 dst[0] = w0;
                 dst[1] = w1;
@@ -1843,7 +2090,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 kc.mul0 = sa->mul0;
                 kc.flags = stroke_flags(sa);
                 kc._pad = 0;
-                sh.sconst[my_stage] = kc;
+                SH_SCONST(sh, my_stage) = kc;
             }
         }
         const bool any_stroke = sbal != 0ull;
@@ -2023,7 +2270,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 const osmt_stroke_aux* __restrict__ sa = &g_aux[aux_i];
                 StrokeConst kc;
                 if (stage != 255u) {
-                    kc = sh.sconst[stage];
+                    kc = SH_SCONST(sh, stage);
                 } else { /* more than STAGECAP strokes in one chunk of one sub-tile: read the table directly */
                     kc.ff0 = sa->ff0;
                     kc.ft0 = sa->ft0;
@@ -2034,6 +2281,16 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                     kc._pad = 0;
                 }
                 const uint32_t sflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.flags);
+                if (sflags & STROKE_DASH_FAST) { /* the op's DashSegments into LDS: the walk reads them per pixel */
+                    const double* OSMT_R src = reinterpret_cast<const double*>(late_args()->dseg + (size_t)aux_i * OSMT_MAX_DASH_SEGS);
+                    static_assert(sizeof(osmt_dash_seg) == 9 * sizeof(double), "nine doubles per DashSegment");
+                    const uint32_t nd = (uint32_t)sa->main_n_segs * (uint32_t)DTAB_F;
+                    for (uint32_t l = fresh_lane(); l < nd; l += 64u) {
+                        const uint32_t sg = l / (uint32_t)DTAB_F, f = l % (uint32_t)DTAB_F;
+                        (&sh.dtab[0][0])[l] = src[sg * 9u + (f < 5u ? f : f + 2u)];
+                    }
+                    __syncthreads();
+                }
                 uint32_t n_rounds = 1u, big_cap = 0u, arena = 0u;
                 if (big) {
                     big_cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.nv);
@@ -2100,7 +2357,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         const uint32_t idx = cell0 + (uint32_t)j * ROWSTEP * PLANE_STRIDE;
                         const double al = __longlong_as_double((long long)sh.plane[idx]);
                         sh.plane[idx] = 0ull;
-                        blend_rgb(acc[j], al * c0, al * c1, al * c2, al); /* from_color: o * (c/255) */
+                        blend_rgb(acc[AJ(j)], al * c0, al * c1, al * c2, al); /* from_color: o * (c/255) */
                     }
                 }
                 __syncthreads(); /* the plane is reused by the next op */
@@ -2116,7 +2373,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 OSMT_DBG(if (lane == 0) sh.dbg[5] += 1u;)
                 uint32_t w_[SUBH];
                 if (stage != 255u) {
-                    const uint4* OSMT_R lw = reinterpret_cast<const uint4*>(&sh.fmask[stage][0]);
+                    const uint4* OSMT_R lw = reinterpret_cast<const uint4*>(&SH_FMASK(sh, stage)[0]);
 #pragma unroll
                     for (int q = 0; q < SUBH / 4; ++q) {
                         const uint4 v = lw[q];
@@ -2140,7 +2397,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 if (!image) {
                     const double c0 = en.c0, c1 = en.c1, c2 = en.c2;
 #pragma unroll
-                    for (int j = 0; j < PXT; ++j) blend_masked(acc[j][0], acc[j][1], acc[j][2], c0, c1, c2, cop, m_[j]);
+                    for (int j = 0; j < PXT; ++j) blend_masked(acc[AJ(j)][0], acc[AJ(j)][1], acc[AJ(j)][2], c0, c1, c2, cop, m_[j]);
                 }
                 /* Filler::Image: icon.get(x % w, y % h) per pixel, the opacity ignored (fill.rs:36-40) — again its own
                  * if-block, through the same masked blend */
@@ -2167,7 +2424,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                                 s2 = c.z;
                                 kk = 1.0 - c.w;
                             }
-                            blend_masked(acc[j][0], acc[j][1], acc[j][2], s0, s1, s2, kk, m_[j]);
+                            blend_masked(acc[AJ(j)][0], acc[AJ(j)][1], acc[AJ(j)][2], s0, s1, s2, kk, m_[j]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -2223,10 +2480,10 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 if (text_hit && y >= ry0 && y <= ry1 && x >= cx0 && x <= cx1)
                     t = plane[(size_t)(y - ry0) * cols + (uint32_t)(x - cx0)];
                 if (t > 0.0) { /* RgbaColor::from_color(&self.color, total) (rasterizer.rs:140) */
-                    blend_rgb(acc[j], t * cr, t * cg, t * cb, t);
+                    blend_rgb(acc[AJ(j)], t * cr, t * cg, t * cb, t);
                 } else if (icon_hit && x >= ix0 && x < ix0 + iw && y >= iy0 && y < iy0 + ih) {
                     const double4 c = ipx[(size_t)(y - iy0) * (uint32_t)iw + (uint32_t)(x - ix0)];
-                    blend_rgb(acc[j], c.x, c.y, c.z, c.w);
+                    blend_rgb(acc[AJ(j)], c.x, c.y, c.z, c.w);
                 }
             }
           }
@@ -2249,9 +2506,9 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         for (int j = 0; j < PXT; ++j) {
             const uint32_t row = ly_o + (uint32_t)j * ROWSTEP;
             uint8_t* px = stg + (row * SUB + lx_o) * 3u;
-            px[0] = (uint8_t)f64_as_u8(255.0 * acc[j][0]);
-            px[1] = (uint8_t)f64_as_u8(255.0 * acc[j][1]);
-            px[2] = (uint8_t)f64_as_u8(255.0 * acc[j][2]);
+            px[0] = (uint8_t)f64_as_u8(255.0 * acc[AJ(j)][0]);
+            px[1] = (uint8_t)f64_as_u8(255.0 * acc[AJ(j)][1]);
+            px[2] = (uint8_t)f64_as_u8(255.0 * acc[AJ(j)][2]);
         }
         __syncthreads();
         constexpr uint32_t ROW_DW = SUB * 3 / 4; /* 24 dwords per row */
@@ -2271,11 +2528,11 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
         const size_t px = (size_t)(rc.y0 + (int32_t)row) * W + (size_t)(rc.x0 + (int32_t)lx_o);
         if (OUT_F64) {
             double4* out = reinterpret_cast<double4*>(g_out) + (size_t)tile * W * W + px;
-            *out = make_double4(acc[j][0], acc[j][1], acc[j][2], 1.0);
+            *out = make_double4(acc[AJ(j)][0], acc[AJ(j)][1], acc[AJ(j)][2], 1.0);
         } else {
             /* postdivide (tile_pixels.rs:171-175) with p.a == 1.0: val / 1.0 == val */
-            const uint32_t v = f64_as_u8(255.0 * acc[j][0]) | (f64_as_u8(255.0 * acc[j][1]) << 8) |
-                               (f64_as_u8(255.0 * acc[j][2]) << 16) | 0xFF000000u;
+            const uint32_t v = f64_as_u8(255.0 * acc[AJ(j)][0]) | (f64_as_u8(255.0 * acc[AJ(j)][1]) << 8) |
+                               (f64_as_u8(255.0 * acc[AJ(j)][2]) << 16) | 0xFF000000u;
             uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g_out) +
                                                         (size_t)tile * g_out_tile_stride) + px;
             /* written once, read by nobody on the device: a non-temporal store keeps the 268 MB of a launch's pixels from
