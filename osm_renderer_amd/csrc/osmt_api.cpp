@@ -1072,12 +1072,30 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     }
 
     char* d_front = nullptr;
+    /* Owns d_front until the scene's free path does: whatever way this function is left before that — a refused batch,
+     * a failed allocation, an exception out of the table building (bad_alloc, caught by guarded()) — the helpers are joined, THEIR
+     * COPIES ON THE STREAM ARE WAITED FOR (joining a helper only means its hipMemcpyAsync calls were issued: up to tens of MB may
+     * still be on their way out of the caller's arrays and into a buffer the cache would hand to the next upload at once) and the
+     * buffer goes back to the cache.  Declared behind `cc`: destroyed before it. */
+    struct front_guard {
+        osmt_ctx* ctx;
+        coord_check* cc;
+        hipStream_t st;
+        char* p = nullptr;
+        ~front_guard() {
+            if (!p) return;
+            cc->wait();
+            (void)hipStreamSynchronize(st);
+            dev_free(ctx, p);
+        }
+    } fg{ctx, &cc, st ? st : nullptr};
     if (split) {
         hipError_t fe = dev_alloc(ctx, (void**)&d_front, front_bytes + 256);
         if (fe != hipSuccess) {
             cc.wait();
             return fail(fe == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", front_bytes, hipGetErrorString(fe));
         }
+        fg.p = d_front;
         /* two helpers: the op side (jobs, ops, rings, dashes) and the coordinate side — 16 + 11 MB for 1024 config-2 tiles */
         auto copy_user_arrays = [&cc, ctx, b, st, d_front, ll, nr, o_jobs, o_ops, o_rings, o_latlon, o_refs, o_pts, o_dashes](unsigned slot, bool coords) {
             cc.rc[slot] = guarded([&] {
@@ -1111,9 +1129,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
             for (size_t j = 0; rc == OSMT_OK && j < b->n_jobs; ++j) rc = validate_job(b, j, false);
             if (rc != OSMT_OK) {
                 const std::string msg = osmt_last_error();
-                cc.wait();
-                dev_free(ctx, d_front);
-                return fail(rc, "%s", msg.c_str());
+                return fail(rc, "%s", msg.c_str()); /* (front_guard: join, wait for the copies, free) */
             }
         }
     }
@@ -1133,11 +1149,7 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     };
     mark(0);
     osmt_scene* s = new (std::nothrow) osmt_scene();
-    if (!s) {
-        cc.wait();
-        dev_free(ctx, d_front);
-        return fail(OSMT_OOM, "out of host memory");
-    }
+    if (!s) return fail(OSMT_OOM, "out of host memory");
     s->own_stream = st;
     /* host-side index tables: point -> job (for projection), op -> stroke slot */
     std::vector<uint32_t>& pt_job = s->h_pt_job;
@@ -1187,8 +1199,6 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     }
     if (n_vsegs >= 0xFFFFFFFFull) {
         delete s;
-        cc.wait();
-        dev_free(ctx, d_front);
         return fail(OSMT_INVALID_ARG, "batch too large for 32-bit indices (stroke segments)");
     }
 
@@ -1223,14 +1233,11 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
-    s->d_front = d_front;
     s->bytes = off - (split ? front_bytes : 0) + 256;
     mark(1);
     hipError_t e = dev_alloc(ctx, (void**)&s->d_base, s->bytes);
     mark(2);
     if (e != hipSuccess) {
-        cc.wait();
-        dev_free(ctx, d_front);
         scene_delete(s);
         return fail(e == hipErrorOutOfMemory ? OSMT_OOM : OSMT_HIP_ERROR, "hipMalloc(%zu) failed: %s", off,
                     hipGetErrorString(e));
@@ -1330,11 +1337,14 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     if (err == hipSuccess) err = up(s->d_op_job, op_job.data(), b->n_ops * 4);
     if (err != hipSuccess) {
         cc.wait();
+        (void)hipStreamSynchronize(st ? st : nullptr); /* copies into d_base may be on their way too */
         dev_free(ctx, s->d_base);
-        dev_free(ctx, s->d_front);
         scene_delete(s);
         return fail(OSMT_HIP_ERROR, "upload failed: %s", hipGetErrorString(err));
     }
+    /* from here on the scene owns the front buffer: every later exit goes through osmt_scene_free (which waits for the stream) */
+    s->d_front = d_front;
+    fg.p = nullptr;
     mark(3);
     rc = cc.join(); /* no kernel has seen the coordinates yet; the helper's copies are on the stream */
     if (rc == OSMT_OK && split && !host_pt_job) { /* the point -> job kernel reads the jobs the helper copied: behind the join */
@@ -1916,6 +1926,10 @@ static void png_job_release(osmt_png_job* j) {
     if (j->s_c) stream_release(ctx, j->s_c);
     if (j->st) stream_release(ctx, j->st);
     delete j;
+    /* the job's own reference (png_begin_body), dropped LAST: a job that outlives osmt_destroy — ended or dropped after the
+     * caller closed the context — would otherwise free its scene, with it the last reference, and then hand buffers and streams
+     * back to a context that ctx_teardown has deleted */
+    ctx_release(ctx);
 }
 
 /* First half.  The pre-pass runs once for the whole batch; then the tiles go through raster -> PNG encode -> file lengths
@@ -1927,9 +1941,11 @@ static int png_begin_body(osmt_ctx* ctx, const osmt_batch* batch, const osmt_lab
     osmt_png_job* j = new (std::nothrow) osmt_png_job();
     if (!j) return fail(OSMT_OOM, "out of host memory");
     j->ctx = ctx;
+    ctx->refs.fetch_add(1); /* like a scene: the context outlives its jobs (released at the end of png_job_release) */
     hipError_t e = stream_acquire(ctx, &j->st); /* the whole job lives on its own stream */
     if (e != hipSuccess) {
         delete j;
+        ctx_release(ctx);
         return fail(OSMT_HIP_ERROR, "stream: %s", hipGetErrorString(e));
     }
     j->batch = batch;

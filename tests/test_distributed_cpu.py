@@ -72,3 +72,23 @@ def test_two_rank_sharding_covers_the_batch(oracle):
     for i in range(n_tiles):
         assert seen[i] == int(full[i].astype(np.uint64).sum())
     assert xsum == int(synth.config_tiles(10000)[:, 0].sum())  # the two shards tile the 10000-tile batch exactly
+
+
+def test_bench_watchdog_gives_up_on_a_call_that_never_returns():
+    """bench.py's guard around osmt_comm_init_rank: a native call that hangs must cost a bounded wait and a
+    message, a call that returns or raises comes back as it is."""
+    import importlib.util
+    import threading
+    import time
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.call_with_timeout(lambda: 41 + 1, 5.0, "quick") == (True, 42)
+    finished, res = bench.call_with_timeout(lambda: (_ for _ in ()).throw(ValueError("boom")), 5.0, "raises")
+    assert finished and isinstance(res, ValueError)
+    gate = threading.Event()
+    t0 = time.time()
+    finished, res = bench.call_with_timeout(gate.wait, 0.3, "stuck")
+    assert (finished, res) == (False, None) and time.time() - t0 < 3.0
+    gate.set()

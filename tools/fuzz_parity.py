@@ -142,8 +142,10 @@ def make_labels(n_tiles, scale, image_ids, image_sizes):
     return L.concat_labels(out)
 
 
-def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
-    """Fuzz for `budget` seconds; returns (tiles rendered, mismatching tiles)."""
+def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False, min_iters=0):
+    """Fuzz for `budget` seconds — and for at least `min_iters` iterations whatever the budget (a test that asserts on WHAT was
+    covered asks for one full cycle of BATCH_SIZES instead of hoping that a time budget reached it on a slow or loaded host);
+    returns (tiles rendered, mismatching tiles)."""
     global rnd
     rnd = np.random.default_rng(seed)
     ctx = ctx or Context(0)
@@ -162,7 +164,7 @@ def run(budget=60.0, seed=1, ctx=None, dump=True, with_labels=False):
     n_tiles = n_bad = 0
     stats = {"batches": {}, "empty_tiles": 0, "folded_tiles": 0, "listed_tiles": 0}
     it = 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget or it < min_iters:
         sizes_now = BATCH_SIZES[:4] if with_labels else BATCH_SIZES  # (the label oracle is the slow side: no 130-tile label batches)
         bs = sizes_now[it % len(sizes_now)]
         it += 1
