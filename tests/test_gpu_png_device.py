@@ -137,6 +137,30 @@ def test_png_begin_end_pipelined_equals_the_one_piece_call(gpu_ctx, oracle):
     assert gpu_ctx.render_batch_png(lists[3]) == want[3]
 
 
+def test_png_job_outlives_its_context():
+    """a begun job that is ended — or just dropped — AFTER the caller destroyed the context (an exception between
+    png_begin and png_end with ctx.close() in a finally block) must not hand its buffers and streams back to a context that
+    has been torn down: the job holds a reference of its own, the teardown runs when the job lets go."""
+    from osm_renderer_amd.renderer import Context
+
+    dl = synth.make_tiles(synth.config_tiles(5, x0=19100, y0=10100), n_poly=10, n_line=8)
+    ref_ctx = Context(0)
+    want = ref_ctx.render_batch_png(dl)
+    ref_ctx.close()
+    for how in ("end", "drop"):
+        ctx = Context(0)
+        job = ctx.png_begin(dl)
+        ctx.close()  # osmt_destroy with a job in flight
+        if how == "end":  # (png_end only passes the job on: the closed context's handle is not used)
+            got = ctx.png_end(job, np.empty(dl.n_jobs * 96 * 1024, dtype=np.uint8), as_bytes=True)
+            assert got == want
+        else:
+            del job  # PngJob.__del__ -> osmt_render_batch_png_end(job, NULL, 0, ..): releases everything
+    after = Context(0)  # the device is fine and a new context renders the same files
+    assert after.render_batch_png(dl) == want
+    after.close()
+
+
 def test_compacted_files_in_dead_framebuffers_or_in_a_buffer_of_their_own(gpu_ctx):
     """A chunk's files are compacted into that chunk's framebuffers (dead once encoded); with more than two chunks the
     framebuffers are re-used, and the job takes a separate buffer (forced here with the diagnostic OSMT_PNG_CHUNKS, which
