@@ -27,6 +27,13 @@
  *                         the crop, inner ring fitted; the hole drawn as a separate op differs)
  *     Inputs were FITTED (the .osm is missing); +-1 px / reversed inputs do not match — see
  *     tests/golden/make_ref_patches.py for what that does and does not prove.
+ *     Round 6, from the goldens BELOW z17 (tests/rendered/14_expected.png, 15_expected.png; tests/golden/ref_river_patches.json,
+ *     tests/test_reference_golden_rivers.py) — one waterway=river at two zooms, widths 5 and 6, Round caps:
+ *       river15_end   1743 px  a free end and its Round cap stub at z15
+ *       river14_end    582 px  the same end one zoom lower
+ *       river14_bends 4026 px  six vertices, four of them inside the window: draw_lines' join rule (NO joins: consecutive
+ *                              segments overlap, the larger alpha of the generation wins) and the walk's direction (drawn the
+ *                              other way one pixel differs)
  *   - label pass (font/rasterizer.rs, tile_pixels.rs:131-162 + the for_labels blend, labeler.rs:91-106):
  *     PINNED by the metro-station label "Арбатская" of tests/rendered/17_expected.png — icon + 9 glyphs,
  *     1135 compared pixels, 0 differ — with NOTHING fitted but the node's integer position (read off the
@@ -36,10 +43,18 @@
  *     font-size 9) shows the same label hanging into the tile below its node's tile.  Not covered by a
  *     reference output: labels that COLLIDE (hand-derived cases in tests/test_labels_oracle.py, from the
  *     reference source) and TextPosition::Line placement (host side, outside the oracle).
+ *   - image fills (Filler::Image, fill.rs:36-40): PINNED by the landuse=cemetery strip of 18_expected.png
+ *     (tests/golden/ref_image_fill_patch.json, tests/test_reference_golden_image_fill.py: 2324 pattern pixels, 0 differ).
  *   - NOT pinned by any reference output (the reference cannot be built here — no rustc/cargo,
- *     crates not vendored — and tests/osm/nano_moscow.osm is absent): Square/Butt caps,
- *     use_caps_for_dashes = false, image fills.  For these the
- *     oracle is checked only against the hand-derived vectors K1..K8 (tests/golden/kat.json,
+ *     crates not vendored — and tests/osm/nano_moscow.osm is absent), one sentence each on why no golden can:
+ *       Square / Butt caps        the stylesheet has two `linecap: square` rules, both on man_made=cutline
+ *                                 (mapnik.mapcss:319-330, colour #f2efe9): no golden at any zoom (14-18) holds a connected
+ *                                 component of that colour larger than 3 px; `butt` occurs in no rule at all;
+ *       use_caps_for_dashes=false the styler sets it per style TYPE (styler.rs:95) and every golden was rendered with the
+ *                                 Josm type (= true): the other branch never ran for them;
+ *       colliding labels          which labels WOULD have been drawn is not recoverable from pixels (needs the .osm);
+ *       anything at @2x           tests/rendered/18_2x_expected.png is missing from the mount (.MISSING_LARGE_BLOBS:2).
+ *     For these the oracle is checked only against the hand-derived vectors K1..K8 (tests/golden/kat.json,
  *     derived from the reference SOURCE) and against a second, independent Python restatement
  *     (tests/_py_area_model.py).  Status of those parts: PARITY UNPINNED.
  *
