@@ -36,7 +36,16 @@ __device__ __forceinline__ int32_t f64_as_i32(double v) {
 }
 /* Rust `f64 as u8`: truncation, saturating, NaN -> 0.  fmax(NaN, 0) == 0 (maxNum), so the clamp
  * covers every case in two instructions before the conversion. */
-__device__ __forceinline__ uint32_t f64_as_u8(double v) { return (uint32_t)(int32_t)fmin(fmax(v, 0.0), 255.0); }
+__device__ __forceinline__ uint32_t f64_as_u8(double v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OSMT_V_PLAIN_CVT)
+    /* v_cvt_u32_f64 truncates, turns NaN and negative values into 0 and saturates above: one clamp from above is left */
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return min(r, 255u);
+#else
+    return (uint32_t)(int32_t)fmin(fmax(v, 0.0), 255.0);
+#endif
+}
 
 /* Inclusive prefix sum over the 64 lanes of a wave on the DPP network: shifts inside the rows of 16 lanes (a lane
  * whose source falls outside the row adds 0), then the row totals broadcast to the following rows (row_bcast:15 into
@@ -1893,6 +1902,43 @@ __device__ __forceinline__ void blend_masked(double& r, double& g, double& b, do
         : "scc");
 }
 
+/* blend_pixel for the pending pixels of ONE stroke generation (tile_pixels.rs:205-223), one of a lane's eight pixels at a time:
+ * source colour from_color(c, al) = (al * c/255, al) (tile_pixels.rs:12-19), dst = src + (1 - al) * dst, mul then add.  Only the
+ * lanes whose cell was drawn into (al > 0: an untouched cell holds +0.0, for which the blend is the identity, bit for bit) — and
+ * when NO lane of the wave has one, i.e. the stroke did not touch these two rows of the sub-tile, the ten instructions are branched
+ * over: a stroke that crosses a sub-tile touches three or four of its eight row pairs.  (Written as compiler-visible control flow
+ * the same skip cost the registers it saved — round 4; inside one asm statement the allocator sees a straight line.) */
+__device__ __forceinline__ void blend_stroke_masked(double& r, double& g, double& b, double al, double c0, double c1, double c2) {
+#ifdef OSMT_V_PLAIN_STROKE_BLEND
+    const double k = 1.0 - al;
+    r = al * c0 + k * r;
+    g = al * c1 + k * g;
+    b = al * c2 + k * b;
+#else
+    unsigned long long save;
+    double t0, t1, t2, k;
+    asm volatile(
+        "v_cmp_lt_f64 vcc, 0, %[al]\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "s_cbranch_execz 1f\n\t"
+        "v_mul_f64 %[t0], %[al], %[c0]\n\t"
+        "v_mul_f64 %[t1], %[al], %[c1]\n\t"
+        "v_mul_f64 %[t2], %[al], %[c2]\n\t"
+        "v_add_f64 %[k], 1.0, -%[al]\n\t"
+        "v_mul_f64 %[r], %[k], %[r]\n\t"
+        "v_mul_f64 %[g], %[k], %[g]\n\t"
+        "v_mul_f64 %[b], %[k], %[b]\n\t"
+        "v_add_f64 %[r], %[t0], %[r]\n\t"
+        "v_add_f64 %[g], %[t1], %[g]\n\t"
+        "v_add_f64 %[b], %[t2], %[b]\n"
+        "1:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "+v"(r), [g] "+v"(g), [b] "+v"(b), [sv] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [k] "=&v"(k)
+        : [al] "v"(al), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2)
+        : "vcc", "scc");
+#endif
+}
+
 template <bool OUT_F64, bool LABELS, bool FOLD>
 __global__ OSMT_RASTER_BOUNDS void k_raster(
     /* ONE by-value argument block.  The tables of the hot loops (lists, coverage words, stroke records, calculator
@@ -2342,7 +2388,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                 }
                 __syncthreads();
                 /* blend this generation's pending pixels (tile_pixels.rs:205-223) */
-                /* branch-free: an untouched cell holds alpha = +0.0, and 0*c + (1 - 0)*old == old exactly */
+                /* an untouched cell holds alpha = +0.0, and 0*c + (1 - 0)*old == old exactly: blend_stroke_masked */
 #if defined(OSMT_ABL) && OSMT_ABL == 2
                 if (false) /* ablation: neither walked nor blended */
 #endif
@@ -2357,7 +2403,7 @@ __global__ OSMT_RASTER_BOUNDS void k_raster(
                         const uint32_t idx = cell0 + (uint32_t)j * ROWSTEP * PLANE_STRIDE;
                         const double al = __longlong_as_double((long long)sh.plane[idx]);
                         sh.plane[idx] = 0ull;
-                        blend_rgb(acc[AJ(j)], al * c0, al * c1, al * c2, al); /* from_color: o * (c/255) */
+                        blend_stroke_masked(acc[AJ(j)][0], acc[AJ(j)][1], acc[AJ(j)][2], al, c0, c1, c2);
                     }
                 }
                 __syncthreads(); /* the plane is reused by the next op */

@@ -6,7 +6,7 @@
 #   variants:<v1,v2,...>        tools/time_variants.py over libosmtile_<v>.so ("base" = libosmtile.so); BIG=1 adds 256 config-5 tiles
 #   fuzz[:<seconds>[:<seed>]]   tools/fuzz_parity.py (areas) ; fuzzlabels[:<seconds>[:<seed>]] with a label pass per tile
 #   bench[:<bench.py args>]     python bench.py -> bench.json (+ the scalars the round's bars are set on)
-#   prof:<workload>[:<passes>]  tools/prof_workload.py: kernel trace + counter passes (kt,sq1,sq2,fetch,write) of a bench.py --pmc-child workload
+#   prof:<workload>[@<passes>]  tools/prof_workload.py: kernel trace + counter passes (kt,sq1,sq2,sq3,fetch,write) of a bench.py --pmc-child workload ("config5:256")
 #   smoke                       __graft_entry__.smoke()
 #   worker                      tools/worker_bench.sh (native request threads)
 #   sh:<command>                anything else, logged to extra_<n>.log
@@ -41,7 +41,7 @@ except Exception as e:
 PY
       ;;
     prof)
-      wl=${arg%%:*}; passes=${arg#*:}; [ "$passes" = "$arg" ] && passes="kt,sq1,fetch,write"
+      wl=${arg%%@*}; passes=${arg#*@}; [ "$passes" = "$arg" ] && passes="kt,sq1,fetch,write"
       timeout 1500 python tools/prof_workload.py $wl $O/${wl//:/_} $passes >> $O/prof.log 2>&1; tail -2 $O/prof.log ;;
     smoke)
       timeout 600 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt ;;

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SQ_PASS_1 = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+SQ_PASS_3 = ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"]  # lane packing: thread-cycles / (64 x active cycles)
 SQ_PASS_2 = ["SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES",
              "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY"]
 

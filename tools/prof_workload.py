@@ -5,8 +5,8 @@
 
 <workload> is a `bench.py --pmc-child` name ("config2", "config5:64", "raster_2x:256", "all"); writes
 <out_prefix>_kernel_trace.txt and <out_prefix>_pmc.txt (SQ issue / wait counters, FETCH_SIZE, WRITE_SIZE — each in its
-own rocprofv3 pass with only --kernel-trace beside it).  passes: comma list out of kt,sq1,sq2,fetch,write (default all
-but sq2).
+own rocprofv3 pass with only --kernel-trace beside it).  passes: comma list out of kt,sq1,sq2,sq3,fetch,write (default all
+but sq2 / sq3).
 """
 import contextlib
 import io
@@ -44,7 +44,7 @@ def main():
                 f.write(summary(dbs[0]))
             else:
                 f.write(f"# no database (rc {r.returncode}): {r.stderr.decode(errors='replace')[-400:]}\n")
-    sets = {"sq1": pmc_pass.SQ_PASS_1, "sq2": pmc_pass.SQ_PASS_2, "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
+    sets = {"sq1": pmc_pass.SQ_PASS_1, "sq2": pmc_pass.SQ_PASS_2, "sq3": pmc_pass.SQ_PASS_3, "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
     with open(prefix + "_pmc.txt", "w") as f:
         for name in passes:
             if name not in sets:
