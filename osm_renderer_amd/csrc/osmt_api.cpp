@@ -144,19 +144,14 @@ struct osmt_scene {
     uint32_t* d_pt_job = nullptr;
     uint32_t* d_op_aux = nullptr;
     osmt_opinfo* d_info = nullptr;
-    double* d_trav = nullptr;
-    double* d_den = nullptr;
     osmt_stroke_aux* d_aux = nullptr;
     osmt_dash_seg* d_dseg = nullptr;
     uint32_t* d_submask = nullptr;
     uint32_t* d_op_blk = nullptr;
     uint32_t* d_op_vseg = nullptr; /* op -> its first virtual segment (stroke ops with segments) */
     osmt_blk_bbox* d_blk = nullptr;
-    double* d_rden = nullptr;
     uint32_t* d_op_job = nullptr;
-    int4* d_vpts = nullptr;     /* per virtual segment: end points, op (k_opinfo -> k_prebin) */
-    uint32_t* d_vop = nullptr;
-    uint32_t* d_cand_off = nullptr;
+    osmt_vseg* d_vseg = nullptr; /* per virtual segment: end points, traveled, length, slot offset, op (k_opinfo -> k_prebin) */
     unsigned long long* d_cursors = nullptr; /* 4 words; the per-sub-tile list counts follow (one memset) */
     uint32_t* d_cnt = nullptr;
     uint2* d_hdr = nullptr;
@@ -717,22 +712,17 @@ osmt_prepass_args prepass_args(const osmt_scene* sc, bool sizing) {
     a.op_job = sc->d_op_job;
     a.op_blk = sc->d_op_blk;
     a.op_vseg = sc->d_op_vseg;
-    a.vpts = sc->d_vpts;
-    a.vop = sc->d_vop;
+    a.vseg = sc->d_vseg;
     a.n_vsegs = sc->n_vsegs;
     a.max_job_ops = sc->max_job_ops;
     a.fold_max_ops = sc->n_jobs <= OSMT_FOLD_MAX_JOBS ? OSMT_FOLD_MAX_OPS : 0u;
     a.scale = sc->scale;
     a.sub_rows = OSMT_TILE_SIZE * sc->scale / OSMT_SUB_H;
     a.info = sc->d_info;
-    a.trav = sc->d_trav;
-    a.den = sc->d_den;
-    a.rden = sc->d_rden;
     a.aux = sc->d_aux;
     a.dseg = sc->d_dseg;
     a.blk = sc->d_blk;
     a.submask = sc->d_submask;
-    a.cand_off = sc->d_cand_off;
     a.cursors = sc->d_cursors;
     a.cnt = sc->d_cnt;
     a.hdr = sc->d_hdr;
@@ -1219,17 +1209,12 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
 
     const size_t o_info = carve(b->n_ops * sizeof(osmt_opinfo));
     /* per virtual segment (not per point: two stroke ops may share a ring, e.g. a casing and its stroke) */
-    const size_t o_trav = carve((n_vsegs + 1) * 8);
-    const size_t o_den = carve((n_vsegs + 1) * 8);
     const size_t o_aux = carve((size_t)(n_strokes + 1) * sizeof(osmt_stroke_aux));
     const size_t o_dseg = carve((size_t)(n_strokes + 1) * OSMT_MAX_DASH_SEGS * sizeof(osmt_dash_seg)); /* touched by dashed ops only */
     const size_t sub_rows = (size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_H;
     const size_t o_submask = carve(b->n_ops * sub_rows * 4);
     const size_t o_blk = carve((n_blk + 1) * sizeof(osmt_blk_bbox));
-    const size_t o_rden = carve((n_vsegs + 1) * 8);
-    const size_t o_candoff = carve((n_vsegs + 1) * 4);
-    const size_t o_vpts = carve((n_vsegs + 1) * sizeof(int4));
-    const size_t o_vop = carve((n_vsegs + 1) * 4);
+    const size_t o_vseg = carve((n_vsegs + 1) * sizeof(osmt_vseg));
     const size_t n_sub = ((size_t)OSMT_TILE_SIZE * b->scale / OSMT_SUB_W) * sub_rows;
     const size_t o_cursors = carve(32 + b->n_jobs * n_sub * 4); /* cursors + list counts: zeroed together every frame */
     const size_t o_hdr = carve(b->n_jobs * n_sub * sizeof(uint2));
@@ -1255,19 +1240,14 @@ static int scene_upload_impl(osmt_ctx* ctx, const osmt_batch* b, osmt_scene** ou
     s->d_pt_job = (uint32_t*)(fbase + o_ptjob);
     s->d_op_aux = (uint32_t*)(fbase + o_opaux);
     s->d_info = (osmt_opinfo*)(rbase + o_info);
-    s->d_trav = (double*)(rbase + o_trav);
-    s->d_den = (double*)(rbase + o_den);
     s->d_aux = (osmt_stroke_aux*)(rbase + o_aux);
     s->d_dseg = (osmt_dash_seg*)(rbase + o_dseg);
     s->d_submask = (uint32_t*)(rbase + o_submask);
     s->d_op_blk = (uint32_t*)(fbase + o_opblk);
     s->d_op_vseg = (uint32_t*)(fbase + o_opvseg);
     s->d_blk = (osmt_blk_bbox*)(rbase + o_blk);
-    s->d_rden = (double*)(rbase + o_rden);
     s->d_op_job = (uint32_t*)(fbase + o_opjob);
-    s->d_vpts = (int4*)(rbase + o_vpts);
-    s->d_vop = (uint32_t*)(rbase + o_vop);
-    s->d_cand_off = (uint32_t*)(rbase + o_candoff);
+    s->d_vseg = (osmt_vseg*)(rbase + o_vseg);
     s->d_cursors = (unsigned long long*)(rbase + o_cursors);
     s->d_cnt = (uint32_t*)(rbase + o_cursors + 32);
     s->d_hdr = (uint2*)(rbase + o_hdr);

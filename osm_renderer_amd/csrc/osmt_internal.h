@@ -107,6 +107,19 @@ struct alignas(16) osmt_srec {
 };
 static_assert(sizeof(osmt_srec) == 64, "osmt_srec is one 64-byte line: four 16-byte stores by k_stroke_bin, four loads by k_raster");
 
+/* What k_opinfo leaves per VIRTUAL SEGMENT (an edge of a stroke op, or one of its two cap stubs; index = op_vseg[op] + running
+ * edge, the stubs last) for the binning kernel, as ONE 48-byte record: three 16-byte stores by the op's lane, three loads by the
+ * segment's lane.  (Round 6: with k_opinfo no longer queueing behind its atomics, the bytes it writes show — pre-pass of 256
+ * config-5 tiles 2.77 -> 2.73 ms, 64 tiles 0.935 -> 0.906, config 2 0.207 -> 0.2055; profiles/r06_n_vseg_aos_stage_times.txt.) */
+struct alignas(16) osmt_vseg {
+    int32_t p1x, p1y, p2x, p2y; /* p1 == p2: draws nothing (a degenerate edge, line.rs:73-75, or an invalid stub) */
+    double trav;                /* traveled before the edge (line.rs:31); 0 for a stub */
+    double den, rden;           /* |p2 - p1| = center_dist_denom (line.rs:104) and its correctly rounded reciprocal */
+    uint32_t cand_off;          /* first slot (relative to the op) of the segment's sub-tile window */
+    uint32_t vop;               /* the op; bit 31: the segment is a cap stub */
+};
+static_assert(sizeof(osmt_vseg) == 48, "three 16-byte words");
+
 /* Ops with more than 64 edges get one bounding box per block of 64 consecutive edges (running
  * edge index over all rings): k_fill_rows skips the blocks whose rows miss the rows it is working on. */
 struct osmt_blk_bbox {
@@ -271,20 +284,14 @@ struct osmt_prepass_args {
     uint32_t max_job_ops;  /* most ops of any tile */
     uint32_t fold_max_ops; /* tiles of at most this many ops get no lists (0: all do); max_job_ops <= fold_max_ops = no k_sublist launch */
     osmt_opinfo* info;
-    /* per VIRTUAL SEGMENT (index = op_vseg[op] + running edge index), so ops that share rings do not collide */
-    double* trav;
-    double* den;
-    double* rden;
     osmt_stroke_aux* aux;
     osmt_dash_seg* dseg; /* [stroke][OSMT_MAX_DASH_SEGS] */
     osmt_blk_bbox* blk;
     uint32_t* submask;
-    uint32_t* cand_off; /* per virtual segment: first slot (relative to the op) of the edge's sub-tile window */
-    /* per virtual segment too, so that the binning kernel starts from ONE level of loads (round 3 went vseg -> table slot ->
-     * op -> opinfo -> osmt_op -> ring -> points, seven dependent round trips for a latency-bound kernel): end points of
-     * the edge / cap stub (p1 == p2: draws nothing) and its op, bit 31 = the segment is a cap stub */
-    int4* vpts;
-    uint32_t* vop;
+    /* per VIRTUAL SEGMENT (index = op_vseg[op] + running edge index, so ops that share rings do not collide): what the binning
+     * kernel needs of an edge / cap stub in ONE record, one level of loads (round 3 went vseg -> table slot -> op -> opinfo ->
+     * osmt_op -> ring -> points; rounds 4-5 kept six arrays: six scattered partial-line stores per edge) */
+    osmt_vseg* vseg;
     unsigned long long* cursors; /* [0] fill arena (64-byte groups), [1] stroke arena (records), [2] list entries; zeroed by the launcher */
     uint32_t* cnt;      /* [n_jobs][nsub], right behind the cursors (zeroed with them): ops that draw into the sub-tile */
     uint2* hdr;         /* [n_jobs][nsub]: k_sublist's (first entry, count) */

@@ -318,13 +318,17 @@ __global__ __launch_bounds__(OPINFO_THREADS * OPINFO_WAVES) void k_opinfo(const 
                      * (line.rs:104: sqrt(dy*dy + dx*dx) of the absolute deltas — the same f64) */
                     const double len = point_dist(prev.x, prev.y, p.x, p.y);
                     const uint32_t e = vbase + seen - 1u; /* the edge's virtual segment: private to this op even when rings are shared */
-                    a.trav[e] = traveled; /* traveled BEFORE this edge */
-                    a.den[e] = len;
-                    a.rden[e] = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
+                    {
+                        osmt_vseg vs;
+                        vs.p1x = prev.x; vs.p1y = prev.y; vs.p2x = p.x; vs.p2y = p.y;
+                        vs.trav = traveled; /* traveled BEFORE this edge */
+                        vs.den = len;
+                        vs.rden = 1.0 / len; /* correctly rounded; inf for a degenerate edge (never walked) */
+                        vs.cand_off = (uint32_t)min(cand, 0xFFFFFFFFull);
+                        vs.vop = o;
+                        a.vseg[e] = vs;
+                    }
                     traveled += len;
-                    a.cand_off[e] = (uint32_t)min(cand, 0xFFFFFFFFull);
-                    a.vpts[e] = make_int4(prev.x, prev.y, p.x, p.y);
-                    a.vop[e] = o;
                     if (!(prev.x == p.x && prev.y == p.y)) { /* a degenerate edge draws nothing (line.rs:73-75) */
                         cand += window_count(vseg_window(prev.x, prev.y, p.x, p.y, len, ft, n_sub_x, n_sub_y));
                         /* cap stubs (line.rs:33-57): only for the first / last iterated edge, only if it is not
@@ -365,12 +369,14 @@ __global__ __launch_bounds__(OPINFO_THREADS * OPINFO_WAVES) void k_opinfo(const 
             for (int i = 0; i < 2; ++i) {
                 const uint32_t e = vbase + n_edges + (uint32_t)i;
                 const bool ok = cs[i]->valid != 0;
-                a.vpts[e] = ok ? make_int4(cs[i]->p1x, cs[i]->p1y, cs[i]->p2x, cs[i]->p2y) : make_int4(0, 0, 0, 0);
-                a.vop[e] = o | 0x80000000u;
-                a.trav[e] = 0.0;
-                a.den[e] = cs[i]->denom;
-                a.rden[e] = 1.0 / cs[i]->denom;
-                a.cand_off[e] = cs[i]->cand_off;
+                osmt_vseg vs;
+                vs.p1x = ok ? cs[i]->p1x : 0; vs.p1y = ok ? cs[i]->p1y : 0; vs.p2x = ok ? cs[i]->p2x : 0; vs.p2y = ok ? cs[i]->p2y : 0;
+                vs.trav = 0.0;
+                vs.den = cs[i]->denom;
+                vs.rden = 1.0 / cs[i]->denom;
+                vs.cand_off = cs[i]->cand_off;
+                vs.vop = o | 0x80000000u;
+                a.vseg[e] = vs;
             }
         }
         /* the op's constants: built in registers, stored as three whole lines */
@@ -1622,12 +1628,10 @@ struct StrokeBinShared {
 };
 
 __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint32_t blk, const uint32_t lane,
-                                                const osmt_opinfo* __restrict__ g_info, const int4* __restrict__ g_vpts,
-                                                const uint32_t* __restrict__ g_vop, const double* __restrict__ g_trav,
-                                                const double* __restrict__ g_den, const double* __restrict__ g_rden, uint32_t n_vsegs,
-                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask, const uint32_t* __restrict__ g_cand_off,
+                                                const osmt_opinfo* __restrict__ g_info, uint32_t n_vsegs,
+                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
                                                 osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                                uint32_t* __restrict__ g_cnt) {
+                                                uint32_t* __restrict__ g_cnt, const osmt_vseg* __restrict__ g_vseg) {
     /* ---- step A, lane = virtual segment: its op, end points, sub-tile window — everything k_opinfo left per segment
      * comes in with ONE level of loads, the op's record with a second ---- */
     const uint32_t g = blk * 64u + lane;
@@ -1635,16 +1639,17 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
     const int32_t n_sub_x = W / SUB, n_sub_y = (int32_t)sub_rows;
     uint32_t n_pairs = 0u;
     if (g < n_vsegs) {
-        const uint32_t vo = g_vop[g];
-        const int4 pp = g_vpts[g];
+        const osmt_vseg vsr = g_vseg[g];
+        const uint32_t vo = vsr.vop;
+        const int4 pp = make_int4(vsr.p1x, vsr.p1y, vsr.p2x, vsr.p2y);
         const uint32_t o = vo & 0x7FFFFFFFu;
         StrokeBinSeg sg;
         sg.is_cap = vo >> 31;
         sg.rec.p1x = pp.x; sg.rec.p1y = pp.y; sg.rec.p2x = pp.z; sg.rec.p2y = pp.w;
-        sg.rec.traveled = g_trav[g]; /* 0 for a cap stub */
-        sg.rec.denom = g_den[g];
-        sg.rec.rdenom = g_rden[g];
-        const uint32_t cand_off = g_cand_off[g];
+        sg.rec.traveled = vsr.trav; /* 0 for a cap stub */
+        sg.rec.denom = vsr.den;
+        sg.rec.rdenom = vsr.rden;
+        const uint32_t cand_off = vsr.cand_off;
         if (!(sg.rec.p1x == sg.rec.p2x && sg.rec.p1y == sg.rec.p2y)) { /* line.rs:73-75; also how an invalid stub is stored */
             const osmt_opinfo* __restrict__ oi = &g_info[o];
             sg.ft = oi->stroke_ft;
@@ -1711,14 +1716,12 @@ __device__ __forceinline__ void stroke_bin_body(StrokeBinShared& sh, const uint3
  * the two kinds overlap on the machine instead of running back to back. */
 __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops, uint32_t n_ops, const osmt_opinfo* __restrict__ g_info,
                                                const osmt_ring* __restrict__ g_rings, const int2* __restrict__ g_pts,
-                                               const double* __restrict__ g_trav, const double* __restrict__ g_den,
-                                               const double* __restrict__ g_rden, const int4* __restrict__ g_vpts,
-                                               const uint32_t* __restrict__ g_vop, const uint32_t* __restrict__ g_op_blk,
+                                               const uint32_t* __restrict__ g_op_blk,
                                                const osmt_blk_bbox* __restrict__ g_blk, uint32_t n_vsegs, uint32_t n_vblk,
                                                uint32_t scale, uint32_t sub_rows, uint32_t* __restrict__ g_submask,
-                                               const uint32_t* __restrict__ g_cand_off, uint32_t* __restrict__ g_fmask,
+                                               uint32_t* __restrict__ g_fmask,
                                                osmt_srec* __restrict__ g_srec, uint2* __restrict__ g_skey, const uint32_t* __restrict__ g_op_job,
-                                               uint32_t* __restrict__ g_cnt) {
+                                               uint32_t* __restrict__ g_cnt, const osmt_vseg* __restrict__ g_vseg) {
     __shared__ union {
         FillShared fill;
         StrokeBinShared bin;
@@ -1731,8 +1734,8 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
     if (b >= n_vblk) return; /* ablation: no fill rows */
 #endif
     if (b < n_vblk)
-        stroke_bin_body(shu.bin, b, threadIdx.x, g_info, g_vpts, g_vop, g_trav, g_den, g_rden, n_vsegs, scale, sub_rows, g_submask, g_cand_off,
-                        g_srec, g_skey, g_op_job, g_cnt);
+        stroke_bin_body(shu.bin, b, threadIdx.x, g_info, n_vsegs, scale, sub_rows, g_submask,
+                        g_srec, g_skey, g_op_job, g_cnt, g_vseg);
     else
         fill_rows_body(shu.fill, b - n_vblk, threadIdx.x, g_ops, n_ops, g_info, g_rings, g_pts, g_op_blk, g_blk, scale, sub_rows, g_submask, g_fmask,
                        g_op_job, g_cnt);
@@ -2761,8 +2764,8 @@ hipError_t osmt_launch_prepass(const osmt_prepass_args& a, hipStream_t st, bool 
     const uint32_t n_vblk = (a.n_vsegs + 63u) / 64u;
     if (a.n_ops)
         hipLaunchKernelGGL(k_prebin, dim3(n_vblk + (a.n_ops + FILL_GROUP - 1u) / FILL_GROUP), dim3(64), 0, st, a.ops, a.n_ops, a.info, a.rings, a.pts,
-                           a.trav, a.den, a.rden, a.vpts, a.vop, a.op_blk, a.blk, a.n_vsegs, n_vblk,
-                           a.scale, a.sub_rows, a.submask, a.cand_off, a.fmask, a.srec, a.skey, a.op_job, a.cnt);
+                           a.op_blk, a.blk, a.n_vsegs, n_vblk,
+                           a.scale, a.sub_rows, a.submask, a.fmask, a.srec, a.skey, a.op_job, a.cnt, a.vseg);
     /* lists only for tiles with more than OSMT_FOLD_MAX_OPS ops (k_raster's waves put the others' together themselves) */
     if (a.n_jobs && (a.fold_max_ops == 0u || a.max_job_ops > a.fold_max_ops))
         hipLaunchKernelGGL(k_sublist, dim3(a.n_jobs), dim3(SUBLIST_THREADS), 0, st, a.jobs, a.scale, a.info, a.submask, a.sub_rows, a.cnt,
