@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "osmt_internal.h"
 #define PNG_TABLE_QUAL static __device__ __constant__
@@ -28,20 +29,22 @@
 #define PNG_TOKENS_BIT (PNG_HDR_BYTES * 8u + PNG_BLOCK_HDR_BITS) /* file bit the first token starts at */
 #define PNG_HEAD_FULL_WORDS ((PNG_TOKENS_BIT >> 5) - 10u)          /* words 10 .. that hold header bits only */
 static_assert(PNG_HEAD_WORDS == PNG_HEAD_FULL_WORDS + ((PNG_TOKENS_BIT & 31u) ? 1u : 0u), "osmt_png_table.h: head words");
-static_assert(PNG_LMAX + 5u + 1u <= 32u, "a token fits one png_put");
-#define PNG_TAB_WORDS 286u
+static_assert(PNG_LMAX + 5u + PNG_LMAX <= 32u && PNG_LMAX + 13u <= 32u, "a run token, and either half of a match token, fits one png_put");
+static_assert(2u * PNG_LMAX + 5u + 13u <= 4u * PNG_LMAX, "a match of four bytes costs no more than four literals: PNG_LMAX bits per filtered byte bound every row");
+#define PNG_TAB_WORDS (286u + 30u)
+#define PNG_DTAB 286u /* tab[PNG_DTAB + s]: distance symbol s */
 
-/* `tab`: the LDS copy of png_code_table (bit-reversed code | length << 16) */
+/* `tab`: the LDS copy of png_code_table and, behind it, png_dist_table (bit-reversed code | length << 16) */
 __device__ __forceinline__ void png_tab_load(uint32_t* tab, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid; i < PNG_TAB_WORDS; i += nthreads) tab[i] = png_code_table[i];
+    for (uint32_t i = tid; i < PNG_TAB_WORDS; i += nthreads) tab[i] = i < 286u ? png_code_table[i] : png_dist_table[i - 286u];
 }
 __device__ __forceinline__ void png_lit(const uint32_t* tab, uint32_t v, uint32_t& bits, uint32_t& n) {
     const uint32_t e = tab[v];
     bits = e & 0xFFFFu;
     n = e >> 16;
 }
-/* match of length L (3..258) at distance 1: length code + extra bits + the one distance code (a single 0 bit) */
-__device__ __forceinline__ void png_run(const uint32_t* tab, uint32_t L, uint32_t& bits, uint32_t& n) {
+/* the length half of a match token: length code + extra bits */
+__device__ __forceinline__ void png_len(const uint32_t* tab, uint32_t L, uint32_t& bits, uint32_t& n) {
     uint32_t idx, eb = 0u, ev = 0u;
     if (L == 258u) {
         idx = 28u;
@@ -56,13 +59,50 @@ __device__ __forceinline__ void png_run(const uint32_t* tab, uint32_t L, uint32_
     const uint32_t e = tab[257u + idx];
     const uint32_t hn = e >> 16;
     bits = (e & 0xFFFFu) | (ev << hn);
-    n = hn + eb + 1u;
+    n = hn + eb;
+}
+/* the distance half: distance code + extra bits (RFC 1951 3.2.5: symbols 0..3 are the distances 1..4, then two symbols per
+ * power of two of d - 1) */
+__device__ __forceinline__ void png_dist(const uint32_t* tab, uint32_t d, uint32_t& bits, uint32_t& n) {
+    uint32_t idx, eb = 0u, ev = 0u;
+    if (d <= 4u) {
+        idx = d - 1u;
+    } else {
+        const uint32_t t = d - 1u;
+        const uint32_t hb = 31u - (uint32_t)__clz((int)t);
+        eb = hb - 1u;
+        idx = 2u * hb + ((t >> eb) & 1u);
+        ev = t & ((1u << eb) - 1u);
+    }
+    const uint32_t e = tab[PNG_DTAB + idx];
+    const uint32_t hn = e >> 16;
+    bits = (e & 0xFFFFu) | (ev << hn);
+    n = hn + eb;
+}
+/* match of length L (3..258) at distance 1: length code + extra bits + the code of distance symbol 0 */
+__device__ __forceinline__ void png_run(const uint32_t* tab, uint32_t L, uint32_t& bits, uint32_t& n) {
+    uint32_t idx, eb = 0u, ev = 0u;
+    if (L == 258u) {
+        idx = 28u;
+    } else if (L <= 10u) {
+        idx = L - 3u;
+    } else {
+        const uint32_t l = L - 3u;
+        eb = (31u - (uint32_t)__clz((int)l)) - 2u;
+        idx = 4u + 4u * eb + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1u);
+    }
+    const uint32_t e = tab[257u + idx];
+    const uint32_t hn = e >> 16;
+    const uint32_t d0 = tab[PNG_DTAB];
+    bits = (e & 0xFFFFu) | (ev << hn) | ((d0 & 0xFFFFu) << (hn + eb));
+    n = hn + eb + (d0 >> 16);
 }
 /* bits of the tokens of run (v, L) */
 __device__ __forceinline__ uint32_t png_run_bits(const uint32_t* tab, uint32_t v, uint32_t L) {
     const uint32_t ln = tab[v] >> 16;
     uint32_t total = ln, R = L - 1u;
-    const uint32_t n258 = (tab[285] >> 16) + 1u; /* code 285: no extra bits */
+    const uint32_t n258 = (tab[285] >> 16) + (tab[PNG_DTAB] >> 16); /* code 285: no extra bits */
     while (R >= 258u) { /* at most 11 rounds per 1024-px row (no integer division) */
         total += n258;
         R -= 258u;
@@ -380,12 +420,30 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
  * file header; bands 1..3 append into staging areas further up the tile's slot (bit 0 of a word), and once the
  * band lengths are known they are moved down, bit-shifted, behind their predecessors (dst <= src, chunked
  * read-then-write).  Adler-32 per band, combined like zlib's adler32_combine. */
+/* Round 6: LZ77 matches beyond the distance-1 runs (tests/_png_model.py is the specification, byte for byte).  79 % of a map
+ * tile's filtered bytes are zeros (runs already), the rest are short bursts of anti-aliasing residuals that cost ~8 bits each —
+ * and the same burst, zeros and next burst come back a few rows further down wherever a line keeps its slope.  Per band, all in
+ * LDS: a hash table of 256 slots (the 4 bytes at a burst's start -> the latest burst with that hash in the rows above) and a
+ * ring of the band's last eight filtered rows (a window of seven rows above buys all but 0.7 % of what the whole band would:
+ * 44.5 against 44.2 kB per config-2 tile); per row: every lane looks its first burst up, the candidates are extended 16 bytes
+ * per step, taken greedily in lane order, and the tokeniser treats a taken match as one token and its end as a run start.
+ * ~1300 matches per config-2 tile: 48.2 -> 44.5 kB (zlib -6 on the same bytes: 42.2).  (First version of the round: the whole
+ * band's history in the tile's output slot — global stores and loads behind a fence per row; at agent scope that fence wrote the
+ * XCD's L2 back once per row: 7.9 ms per 1024 tiles instead of 1.7.) */
+#define PNG_LZ_SLOTS 256u /* (1024 slots: 44.51 kB per config-2 tile, 256: 44.74 — and a fourth workgroup fits a CU's LDS) */
+#define PNG_LZ_HASH_SHIFT 24u
+#define PNG_LZ_RING 8u /* rows kept: the current one and the seven above it */
+#define PNG_LZ_MIN 4u
 template <int PX>
-__global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4 : 2, PX == 4 ? 4 : 2))) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
                                                          uint32_t H, uint32_t ihdr_crc, uint8_t* g_out, size_t out_stride,
-                                                         uint32_t band_cap_words, uint32_t* __restrict__ g_len) {
+                                                         uint32_t band_cap_words, uint32_t* __restrict__ g_len, uint32_t lz_enable) {
     constexpr uint32_t W = 64u * PX, NB = 3u * W + 1u, NBY = 3u * PX; /* bytes per lane */
     constexpr uint32_t ROWW = (PNG_LMAX * NB) / 32u + 3u;
+    constexpr uint32_t ROWBW = (NB + 3u + 20u + 3u) / 4u; /* a filtered row in LDS: byte k at byte k + 3 (a lane's span is whole dwords); a compare reads 20 bytes ahead */
+    static_assert(NB - 1u < 2048u && NBY % 4u == 0u && NBY <= 24u, "slot packing, lane spans");
+    __shared__ uint32_t sh_lz_tab[4][PNG_LZ_SLOTS];
+    __shared__ uint32_t sh_hist[4][PNG_LZ_RING][ROWBW];
     __shared__ uint32_t sh_bits[4][ROWW];
     __shared__ uint32_t sh_tab[PNG_TAB_WORDS];
     __shared__ uint32_t sh_crc_tab[256];
@@ -406,10 +464,12 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         sh_crc_tab[i] = c;
     }
     png_tab_load(sh_tab, tid, 256u);
+    for (uint32_t i = tid; i < 4u * PNG_LZ_SLOTS; i += 256u) (&sh_lz_tab[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t rows = H / 4u, y_begin = wave * rows, y_end = y_begin + rows;
     /* where this band's bits go while it is being produced */
     const uint32_t stage_w = wave == 0u ? 0u : 11u + PNG_HEAD_WORDS + wave * band_cap_words; /* band 0: the file itself */
+    const bool lz_on = lz_enable != 0u;
     uint32_t gbit = wave == 0u ? PNG_TOKENS_BIT : 0u;                        /* bit cursor relative to out_w[stage_w] */
     /* band 0 continues the last word of the block header */
     uint32_t carry = (wave == 0u && (PNG_TOKENS_BIT & 31u)) ? png_head_words[PNG_HEAD_WORDS - 1u] : 0u;
@@ -483,8 +543,108 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
             const bool st = i ? (fb[i] != fb[i - 1]) : (lane == 0u || fb[0] != pbyte);
             startmask |= (st ? 1u : 0u) << i;
         }
-        const uint32_t first_start = startmask ? base + (uint32_t)__builtin_ctz(startmask) : 0xFFFFFFFFu;
-        const unsigned long long has = __ballot(startmask != 0u);
+        /* ---- matches (see above): `eff` = where a literal + run token starts, `bound` = where a run ends inside the lane ---- */
+        uint32_t eff = startmask, bound = startmask;
+        bool m_sel = false;
+        uint32_t m_i = 0u, m_len = 0u, m_dist = 0u;
+        if (lz_on) {
+            const uint32_t r = y - y_begin;
+            uint32_t* const rowb = sh_hist[wave][r & (PNG_LZ_RING - 1u)]; /* takes the place of the row eight above */
+            uint32_t* const tab = sh_lz_tab[wave];
+#pragma unroll
+            for (int q = 0; q < (int)NBY / 4; ++q)
+                rowb[1u + lane * (NBY / 4u) + (uint32_t)q] = fb[4 * q] | (fb[4 * q + 1] << 8) | (fb[4 * q + 2] << 16) | (fb[4 * q + 3] << 24);
+            if (lane == 0u) rowb[0] = 0x04000000u; /* the filter-type byte at byte 3 */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* the lane's first burst: a non-zero byte behind a zero (or at the start of the row) */
+            uint32_t burst = 0u;
+#pragma unroll
+            for (int i = 0; i < (int)NBY; ++i) {
+                const bool pz = i ? (fb[i - 1] == 0u) : (lane == 0u || pbyte == 0u);
+                burst |= ((fb[i] != 0u && pz) ? 1u : 0u) << i;
+            }
+            const uint32_t kb = burst ? (uint32_t)__builtin_ctz(burst) : 0u;
+            const uint32_t k = base + kb;
+            const bool has_b = burst != 0u && k + 4u <= NB;
+            uint32_t hsh = 0u, cand = 0u;
+            if (has_b) {
+                const uint32_t a = k + 3u;
+                const uint32_t w4 = __builtin_amdgcn_alignbyte(rowb[(a >> 2) + 1u], rowb[a >> 2], a & 3u);
+                hsh = (w4 * 2654435761u) >> PNG_LZ_HASH_SHIFT;
+                cand = tab[hsh];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); /* every lane has looked up before any lane inserts: a row never matches itself */
+            if (has_b) atomicMax(&tab[hsh], 1u + ((r << 11) | k));
+            uint32_t n = 0u, mx = 0u, ck = 0u, cr = 0u;
+            bool going = false;
+            if (cand) {
+                cr = (cand - 1u) >> 11;
+                ck = (cand - 1u) & 2047u;
+                if (r - cr < PNG_LZ_RING) { /* still in the ring (the distance is below 8 rows: far inside deflate's 32 KiB) */
+                    m_dist = (r - cr) * NB + (k - ck);
+                    mx = min(258u, min(NB - k, NB - ck));
+                    going = true;
+                }
+            }
+            const uint32_t* const hsrc = sh_hist[wave][cr & (PNG_LZ_RING - 1u)];
+            while (__ballot(going)) {
+                if (going) {
+                    const uint32_t ca = k + 3u + n, ha = ck + 3u + n;
+                    const uint32_t* cp = rowb + (ca >> 2);
+                    const uint32_t* hp = hsrc + (ha >> 2);
+                    uint32_t cw[5], hw[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        cw[j] = cp[j];
+                        hw[j] = hp[j];
+                    }
+                    uint32_t d = 16u;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const uint32_t x = __builtin_amdgcn_alignbyte(cw[j + 1], cw[j], ca & 3u) ^ __builtin_amdgcn_alignbyte(hw[j + 1], hw[j], ha & 3u);
+                        if (x) d = 4u * (uint32_t)j + ((uint32_t)__builtin_ctz(x) >> 3);
+                    }
+                    n += d;
+                    if (d < 16u || n >= mx) going = false;
+                }
+            }
+            n = min(n, mx);
+            /* taken greedily, lanes (= positions) in order */
+            unsigned long long cb = __ballot(n >= PNG_LZ_MIN);
+            uint32_t cover = 0u;
+            while (cb) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(cb);
+                cb &= cb - 1ull;
+                const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)l), nn = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)l);
+                if (kk >= cover) {
+                    if (lane == l) m_sel = true;
+                    cover = kk + nn;
+                }
+            }
+            /* where the last taken match of the lanes below ends */
+            const unsigned long long below = __ballot(m_sel) & ((1ull << lane) - 1ull);
+            const uint32_t endv = m_sel ? k + n : 0u;
+            const uint32_t e2 = (uint32_t)__shfl((int)endv, below ? 63 - (int)__builtin_clzll(below) : 0);
+            const uint32_t in_end = below ? e2 : 0u;
+            /* the first byte behind the cover that comes in from the left, relative to this lane's span */
+            const int32_t rel = below ? (int32_t)in_end - (int32_t)base : -1;
+            const uint32_t in_cov = (uint32_t)min(max(rel, 0), (int32_t)NBY);
+            uint32_t covered = (1u << in_cov) - 1u, forced = 0u;
+            if (rel >= 0 && rel < (int32_t)NBY) forced |= 1u << (uint32_t)rel;
+            if (m_sel) {
+                m_i = kb;
+                m_len = n;
+                const uint32_t me = min(kb + n, NBY);
+                covered |= ((1u << me) - 1u) & ~((1u << kb) - 1u);
+                if (kb + n < NBY) forced |= 1u << (kb + n);
+            }
+            eff = (startmask | forced) & ~covered;
+            bound = eff | (m_sel ? 1u << m_i : 0u);
+        }
+        const uint32_t first_start = bound ? base + (uint32_t)__builtin_ctz(bound) : 0xFFFFFFFFu;
+        const unsigned long long has = __ballot(bound != 0u);
         const unsigned long long later = lane < 63u ? (has >> (lane + 1u)) : 0ull;
         const int nxt_lane = later ? (int)lane + 1 + __builtin_ctzll(later) : (int)lane;
         const uint32_t nxt_pos_raw = (uint32_t)__shfl((int)first_start, nxt_lane);
@@ -495,11 +655,17 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         for (int i = 0; i < (int)NBY; ++i) {
             a1 += fb[i];
             a2 += (NB - (base + (uint32_t)i)) * fb[i];
-            if ((startmask >> i) & 1u) {
-                const uint32_t rest = startmask >> (i + 1); /* i + 1 < 32 always: NBY <= 24 */
+            if ((eff >> i) & 1u) {
+                const uint32_t rest = bound >> (i + 1); /* i + 1 < 32 always: NBY <= 24 */
                 const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
                 my_bits += png_run_bits(sh_tab, fb[i], end - (base + (uint32_t)i));
             }
+        }
+        uint32_t ml_b = 0u, ml_n = 0u, md_b = 0u, md_n = 0u; /* the taken match's two halves */
+        if (m_sel) {
+            png_len(sh_tab, m_len, ml_b, ml_n);
+            png_dist(sh_tab, m_dist, md_b, md_n);
+            my_bits += ml_n + md_n;
         }
         uint32_t incl = my_bits;
 #pragma unroll
@@ -520,8 +686,12 @@ __global__ __launch_bounds__(256) void k_png_encode_fast(const uint8_t* __restri
         }
 #pragma unroll
         for (int i = 0; i < (int)NBY; ++i) {
-            if ((startmask >> i) & 1u) {
-                const uint32_t rest = startmask >> (i + 1);
+            if (m_sel && m_i == (uint32_t)i) {
+                png_put(bits, pos, ml_b, ml_n);
+                png_put(bits, pos, md_b, md_n);
+            }
+            if ((eff >> i) & 1u) {
+                const uint32_t rest = bound >> (i + 1);
                 const uint32_t end = rest ? base + (uint32_t)i + 1u + (uint32_t)__builtin_ctz(rest) : nxt_pos;
                 uint32_t lb, ln;
                 png_lit(sh_tab, fb[i], lb, ln);
@@ -710,16 +880,21 @@ hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uin
                            size_t out_stride, uint32_t* out_len, hipStream_t st) {
     if (n == 0) return hipSuccess;
     if (W > PNG_MAX_W) return hipErrorInvalidValue;
+    /* OSMT_PNG_LZ=0: runs only, as before round 6 (bigger files, a shorter kernel): for measurements */
+    static const uint32_t lz_enable = [] {
+        const char* v = getenv("OSMT_PNG_LZ");
+        return (uint32_t)((v && v[0] == '0') ? 0 : 1);
+    }();
     if ((W == 256u || W == 512u) && (H % 4u) == 0u && H >= 4u) {
         /* staging capacity of one band: H/4 rows of at most PNG_LMAX bits per filtered byte */
         const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * PNG_LMAX + 31u) / 32u + 2u);
         if ((size_t)(11u + PNG_HEAD_WORDS + 4u * band_cap_words) * 4u + 64u <= out_stride) {
             if (W == 256u)
                 hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
-                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
+                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len, lz_enable);
             else
                 hipLaunchKernelGGL((k_png_encode_fast<8>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
-                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len);
+                                   ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len, lz_enable);
             return hipGetLastError();
         }
     }

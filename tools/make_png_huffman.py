@@ -24,6 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tests import _png_model as png_model  # noqa: E402  (the tokeniser; its code tables are what this script replaces)
 LMAX = 12
 LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
 LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
@@ -43,28 +44,22 @@ def paeth_filter(rgb):
 
 
 def histogram(rgb):
-    """token histogram of one tile, tokenised like the kernel: literal, then runs of <= 258 at distance 1, then <= 2 literals"""
-    f = paeth_filter(rgb)
-    rows = np.concatenate([np.full((f.shape[0], 1), 4, np.uint8), f], axis=1)
+    """token histograms of one tile, tokenised by the model of the kernel (tests/_png_model.py: literals, distance-1 runs and the
+    hash matches of round 6): (literal/length counts, distance counts, extra bits, tokens, filtered rows)"""
+    toks, rows = png_model.tile_tokens(rgb)
     h = np.zeros(286, np.int64)
+    hd = np.zeros(30, np.int64)
     extra = 0
-    matches = 0
-    for row in rows:
-        h[4] += 1
-        r = row[1:]
-        brk = np.flatnonzero(np.diff(r.astype(np.int16)) != 0) + 1
-        starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [len(r)]])
-        for s, e in zip(starts, ends):
-            v = int(r[s]); h[v] += 1
-            R = int(e - s) - 1
-            while R >= 3:
-                m = min(R, 258)
-                idx = max(i for i in range(29) if LEN_BASE[i] <= m)
-                h[257 + idx] += 1; extra += LEN_EXTRA[idx]; matches += 1
-                R -= m
-            h[v] += R
+    for t in toks:
+        if t[0] == "lit":
+            h[t[1]] += 1
+        else:
+            idx = max(i for i in range(29) if LEN_BASE[i] <= t[1])
+            di = max(i for i in range(30) if png_model.DIST_BASE[i] <= t[2])
+            h[257 + idx] += 1; hd[di] += 1
+            extra += LEN_EXTRA[idx] + png_model.DIST_EXTRA[di]
     h[256] += 1
-    return h, extra, matches, rows
+    return h, hd, extra, toks, np.frombuffer(b"".join(rows), dtype=np.uint8)
 
 
 def limited_lengths(freq, lmax):
@@ -155,28 +150,20 @@ def dynamic_header(litlen, dist):
     return b
 
 
-def encode_stream(rows, litlen, codes, hdr):
-    """the deflate stream of a tile under the table (the same tokens as tests/_png_model.py): for the self-check"""
+def encode_stream(toks, litlen, codes, dlen, dcodes, hdr):
+    """the deflate stream of a tile's tokens under the table: for the self-check"""
     b = Bits(); b.put(hdr.acc, hdr.n)
-    def lit(v): b.put(rev(codes[v], litlen[v]), litlen[v])
-    for row in rows:
-        lit(4)
-        r = row[1:]; n = len(r); i = 0
-        while i < n:
-            v = int(r[i]); j = i
-            while j + 1 < n and r[j + 1] == v: j += 1
-            lit(v)
-            R = j - i
-            while R >= 3:
-                m = min(R, 258)
-                idx = max(k for k in range(29) if LEN_BASE[k] <= m)
-                s = 257 + idx
-                b.put(rev(codes[s], litlen[s]), litlen[s])
-                if LEN_EXTRA[idx]: b.put(m - LEN_BASE[idx], LEN_EXTRA[idx])
-                b.put(0, 1)  # the one distance code
-                R -= m
-            for _ in range(R): lit(v)
-            i = j + 1
+    for t in toks:
+        if t[0] == "lit":
+            b.put(rev(codes[t[1]], litlen[t[1]]), litlen[t[1]])
+            continue
+        idx = max(k for k in range(29) if LEN_BASE[k] <= t[1])
+        s = 257 + idx
+        b.put(rev(codes[s], litlen[s]), litlen[s])
+        if LEN_EXTRA[idx]: b.put(t[1] - LEN_BASE[idx], LEN_EXTRA[idx])
+        di = max(k for k in range(30) if png_model.DIST_BASE[k] <= t[2])
+        b.put(rev(dcodes[di], dlen[di]), dlen[di])
+        if png_model.DIST_EXTRA[di]: b.put(t[2] - png_model.DIST_BASE[di], png_model.DIST_EXTRA[di])
     b.put(rev(codes[256], litlen[256]), litlen[256])
     return b.acc.to_bytes((b.n + 7) // 8, "little"), b.n
 
@@ -208,30 +195,41 @@ def main():
     assert min(litlen) >= 1 and max(litlen) <= LMAX
     assert abs(sum(2.0 ** -l for l in litlen) - 1.0) < 1e-12, "the code must be complete"
     codes = canonical(litlen)
-    hdr = dynamic_header(litlen, [1])
+    # the distance code, fitted the same way: every one of the 30 symbols gets a code (a match may sit anywhere within 32 KiB)
+    fd = sum(h[1] for h in train_s).astype(np.float64)
+    mixd = fd / fd.sum()
+    if train_r:
+        frd = sum(h[1] for h in train_r).astype(np.float64)
+        mixd = 0.5 * mixd + 0.5 * frd / frd.sum()
+    dlen = limited_lengths(mixd, LMAX)
+    assert min(dlen) >= 1 and max(dlen) <= LMAX and abs(sum(2.0 ** -l for l in dlen) - 1.0) < 1e-12
+    dcodes = canonical(dlen)
+    hdr = dynamic_header(litlen, dlen)
 
-    def fixed_bits(h, extra, matches):
+    def fixed_bits(h, hd, extra):
         b = 3
         for s, c in enumerate(h):
             b += int(c) * (8 if s < 144 else 9 if s < 256 else 7 if s < 280 else 8)
-        return b + extra + 5 * matches
-    def table_bits(h, extra, matches):
-        return hdr.n + sum(int(c) * litlen[s] for s, c in enumerate(h)) + extra + matches
+        return b + extra + 5 * int(hd.sum())
+    def table_bits(h, hd, extra):
+        return hdr.n + sum(int(c) * litlen[s] for s, c in enumerate(h)) + sum(int(c) * dlen[s] for s, c in enumerate(hd)) + extra
     for name, test in (("config-2 tiles (held out)", test_s), ("reference golden tiles (held out)", test_r)):
         if not test: continue
-        fb = np.mean([fixed_bits(h, e, m) for h, e, m, _ in test]) / 8 / 1024
-        tb = np.mean([table_bits(h, e, m) for h, e, m, _ in test]) / 8 / 1024
-        zb = np.mean([len(zlib.compress(r.tobytes(), 6)) for _, _, _, r in test]) / 1024
-        print(f"{name}: fixed code {fb:.1f} KiB, this table {tb:.1f} KiB, zlib -6 on the same filtered bytes {zb:.1f} KiB")
+        fb = np.mean([fixed_bits(h, hd, e) for h, hd, e, _, _ in test]) / 8 / 1000
+        tb = np.mean([table_bits(h, hd, e) for h, hd, e, _, _ in test]) / 8 / 1000
+        zb = np.mean([len(zlib.compress(r.tobytes(), 6)) for _, _, _, _, r in test]) / 1000
+        nm = np.mean([sum(1 for t in toks if t[0] == "match" and t[2] != 1) for _, _, _, toks, _ in test])
+        print(f"{name}: fixed code {fb:.1f} kB, this table {tb:.1f} kB ({nm:.0f} hash matches per tile), zlib -6 on the same filtered bytes {zb:.1f} kB")
     # self-check: zlib inflates a stream written with the table to the filtered bytes
-    for h, e, m, rows in (test_s[:1] + test_r[:1]):
-        data, nbits = encode_stream(rows, litlen, codes, hdr)
-        assert nbits == table_bits(h, e, m) + 0, (nbits, table_bits(h, e, m))
+    for h, hd, e, toks, rows in (test_s[:1] + test_r[:1]):
+        data, nbits = encode_stream(toks, litlen, codes, dlen, dcodes, hdr)
+        assert nbits == table_bits(h, hd, e), (nbits, table_bits(h, hd, e))
         got = zlib.decompressobj(-15).decompress(data)
         assert got == rows.tobytes(), "zlib does not inflate the stream to the filtered bytes"
     print(f"header {hdr.n} bits, longest code {max(litlen)} bits, code of 0: {litlen[0]} bits, end of block: {litlen[256]} bits")
 
     entries = [rev(codes[s], litlen[s]) | (litlen[s] << 16) for s in range(286)]
+    dentries = [rev(dcodes[s], dlen[s]) | (dlen[s] << 16) for s in range(30)]
     # the file from byte 40 on: 'T' of "IDAT", the zlib header 78 01, then the block header bits
     head = Bits(); head.put(0x54, 8); head.put(0x78, 8); head.put(0x01, 8); head.put(hdr.acc, hdr.n)
     nwords = (head.n + 31) // 32
@@ -248,10 +246,15 @@ def main():
         for k in range(0, 286, 8):
             f.write("    " + ", ".join(f"0x{e:08X}u" for e in entries[k:k + 8]) + ",\n")
         f.write("};\n")
+        f.write("/* the distance code: entry = bit-reversed code | length << 16 of distance symbol 0 .. 29 (RFC 1951 3.2.5) */\n")
+        f.write("PNG_TABLE_QUAL uint32_t png_dist_table[30] = {\n")
+        for k in range(0, 30, 8):
+            f.write("    " + ", ".join(f"0x{e:08X}u" for e in dentries[k:k + 8]) + ",\n")
+        f.write("};\n")
     with open(os.path.join(ROOT, "tests", "golden", "png_huffman.json"), "w") as f:
         json.dump({"what": "the GPU PNG encoder's prefix code (tools/make_png_huffman.py): code lengths (tests/_png_model.py "
                            "derives the canonical codes itself) and the block header bits, LSB first, as a hex integer",
-                   "lmax": LMAX, "litlen_lengths": litlen, "dist_lengths": [1], "block_header_bits": hdr.n,
+                   "lmax": LMAX, "litlen_lengths": litlen, "dist_lengths": dlen, "block_header_bits": hdr.n,
                    "block_header_hex": "%x" % hdr.acc}, f)
     print("wrote osm_renderer_amd/csrc/osmt_png_table.h and tests/golden/png_huffman.json")
 
