@@ -1850,7 +1850,7 @@ size_t osmt_png_device_bound(uint32_t W, uint32_t H) {
     /* 43 header bytes + one deflate block (its constant header, then at most PNG_LMAX bits per filtered byte, EOB) +
      * Adler, CRC, IEND */
     const size_t bits = PNG_BLOCK_HDR_BITS + (size_t)H * (3 * (size_t)W + 1) * PNG_LMAX + PNG_LMAX;
-    /* + slack: the fast kernel stages four row bands in the slot behind the header words, each rounded up to words */
+    /* + slack: the fast kernel stages its eight row bands in the slot behind the header words, each rounded up to words (3 words per band) */
     return align_up(43 + (bits + 7) / 8 + 4 + 4 + 12 + 8 + 4 * PNG_HEAD_WORDS + 128, 256);
 }
 

@@ -413,11 +413,11 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
 }
 
 /* Fast path of k_png_encode for W = 64 * PX (PX = 4: 256-px tiles, PX = 8: 512): ONE tokenisation pass.
- * Wave w owns the band of rows [w*H/4, (w+1)*H/4) and walks it top to bottom; a lane owns PX consecutive pixels,
+ * Wave w owns the band of rows [w*H/PNG_BANDS, (w+1)*H/PNG_BANDS) and walks it top to bottom; a lane owns PX consecutive pixels,
  * whose raw values, the row above (carried in registers from the previous iteration) and the 3*PX filtered bytes
  * all live in registers — run starts, run ends inside the lane and token sizes are straight-line code, the next
  * row's pixels are fetched while the current one is tokenised.  Band 0 appends its rows directly behind the
- * file header; bands 1..3 append into staging areas further up the tile's slot (bit 0 of a word), and once the
+ * file header; bands 1.. append into staging areas further up the tile's slot (bit 0 of a word), and once the
  * band lengths are known they are moved down, bit-shifted, behind their predecessors (dst <= src, chunked
  * read-then-write).  Adler-32 per band, combined like zlib's adler32_combine. */
 /* Round 6: LZ77 matches beyond the distance-1 runs (tests/_png_model.py is the specification, byte for byte).  79 % of a map
@@ -434,39 +434,43 @@ __global__ __launch_bounds__(64 * PNG_WAVES) void k_png_encode(const uint8_t* __
 #define PNG_LZ_HASH_SHIFT 24u
 #define PNG_LZ_RING 8u /* rows kept: the current one and the seven above it */
 #define PNG_LZ_MIN 4u
+/* row bands of a tile = waves of its workgroup (round 6: eight, was four: a tile's latency halves — it is what a chunk of
+ * the PNG call, or a single-tile request, waits for — and a full batch still fills the machine, two workgroups per CU) */
+#define PNG_BANDS 8u
+#define PNG_NT (64u * PNG_BANDS)
 template <int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4 : 2, PX == 4 ? 4 : 2))) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
+__global__ __launch_bounds__(PNG_NT) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4 : 2, PX == 4 ? 4 : 2))) void k_png_encode_fast(const uint8_t* __restrict__ g_rgba, size_t tile_stride, uint32_t n_tiles,
                                                          uint32_t H, uint32_t ihdr_crc, uint8_t* g_out, size_t out_stride,
                                                          uint32_t band_cap_words, uint32_t* __restrict__ g_len, uint32_t lz_enable) {
     constexpr uint32_t W = 64u * PX, NB = 3u * W + 1u, NBY = 3u * PX; /* bytes per lane */
     constexpr uint32_t ROWW = (PNG_LMAX * NB) / 32u + 3u;
     constexpr uint32_t ROWBW = (NB + 3u + 20u + 3u) / 4u; /* a filtered row in LDS: byte k at byte k + 3 (a lane's span is whole dwords); a compare reads 20 bytes ahead */
     static_assert(NB - 1u < 2048u && NBY % 4u == 0u && NBY <= 24u, "slot packing, lane spans");
-    __shared__ uint32_t sh_lz_tab[4][PNG_LZ_SLOTS];
-    __shared__ uint32_t sh_hist[4][PNG_LZ_RING][ROWBW];
-    __shared__ uint32_t sh_bits[4][ROWW];
+    __shared__ uint32_t sh_lz_tab[PNG_BANDS][PNG_LZ_SLOTS];
+    __shared__ uint32_t sh_hist[PNG_BANDS][PNG_LZ_RING][ROWBW];
+    __shared__ uint32_t sh_bits[PNG_BANDS][ROWW];
     __shared__ uint32_t sh_tab[PNG_TAB_WORDS];
     __shared__ uint32_t sh_crc_tab[256];
     __shared__ uint32_t sh_col[32];
-    __shared__ uint32_t sh_raw[256];
-    __shared__ uint32_t sh_carry[4];
-    __shared__ uint32_t sh_band_bits[4], sh_band_a[4], sh_band_b[4];
-    __shared__ uint32_t sh_move[256 + 1];
+    __shared__ uint32_t sh_raw[PNG_NT];
+    __shared__ uint32_t sh_carry[PNG_BANDS];
+    __shared__ uint32_t sh_band_bits[PNG_BANDS], sh_band_a[PNG_BANDS], sh_band_b[PNG_BANDS];
+    __shared__ uint32_t sh_move[1];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint8_t* __restrict__ src = g_rgba + (size_t)tile * tile_stride;
     uint8_t* out = g_out + (size_t)tile * out_stride;
     uint32_t* out_w = reinterpret_cast<uint32_t*>(out);
-    for (uint32_t i = tid; i < 256u; i += 256u) {
+    for (uint32_t i = tid; i < 256u; i += PNG_NT) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
         sh_crc_tab[i] = c;
     }
-    png_tab_load(sh_tab, tid, 256u);
-    for (uint32_t i = tid; i < 4u * PNG_LZ_SLOTS; i += 256u) (&sh_lz_tab[0][0])[i] = 0u;
+    png_tab_load(sh_tab, tid, PNG_NT);
+    for (uint32_t i = tid; i < PNG_BANDS * PNG_LZ_SLOTS; i += PNG_NT) (&sh_lz_tab[0][0])[i] = 0u;
     __syncthreads();
-    const uint32_t rows = H / 4u, y_begin = wave * rows, y_end = y_begin + rows;
+    const uint32_t rows = H / PNG_BANDS, y_begin = wave * rows, y_end = y_begin + rows;
     /* where this band's bits go while it is being produced */
     const uint32_t stage_w = wave == 0u ? 0u : 11u + PNG_HEAD_WORDS + wave * band_cap_words; /* band 0: the file itself */
     const bool lz_on = lz_enable != 0u;
@@ -753,15 +757,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4
     }
     __threadfence_block();
     __syncthreads();
-    /* ---- move bands 1..3 down behind their predecessors ---- */
+    /* ---- move bands 1.. down behind their predecessors ---- */
     uint32_t endpos = PNG_TOKENS_BIT + sh_band_bits[0];
-    for (uint32_t b = 1; b < 4u; ++b) {
+    for (uint32_t b = 1; b < PNG_BANDS; ++b) {
         const uint32_t L = sh_band_bits[b];
         const uint32_t sw = 11u + PNG_HEAD_WORDS + b * band_cap_words; /* staging: bit 0 of out_w[sw] */
         const uint32_t sh = endpos & 31u, wb = endpos >> 5;
         const uint32_t n_src = (L + 31u) >> 5;
         const uint32_t n_dst = ((endpos + L + 31u) >> 5) - wb; /* destination words holding bits of this band */
-        for (uint32_t c = 0; c < n_dst; c += 256u) {
+        for (uint32_t c = 0; c < n_dst; c += PNG_NT) {
             const uint32_t k = c + tid;
             uint32_t w = 0u;
             if (k < n_dst) {
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4
         /* Adler-32 of the concatenation (zlib's adler32_combine): A = A1 + A2 - 1, B = B1 + B2 + len2 * (A1 - 1) */
         unsigned long long A = sh_band_a[0], B = sh_band_b[0];
         const unsigned long long len2 = (unsigned long long)rows * NB;
-        for (uint32_t b = 1; b < 4u; ++b) {
+        for (uint32_t b = 1; b < PNG_BANDS; ++b) {
             const unsigned long long A2 = sh_band_a[b], B2 = sh_band_b[b];
             B = (B + B2 + (len2 % 65521ull) * ((A + 65520ull) % 65521ull)) % 65521ull;
             A = (A + A2 + 65520ull) % 65521ull;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4
     __threadfence_block();
     __syncthreads();
     const uint32_t c0 = 37u, c1 = endb + 4u;
-    const uint32_t blk = (c1 - c0 + 255u) / 256u;
+    const uint32_t blk = (c1 - c0 + PNG_NT - 1u) / PNG_NT;
     {
         const uint32_t b0 = min(c1, c0 + tid * blk), b1 = min(c1, b0 + blk);
         uint32_t s = 0u;
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PX == 4 ? 4
     __syncthreads();
     if (tid == 0) {
         uint32_t s = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < 256u; ++i) {
+        for (uint32_t i = 0; i < PNG_NT; ++i) {
             const uint32_t b0 = min(c1, c0 + i * blk), b1 = min(c1, b0 + blk);
             const uint32_t len = b1 - b0;
             if (!len) break;
@@ -885,15 +889,15 @@ hipError_t osmt_launch_png(const void* rgba, size_t tile_stride, uint32_t n, uin
         const char* v = getenv("OSMT_PNG_LZ");
         return (uint32_t)((v && v[0] == '0') ? 0 : 1);
     }();
-    if ((W == 256u || W == 512u) && (H % 4u) == 0u && H >= 4u) {
-        /* staging capacity of one band: H/4 rows of at most PNG_LMAX bits per filtered byte */
-        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / 4u) * (3u * W + 1u) * PNG_LMAX + 31u) / 32u + 2u);
-        if ((size_t)(11u + PNG_HEAD_WORDS + 4u * band_cap_words) * 4u + 64u <= out_stride) {
+    if ((W == 256u || W == 512u) && (H % PNG_BANDS) == 0u && H >= PNG_BANDS) {
+        /* staging capacity of one band: H / PNG_BANDS rows of at most PNG_LMAX bits per filtered byte */
+        const uint32_t band_cap_words = (uint32_t)(((size_t)(H / PNG_BANDS) * (3u * W + 1u) * PNG_LMAX + 31u) / 32u + 2u);
+        if ((size_t)(11u + PNG_HEAD_WORDS + PNG_BANDS * band_cap_words) * 4u + 64u <= out_stride) {
             if (W == 256u)
-                hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
+                hipLaunchKernelGGL((k_png_encode_fast<4>), dim3(n), dim3(PNG_NT), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
                                    ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len, lz_enable);
             else
-                hipLaunchKernelGGL((k_png_encode_fast<8>), dim3(n), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
+                hipLaunchKernelGGL((k_png_encode_fast<8>), dim3(n), dim3(PNG_NT), 0, st, reinterpret_cast<const uint8_t*>(rgba), tile_stride, n, H,
                                    ihdr_crc, reinterpret_cast<uint8_t*>(out), out_stride, band_cap_words, out_len, lz_enable);
             return hipGetLastError();
         }

@@ -1,6 +1,6 @@
 """Byte-exact CPU model of the GPU PNG encoder (csrc/osmt_pngenc.hip): ONE deflate block under the constant prefix codes of
 tests/golden/png_huffman.json (literal/length and distance), Paeth filter, distance-1 runs and — on the kernel's fast path,
-256- or 512-pixel-wide images whose height splits into four bands — LZ77 matches found through a small hash table per band
+256- or 512-pixel-wide images whose height splits into eight bands — LZ77 matches found through a small hash table per band
 (round 6).  Test infrastructure for tests/test_gpu_png_device.py; the model IS the specification of the kernel's choices:
 
   row            f[0] = 4 (Paeth), f[1 .. 3W] the filtered bytes; NB = 3W + 1
@@ -28,6 +28,7 @@ DIST_EXTRA = [0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,1
 LZ_HASH_BITS = 8
 LZ_MIN_MATCH = 4
 LZ_WINDOW_ROWS = 7
+LZ_BANDS = 8  # row bands of a tile (PNG_BANDS: the waves of the kernel's workgroup), each with a table and a history of its own
 
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png_huffman.json")) as _f:
     _T = json.load(_f)
@@ -99,7 +100,7 @@ class Bits:
 
 def lz_applies(W, H):
     """the kernel's fast path (k_png_encode_fast): the only one that searches for matches"""
-    return W in (256, 512) and H % 4 == 0 and H >= 4
+    return W in (256, 512) and H % LZ_BANDS == 0 and H >= LZ_BANDS
 
 def hash4(b0, b1, b2, b3):
     w = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)
@@ -150,7 +151,7 @@ def tile_tokens(rgba, lz=None):
     out = []
     if use_lz:
         NBY = 3 * W // 64
-        rpb = H // 4
+        rpb = H // LZ_BANDS
     for y in range(H):
         row = rows[y]
         taken = []
