@@ -1753,6 +1753,10 @@ __global__ __launch_bounds__(64) void k_prebin(const osmt_op* __restrict__ g_ops
 #define OSMT_V_SUBLIST_THREADS 1024
 #endif
 constexpr uint32_t SUBLIST_THREADS = OSMT_V_SUBLIST_THREADS;
+#ifndef OSMT_V_SUBLIST_AHEAD
+#define OSMT_V_SUBLIST_AHEAD 4
+#endif
+constexpr uint32_t SUBLIST_AHEAD = OSMT_V_SUBLIST_AHEAD; /* chunks of 64 ops whose records are in flight */
 constexpr uint32_t SUBLIST_MAX_SUB = (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_W) * (OSMT_TILE_SIZE * OSMT_MAX_SCALE / OSMT_SUB_H);
 __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job* __restrict__ g_jobs, uint32_t g_scale,
                                                              const osmt_opinfo* __restrict__ g_info, const uint32_t* __restrict__ g_submask,
@@ -1762,6 +1766,7 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                                                              uint32_t g_fold_max_ops) {
     __shared__ uint32_t s_off[SUBLIST_MAX_SUB]; /* counts, then exclusive offsets inside the tile */
     __shared__ uint32_t s_base[2];              /* first entry of the tile; 1 if the reservation fits */
+    __shared__ uint2 s_q[SUBLIST_THREADS / 64u][128]; /* per wave: the ops that draw into its row, sifted out of the tile's ops in order */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
     /* fold mode only (small batches): k_raster's waves build the lists of such a tile themselves.  With g_fold_max_ops == 0 EVERY
@@ -1782,29 +1787,46 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
         const uint32_t i = b0 + lane;
         return (i < n_ops && sy < g_sub_rows) ? g_submask[(size_t)(job.op_off + i) * g_sub_rows + sy] : 0u;
     };
-    /* what an entry takes from its op's record (the arena position is resolved per sub-tile below) */
+    /* what an entry takes from its op's record, as loaded (bytes 16..19 and 32..63 of the 64-byte osmt_opinfo): the request only
+     * names registers, everything that READS them — and so waits for them — happens in `unpack`, one chunk later */
+    struct OpRaw {
+        uint32_t aux;
+        uint4 a, b; /* a: kind | cap | color[0..1], color[2], arena_off, rec_cap;  b: fill_geom, image_id, opacity (two words) */
+    };
+    static_assert(offsetof(osmt_opinfo, aux) == 16 && offsetof(osmt_opinfo, kind) == 32 && offsetof(osmt_opinfo, color) == 34 &&
+                      offsetof(osmt_opinfo, arena_off) == 40 && offsetof(osmt_opinfo, rec_cap) == 44 &&
+                      offsetof(osmt_opinfo, fill_geom) == 48 && offsetof(osmt_opinfo, image_id) == 52 && offsetof(osmt_opinfo, opacity) == 56,
+                  "k_sublist reads osmt_opinfo as three vector loads");
     struct OpRec {
         osmt_ent e;
         uint32_t geom, arena0;
         bool is_stroke;
     };
-    auto fetch = [&](uint32_t w, uint32_t b0) -> OpRec {
+    auto fetch = [&](uint32_t w, uint32_t op) -> OpRaw {
+        OpRaw r;
+        r.aux = 0u;
+        r.a = make_uint4(0u, 0u, 0u, 0u);
+        r.b = make_uint4(0u, 0u, 0u, 0u);
+        if (w != 0u) {
+            const char* __restrict__ hi = reinterpret_cast<const char*>(&g_info[job.op_off + op]);
+            r.aux = *reinterpret_cast<const uint32_t*>(hi + 16);
+            r.a = *reinterpret_cast<const uint4*>(hi + 32);
+            r.b = *reinterpret_cast<const uint4*>(hi + 48);
+        }
+        return r;
+    };
+    auto unpack = [&](const OpRaw& q) -> OpRec {
         OpRec r;
         r.e = {};
-        r.geom = 0u;
-        r.arena0 = 0u;
-        r.is_stroke = false;
-        if (w != 0u) {
-            const osmt_opinfo* __restrict__ hi = &g_info[job.op_off + b0 + lane];
-            const uint32_t kind = hi->kind;
-            r.is_stroke = kind == OSMT_OP_STROKE;
-            r.arena0 = hi->arena_off;
-            r.geom = hi->fill_geom;
-            r.e.kind_color = kind | ((uint32_t)hi->color[0] << 8) | ((uint32_t)hi->color[1] << 16) | ((uint32_t)hi->color[2] << 24);
-            r.e.opacity = hi->opacity;
-            r.e.aux = r.is_stroke ? hi->aux : hi->image_id;
-            r.e.nv = r.is_stroke ? hi->rec_cap : 0u;
-        }
+        const uint32_t kind = q.a.x & 255u;
+        r.is_stroke = kind == OSMT_OP_STROKE;
+        r.arena0 = q.a.z;
+        r.geom = q.b.x;
+        /* kind | color[0] << 8 | color[1] << 16 | color[2] << 24 (color sits at bytes 2, 3 of the first word and 0 of the second) */
+        r.e.kind_color = kind | ((q.a.x >> 16) << 8) | (q.a.y << 24);
+        r.e.opacity = __hiloint2double((int)q.b.w, (int)q.b.z);
+        r.e.aux = r.is_stroke ? q.aux : q.b.y;
+        r.e.nv = r.is_stroke ? q.a.w : 0u;
         return r;
     };
     const uint32_t pre_w = load_bits(wave, 0u); /* the wave's first row is row `wave` */
@@ -1830,7 +1852,6 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
             if (!s_base[1] && g_err) *(volatile uint32_t*)g_err = OSMT_PREPASS_ERR_LIST_ARENA; /* the tile would be blank: tell the host */
         }
     }
-    const OpRec pre = fetch(pre_w, 0u);
     __syncthreads();
     const uint32_t base = s_base[0];
     const bool fits = s_base[1] != 0u;
@@ -1846,12 +1867,15 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
         }
         if (__ballot(row_n != 0u) == 0ull) continue; /* nothing draws into this row (or the reservation failed) */
         const bool first_row = sy == wave;
-        uint32_t bits_next = first_row ? pre_w : load_bits(sy, 0u);
-        for (uint32_t b0 = 0; b0 < n_ops; b0 += 64u) {
-            const uint32_t w = bits_next;
-            if (b0 + 64u < n_ops) bits_next = load_bits(sy, b0 + 64u);
-            if (__ballot(w != 0u) == 0ull) continue;
-            const OpRec rec = (first_row && b0 == 0u) ? pre : fetch(w, b0);
+        /* Round 6.  A wave used to take the tile's ops 64 at a time and run the eight-column loop below on every chunk in which
+         * ANY op draws into its row: on a config-5 tile 141 chunks of ~240 instructions with six busy lanes each (34 k
+         * instructions per wave, 0.32-0.35 ms per 256 tiles, issue-bound at four waves per SIMD).  Now the chunks are only SIFTED
+         * — the ops that draw into this row go, in op order, into a ring in LDS (ballot, rank, one store) — and the column
+         * loop runs on 64 ops that all do: a tenth of the passes.  The op words are requested SUBLIST_AHEAD chunks before they
+         * are sifted; a batch's op records while the next batch is being sifted (the request only names registers, `unpack`
+         * is what waits). */
+        auto work = [&](const uint32_t w, const OpRaw& raw) {
+            const OpRec rec = unpack(raw);
             osmt_ent e = rec.e;
             const uint32_t geom = rec.geom, arena0 = rec.arena0;
             const bool is_stroke = rec.is_stroke;
@@ -1874,6 +1898,47 @@ __global__ __launch_bounds__(SUBLIST_THREADS) void k_sublist(const osmt_tile_job
                     row_n -= took;
                 }
             }
+        };
+        constexpr uint32_t PD = SUBLIST_AHEAD;
+        uint2* const q = s_q[wave]; /* (op, its word for this row), 128 places: a sift adds at most 64 to fewer than 64 */
+        uint32_t head = 0u, tail = 0u;
+        bool have = false;
+        uint32_t w_p = 0u;
+        OpRaw raw_p = {};
+        auto request = [&](uint32_t n) { /* the next n <= 64 sifted ops: their records are asked for */
+            __builtin_amdgcn_wave_barrier(); /* one wave's LDS traffic stays in program order; this keeps the compiler from moving it */
+            asm volatile("" ::: "memory");
+            const uint2 it = lane < n ? q[(head + lane) & 127u] : make_uint2(0u, 0u);
+            w_p = it.y;
+            raw_p = fetch(it.y, it.x);
+            head += n;
+            have = true;
+        };
+        uint32_t wq[PD];
+#pragma unroll
+        for (uint32_t j = 0; j < PD; ++j) wq[j] = (j == 0u && first_row) ? pre_w : (64u * j < n_ops ? load_bits(sy, 64u * j) : 0u);
+        for (uint32_t b0 = 0; b0 < n_ops; b0 += 64u * PD) {
+#pragma unroll
+            for (uint32_t j = 0; j < PD; ++j) {
+                const uint32_t c = b0 + 64u * j; /* this chunk; slot j of the ring holds its words */
+                if (c >= n_ops) break;
+                const uint32_t w = wq[j];
+                wq[j] = c + 64u * PD < n_ops ? load_bits(sy, c + 64u * PD) : 0u;
+                const unsigned long long m = __ballot(w != 0u);
+                if (m == 0ull) continue;
+                if (w != 0u) q[(tail + (uint32_t)__popcll(m & lanes_below)) & 127u] = make_uint2(c + lane, w);
+                tail += (uint32_t)__popcll(m);
+                if (tail - head >= 64u) {
+                    if (have) work(w_p, raw_p);
+                    request(64u);
+                }
+            }
+        }
+        if (have) work(w_p, raw_p);
+        have = false;
+        if (tail != head) {
+            request(tail - head);
+            work(w_p, raw_p);
         }
     }
 }
