@@ -445,3 +445,37 @@ def test_small_batches_build_their_lists_in_the_raster_kernel(gpu_ctx, oracle):
     big = display_list.concat(tiles + [tile(3) for _ in range(62)])  # 70 tiles: every tile has lists
     got_big = assert_parity(gpu_ctx, oracle, big, f64_jobs=[5, 6], msg="the same tiles with lists")
     assert np.array_equal(got_small, got_big[: len(tiles)])
+
+
+@pytest.mark.parametrize("hits", [1, 63, 64, 65, 127, 128, 129, 200])
+def test_sublist_sift_ring_boundaries(gpu_ctx, oracle, hits):
+    """k_sublist (round 6) sifts a tile's ops per sub-tile ROW into a 128-entry ring in LDS — the ops that draw into the row, in op
+    order — and builds the row's eight lists from 64 sifted ops at a time.  A tile whose row 2 is hit by exactly `hits` ops (one
+    fewer, exactly and one more than a batch and than the ring), scattered among ops that draw elsewhere or nowhere, in a batch of
+    more than 64 tiles (smaller batches build their lists in k_raster<FOLD>); a second tile piles the same ops into one column."""
+    from osm_renderer_amd.display_list import concat
+
+    rnd = np.random.default_rng(900 + hits)
+    tiles = []
+    for variant in range(2):
+        tb = TileBuilder(x=variant, canvas=(245, 240, 230))
+        n_total = hits * 3 + 40
+        chosen = set(rnd.choice(n_total, size=hits, replace=False).tolist())
+        for i in range(n_total):
+            col = tuple(int(v) for v in rnd.integers(0, 256, size=3))
+            if i in chosen:  # inside sub-tile row 2 (y in 32..47): a short thin stroke or a small box
+                x = int(rnd.integers(4, 250)) if variant == 0 else int(rnd.integers(70, 90))
+                y = int(rnd.integers(35, 45))
+                if i % 3:
+                    tb.stroke([(x, y), (x + int(rnd.integers(2, 6)), y + int(rnd.integers(-1, 2)))], 1.0, col, 0.7)
+                else:
+                    tb.fill([[(x, y - 1), (x + 3, y - 1), (x + 3, y + 2), (x, y + 2), (x, y - 1)]], col, 0.5)
+            elif i % 4 == 0:
+                tb.nop()
+            else:  # far from row 2 (rows 5 and below), or outside the tile altogether
+                x, y = int(rnd.integers(4, 250)), int(rnd.integers(90, 250)) if i % 4 != 3 else int(rnd.integers(300, 400))
+                tb.stroke([(x, y), (x + 4, y + 1)], 1.0, col, 0.9)
+        tiles.append(tb.build())
+    empty = TileBuilder(x=9, canvas=(1, 2, 3)).build()
+    dl = concat(tiles + [empty] * 64)  # 66 tiles: every tile's lists come from k_sublist
+    assert_parity(gpu_ctx, oracle, dl, f64_jobs=[0, 1], msg=f"{hits} ops in one sub-tile row")
